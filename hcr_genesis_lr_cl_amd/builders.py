@@ -1,0 +1,163 @@
+"""cfg + RobotModel -> the C-ABI structs (LgModelDesc / LgSimOptions / LgTaskCfg).
+
+Each derived constant cites where the reference derives the same number.
+"""
+from __future__ import annotations
+
+import math
+
+import numpy as np
+
+from . import abi
+from . import config as cfgmod
+
+
+def make_model_desc(model, cfg):
+    """Link-index sets by substring match, genesis_simulator.py:333-363."""
+    term = model.find_link_indices(cfg.asset.terminate_after_contacts_on)
+    pen = model.find_link_indices(cfg.asset.penalize_contacts_on)
+    state = model.find_link_indices(cfg.asset.contact_state_link_names) if cfg.asset.obtain_link_contact_states else []
+    return abi.model_desc(model, term, pen, state)
+
+
+def make_sim_options(model, cfg, terrain=None):
+    o = abi.LgSimOptions()
+    o.dt = cfg.sim.dt
+    o.decimation = cfg.control.decimation
+    o.gravity_z = -9.81  # engine default, identical to cfg.sim.gravity (legged_robot_config.py:254)
+    o.contact_k, o.contact_b = cfg.hip.contact_stiffness, cfg.hip.contact_damping
+    o.terrain_friction = cfg.terrain.static_friction  # genesis_simulator.py:276
+    o.limit_k, o.limit_b = cfg.hip.joint_limit_stiffness, cfg.hip.joint_limit_damping
+    o.contact_iters = cfg.hip.contact_iters
+    o.contact_margin, o.limit_margin = cfg.hip.contact_margin, cfg.hip.limit_margin
+    o.max_base_lin_vel, o.max_base_ang_vel = cfg.hip.max_base_lin_vel, cfg.hip.max_base_ang_vel
+    o.joint_vel_clamp = cfg.hip.joint_vel_clamp
+    o.action_scale = cfg.control.action_scale
+    kp, kd = cfgmod.pd_gains(cfg)
+    abi.fill_array(o.kp, kp)
+    abi.fill_array(o.kd, kd)
+    abi.fill_array(o.default_dof_pos, cfgmod.default_dof_pos(cfg))
+    abi.fill_array(o.base_init_pos, cfg.init_state.pos)
+    bx, by = cfgmod.terrain_bounds(cfg)
+    abi.fill_array(o.bound_x, bx)
+    abi.fill_array(o.bound_y, by)
+    if terrain is not None:
+        o.terrain_rows, o.terrain_cols = int(terrain.tot_rows), int(terrain.tot_cols)
+    o.hscale, o.vscale, o.border = cfg.terrain.horizontal_scale, cfg.terrain.vertical_scale, cfg.terrain.border_size
+    if cfg.terrain.measure_heights and cfg.terrain.mesh_type != "plane":
+        o.n_height_points = len(cfg.terrain.measured_points_x) * len(cfg.terrain.measured_points_y)
+        o.feet_terrain_info = int(bool(cfg.terrain.obtain_terrain_info_around_feet))
+    return o
+
+
+def go2_noise_vec(cfg):
+    """go2.py:92-117 for the 45-wide frame."""
+    ns, lvl, sc = cfg.noise.noise_scales, cfg.noise.noise_level, cfg.normalization.obs_scales
+    v = np.zeros(45, np.float32)
+    v[3:6] = ns.gravity * lvl
+    v[6:9] = ns.ang_vel * lvl * sc.ang_vel
+    v[9:21] = ns.dof_pos * lvl * sc.dof_pos
+    v[21:33] = ns.dof_vel * lvl * sc.dof_vel
+    return v
+
+
+def go2_slots(A=12, obs_frame=45):
+    s = abi.LgRandSlots()
+    off = 0
+    for name, w in (("cb_cmd", 3), ("push", 2), ("reset_cmd", 3), ("reset_dof", A), ("reset_root_xy", 2),
+                    ("reset_lin_vel", 3), ("reset_ang_vel", 3), ("dr_friction", 1), ("dr_mass", 1), ("dr_com", 3),
+                    ("dr_kp", A), ("dr_kd", A), ("dr_joint", 3), ("terrain_level", 1), ("task", 8),
+                    ("noise", obs_frame)):
+        setattr(s, name, off)
+        off += w
+    s.n_slots = off
+    return s
+
+
+def _span(lo, hi):
+    # torch_rand_float (math_utils.py:79-81): (upper - lower) * rand + lower, scalars cast to f32
+    return np.float32(lo), np.float32(hi - lo)
+
+
+def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
+    t = abi.LgTaskCfg()
+    dt = cfgmod.control_dt(cfg)
+    layout = cfg.reset.obs_layout
+    A = model.n_dof
+    t.obs_layout = {"go2": abi.OBS_GO2, "go2_wtw": abi.OBS_GO2_WTW, "go2_ee": abi.OBS_GO2_EE,
+                    "tron1_ee": abi.OBS_TRON1_EE}[layout]
+    if layout == "go2":
+        t.num_obs, t.obs_frame, t.obs_stack = 45, 45, 1
+        t.num_priv_obs = t.priv_frame = t.priv_stack = 0
+        abi.fill_array(t.noise_vec, go2_noise_vec(cfg))
+        t.slots = go2_slots(A, 45)
+    else:
+        raise NotImplementedError(layout)
+    t.control_dt = dt
+    t.clip_actions = cfg.normalization.clip_actions
+    t.clip_obs = cfg.normalization.clip_observations
+    t.max_episode_length = cfgmod.max_episode_length(cfg)
+    t.fail_threshold = cfg.env.fail_to_terminal_time_s / dt          # legged_robot.py:90
+    t.max_projected_gravity = cfg.rewards.max_projected_gravity
+    t.resample_steps = int(cfg.commands.resampling_time / dt)        # legged_robot.py:305
+    t.push_interval = int(np.ceil(cfg.domain_rand.push_interval_s / dt)) if cfg.domain_rand.push_robots else 0
+    t.max_push_vel_xy = cfg.domain_rand.max_push_vel_xy
+    t.heading_command = int(cfg.commands.heading_command)
+    abi.fill_array(t.yaw_clip, cfg.commands.ranges.ang_vel_yaw)
+    scales = np.zeros(abi.NUM_REWARDS, np.float32)
+    for name, s in cfgmod.reward_scales_sorted(cfg).items():
+        if name not in abi.REWARD_ID:
+            raise NotImplementedError(f"reward term {name!r} has no kernel implementation")
+        scales[abi.REWARD_ID[name]] = s * dt                          # legged_robot.py:421 (python float math)
+    abi.fill_array(t.reward_scales, scales)
+    r = cfg.rewards
+    t.only_positive_rewards = int(r.only_positive_rewards)
+    t.tracking_sigma, t.base_height_target = r.tracking_sigma, r.base_height_target
+    t.foot_clearance_target, t.foot_height_offset = r.foot_clearance_target, r.foot_height_offset
+    t.foot_clearance_sigma = r.foot_clearance_tracking_sigma
+    t.about_landing_threshold = getattr(r, "about_landing_threshold", 0.0)
+    t.feet_air_time_threshold = cfg.reset.feet_air_time_threshold
+    t.base_height_sigma = getattr(r, "base_height_tracking_sigma", 0.01)
+    t.euler_sigma = getattr(r, "euler_tracking_sigma", 0.1)
+    t.foot_distance_threshold = getattr(r, "foot_distance_threshold", 0.0)
+    sc = cfg.normalization.obs_scales
+    t.obs_scale_lin_vel, t.obs_scale_ang_vel = sc.lin_vel, sc.ang_vel
+    t.obs_scale_dof_pos, t.obs_scale_dof_vel, t.obs_scale_height = sc.dof_pos, sc.dof_vel, sc.height_measurements
+    t.add_noise = int(cfg.noise.add_noise)
+    # reset distribution: go2.py:17-37 (additive per joint type), go2.py:119-134
+    lo, span = np.zeros(A, np.float32), np.zeros(A, np.float32)
+    for i, dn in enumerate(cfg.asset.dof_names):
+        for key, rng in cfg.reset.dof_ranges.items():
+            if key in dn:
+                lo[i], span[i] = _span(-rng, rng)
+    abi.fill_array(t.reset_dof_lo, lo)
+    abi.fill_array(t.reset_dof_span, span)
+    t.reset_root_xy_lo, t.reset_root_xy_span = _span(-0.5, 0.5)        # legged_robot.py:288
+    t.custom_origins = int(cfg.terrain.mesh_type in ("heightfield", "trimesh"))
+    rv = cfg.reset.root_vel_range
+    t.reset_lin_vel_lo, t.reset_lin_vel_span = _span(-rv, rv)
+    t.reset_ang_vel_lo, t.reset_ang_vel_span = _span(-rv, rv)
+    abi.fill_array(t.base_init_quat, cfg.init_state.rot)
+    d = cfg.domain_rand
+    t.dr_friction_on, t.dr_mass_on, t.dr_com_on = int(d.randomize_friction), int(d.randomize_base_mass), int(d.randomize_com_displacement)
+    t.dr_pd_on = int(d.randomize_pd_gain)
+    t.dr_joint_on = int(d.randomize_joint_armature or d.randomize_joint_friction or d.randomize_joint_damping)
+    t.dr_friction_lo, t.dr_friction_span = _span(*d.friction_range)
+    t.dr_mass_lo, t.dr_mass_span = _span(*d.added_mass_range)
+    for i, rg in enumerate((d.com_pos_x_range, d.com_pos_y_range, d.com_pos_z_range)):
+        t.dr_com_lo[i], t.dr_com_span[i] = _span(*rg)
+    t.dr_kp_lo, t.dr_kp_span = _span(*d.kp_range)
+    t.dr_kd_lo, t.dr_kd_span = _span(*d.kd_range)
+    for i, rg in enumerate((d.joint_armature_range, d.joint_friction_range, d.joint_damping_range)):
+        t.dr_joint_lo[i], t.dr_joint_span[i] = _span(*rg)
+    t.friction_offset = (d.friction_range[0] + d.friction_range[1]) / 2  # legged_robot.py:448-453
+    t.kp_offset = (d.kp_range[0] + d.kp_range[1]) / 2
+    t.kd_offset = (d.kd_range[0] + d.kd_range[1]) / 2
+    t.terrain_curriculum = int(cfg.terrain.curriculum and t.custom_origins)  # legged_robot.py:443-444
+    t.max_terrain_level = cfg.terrain.num_rows
+    t.terrain_cols_n = cfg.terrain.num_cols
+    t.terrain_env_length = cfg.terrain.terrain_length
+    t.episode_length_s = cfg.env.episode_length_s
+    t.seed = int(cfg.hip.seed if seed is None else seed)
+    t.env_id_offset = int(env_id_offset)
+    return t

@@ -1,0 +1,209 @@
+"""Configuration tree with the attribute names the reference's env/simulator code reads.
+
+The reference keeps its configs as nested Python classes instantiated recursively
+(legged_gym/envs/base/base_config.py:3-25, legged_robot_config.py, common_cfgs.py,
+go2/go2_config.py).  Task code addresses them as ``cfg.<section>.<field>``; this module
+offers the same addressing for the tasks in scope, declared with a small ``section`` helper
+instead of class bodies.  Values are the reference's (file:line cited per block).
+
+``cfg = GO2Cfg()`` gives an independent instance: every section is copied so that editing
+``cfg.env.num_envs`` does not leak into other instances (base_config.py:20-25).
+"""
+from __future__ import annotations
+
+import copy
+import math
+
+import numpy as np
+
+
+class Section:
+    """Bag of attributes; nested sections are Section subclasses."""
+
+    def __init__(self):
+        for k in dir(type(self)):
+            if k.startswith("__"):
+                continue
+            v = getattr(type(self), k)
+            if isinstance(v, type) and issubclass(v, Section):
+                setattr(self, k, v())
+            elif isinstance(v, (list, dict)):
+                setattr(self, k, copy.deepcopy(v))
+
+    def to_dict(self):
+        """Sorted-key dict, nested (reference helpers.py:10-25 iterates dir() => alphabetical)."""
+        out = {}
+        for k in sorted(dir(self)):
+            if k.startswith("_") or k == "to_dict":
+                continue
+            v = getattr(self, k)
+            if callable(v) and not isinstance(v, Section):
+                continue
+            out[k] = v.to_dict() if isinstance(v, Section) else v
+        return out
+
+
+def section(*bases, **fields):
+    bases = tuple(b for b in bases) or (Section,)
+    return type("section", bases, dict(fields))
+
+
+# ---------------------------------------------------------------------------------------------
+# legged_robot_config.py:3-262 (defaults) -- only fields the hot path reads
+class LeggedRobotCfg(Section):
+    env = section(
+        num_envs=4096, num_observations=48, num_privileged_obs=None, num_actions=12,
+        send_timeouts=True, episode_length_s=20, env_spacing=1.0, fail_to_terminal_time_s=0.1, debug=False)
+    terrain = section(
+        mesh_type="plane", plane_length=200.0, horizontal_scale=0.1, vertical_scale=0.005,
+        border_size=5, border_height=1.0, curriculum=False, static_friction=1.0, dynamic_friction=1.0,
+        restitution=0.0, obtain_terrain_info_around_feet=False, measure_heights=False,
+        measured_points_x=[round(-0.8 + 0.1 * i, 1) for i in range(17)],
+        measured_points_y=[round(-0.5 + 0.1 * i, 1) for i in range(11)],
+        selected=False, terrain_kwargs=None, max_init_terrain_level=1,
+        terrain_length=6.0, terrain_width=6.0, platform_size=3.0, num_rows=4, num_cols=4,
+        terrain_proportions=[0.1, 0.1, 0.35, 0.25, 0.2], slope_treshold=0.75)
+    init_state = section(
+        pos=[0.0, 0.0, 1.0], rot=[0.0, 0.0, 0.0, 1.0], lin_vel=[0.0, 0.0, 0.0], ang_vel=[0.0, 0.0, 0.0],
+        default_joint_angles={"joint_a": 0.0, "joint_b": 0.0})
+    control = section(
+        control_type="P", stiffness={"joint_a": 10.0, "joint_b": 15.0}, damping={"joint_a": 1.0, "joint_b": 1.5},
+        action_scale=0.5, dt=0.02, decimation=4)
+    asset = section(
+        name=None, file="", foot_name="", penalize_contacts_on=[], terminate_after_contacts_on=[],
+        fix_base_link=False, obtain_link_contact_states=False, contact_state_link_names=["thigh", "calf", "foot"],
+        base_link_name="", self_collisions=0, dof_names=["joint_a", "joint_b"], links_to_keep=[],
+        dof_vel_limits=[])
+    rewards = section(
+        scales=section(
+            termination=-0.0, tracking_lin_vel=0, tracking_ang_vel=0, lin_vel_z=0, ang_vel_xy=0, orientation=-0.0,
+            torques=0, dof_vel=-0.0, dof_acc=0, base_height=-0.0, feet_air_time=0, collision=0, feet_stumble=-0.0,
+            action_rate=0, dof_pos_stand_still=-0.0),
+        only_positive_rewards=True, tracking_sigma=0.25, soft_dof_pos_limit=1.0, soft_dof_vel_limit=1.0,
+        soft_torque_limit=1.0, base_height_target=1.0, foot_clearance_target=0.04, foot_height_offset=0.0,
+        foot_clearance_tracking_sigma=0.01, max_projected_gravity=-0.1)
+    commands = section(
+        curriculum=False, max_curriculum=1.0, num_commands=4, resampling_time=10.0, heading_command=True,
+        curriculum_threshold=0.8,
+        ranges=section(lin_vel_x=[-1.0, 1.0], lin_vel_y=[-1.0, 1.0], ang_vel_yaw=[-1, 1], heading=[-3.14, 3.14]))
+    domain_rand = section(
+        randomize_friction=True, friction_range=[0.5, 1.25], randomize_base_mass=True, added_mass_range=[-1.0, 1.0],
+        push_robots=True, push_interval_s=15, max_push_vel_xy=1.0,
+        randomize_com_displacement=True, com_pos_x_range=[-0.01, 0.01], com_pos_y_range=[-0.01, 0.01],
+        com_pos_z_range=[-0.01, 0.01], randomize_ctrl_delay=False, ctrl_delay_step_range=[0, 1],
+        randomize_pd_gain=False, kp_range=[0.8, 1.2], kd_range=[0.8, 1.2],
+        randomize_joint_armature=False, joint_armature_range=[0.0, 0.05],
+        randomize_joint_friction=False, joint_friction_range=[0.0, 0.1],
+        randomize_joint_damping=False, joint_damping_range=[0.0, 1.0])
+    normalization = section(
+        obs_scales=section(lin_vel=1.0, ang_vel=0.25, dof_pos=1.0, dof_vel=0.05, height_measurements=5.0),
+        clip_observations=100.0, clip_actions=100.0)
+    noise = section(
+        add_noise=True, noise_level=1.0,
+        noise_scales=section(dof_pos=0.01, dof_vel=0.5, lin_vel=0.1, ang_vel=0.2, gravity=0.05, height_measurements=0.1))
+    sensor = section(add_depth=False)
+    viewer = section(ref_env=0, pos=[4.0, 4.0, 2.0], lookat=[0.0, 0.0, 0.0])
+    sim = section(dt=0.005, substeps=1, max_collision_pairs=100, IK_max_targets=2, gravity=[0.0, 0.0, -9.81])
+    # engine constants of this backend (no counterpart in the reference: Genesis' soft-constraint
+    # parameters are internal to genesis-world).  See DESIGN.md "Contact model".
+    hip = section(contact_stiffness=4.0e4, contact_damping=4.0e2, joint_limit_stiffness=5.0e3,
+                  joint_limit_damping=5.0e1, contact_iters=3, contact_margin=0.02, limit_margin=0.2,
+                  max_base_lin_vel=50.0, max_base_ang_vel=40.0, joint_vel_clamp=2.0, seed=1)
+
+
+_GO2_LEGS = ("FR", "FL", "RR", "RL")  # policy order, common_cfgs.py:52-65
+
+
+# common_cfgs.py:10-71 (Go2FlatCommonCfg) + go2/go2_config.py:5-78 (GO2Cfg)
+class GO2Cfg(LeggedRobotCfg):
+    env = section(LeggedRobotCfg.env, num_envs=4096, num_observations=45, num_privileged_obs=None, num_actions=12)
+    terrain = section(LeggedRobotCfg.terrain, mesh_type="plane")
+    init_state = section(
+        LeggedRobotCfg.init_state, pos=[0.0, 0.0, 0.42],
+        default_joint_angles={f"{leg}_{j}_joint": a for leg in ("FL", "RL", "FR", "RR")
+                              for j, a in (("hip", 0.0), ("thigh", 0.8), ("calf", -1.5))})
+    control = section(LeggedRobotCfg.control, stiffness={"joint": 20.0}, damping={"joint": 0.5},
+                      action_scale=0.25, dt=0.02, decimation=4)
+    asset = section(
+        LeggedRobotCfg.asset, name="go2", file="{LEGGED_GYM_ROOT_DIR}/resources/robots/go2/urdf/go2.urdf",
+        foot_name="foot", penalize_contacts_on=["thigh", "calf"], terminate_after_contacts_on=["base", "Head"],
+        base_link_name="base", dof_names=[f"{leg}_{j}_joint" for leg in _GO2_LEGS for j in ("hip", "thigh", "calf")],
+        links_to_keep=["FL_foot", "FR_foot", "RL_foot", "RR_foot"],
+        dof_vel_limits=[30.1, 30.1, 15.7] * 4)
+    rewards = section(
+        LeggedRobotCfg.rewards, soft_dof_pos_limit=0.9, base_height_target=0.36, foot_clearance_target=0.05,
+        foot_height_offset=0.022, foot_clearance_tracking_sigma=0.01, only_positive_rewards=True,
+        scales=section(
+            LeggedRobotCfg.rewards.scales, dof_pos_limits=-1.0, collision=-1.0, tracking_lin_vel=1.0,
+            tracking_ang_vel=0.5, lin_vel_z=-0.5, base_height=-2.0, ang_vel_xy=-0.05, orientation=-1.0,
+            dof_vel=-5.0e-4, dof_acc=-2.0e-7, action_rate=-0.01, action_smoothness=-0.01, torques=-2.0e-4,
+            feet_air_time=1.0, foot_clearance=0.5))
+    commands = section(
+        LeggedRobotCfg.commands, curriculum=True, max_curriculum=1.0, num_commands=4, resampling_time=10.0,
+        heading_command=True,
+        ranges=section(LeggedRobotCfg.commands.ranges, lin_vel_x=[-0.5, 0.5], lin_vel_y=[-1.0, 1.0],
+                       ang_vel_yaw=[-1, 1], heading=[-3.14, 3.14]))
+    domain_rand = section(
+        LeggedRobotCfg.domain_rand, randomize_friction=True, friction_range=[0.5, 1.25],
+        randomize_base_mass=True, added_mass_range=[-1.0, 1.0], push_robots=True, push_interval_s=15,
+        max_push_vel_xy=1.0, randomize_com_displacement=True, com_pos_x_range=[-0.01, 0.01],
+        com_pos_y_range=[-0.01, 0.01], com_pos_z_range=[-0.01, 0.01])
+    # task specifics the reference hard-codes in go2.py:17-37,131-133
+    reset = section(dof_ranges={"hip": 0.2, "thigh": 0.4, "calf": 0.4}, root_vel_range=0.0, robot="go2",
+                    obs_layout="go2", feet_air_time_threshold=0.3)
+
+
+def class_to_dict(obj):
+    """helpers.py:10-25 equivalent for Section trees / plain objects."""
+    if isinstance(obj, Section):
+        return obj.to_dict()
+    if not hasattr(obj, "__dict__"):
+        return obj
+    return {k: class_to_dict(getattr(obj, k)) for k in sorted(dir(obj)) if not k.startswith("_")}
+
+
+def reward_scales_sorted(cfg):
+    """name -> raw scale (before the x dt of legged_robot.py:416-421), alphabetical, zeros dropped."""
+    d = class_to_dict(cfg.rewards.scales)
+    return {k: float(v) for k, v in sorted(d.items()) if float(v) != 0.0}
+
+
+def control_dt(cfg):
+    return cfg.sim.dt * cfg.control.decimation
+
+
+def max_episode_length(cfg):
+    return float(np.ceil(cfg.env.episode_length_s / control_dt(cfg)))  # legged_robot.py:446
+
+
+def pd_gains(cfg):
+    """genesis_simulator.py:476-486: first stiffness key that is a substring of the dof name."""
+    kp, kd = [], []
+    for dn in cfg.asset.dof_names:
+        for key in cfg.control.stiffness.keys():
+            if key in dn:
+                kp.append(cfg.control.stiffness[key])
+                kd.append(cfg.control.damping[key])
+    return np.array(kp, np.float32), np.array(kd, np.float32)
+
+
+def default_dof_pos(cfg):
+    return np.array([cfg.init_state.default_joint_angles[n] for n in cfg.asset.dof_names], np.float32)
+
+
+def terrain_bounds(cfg):
+    """genesis_simulator.py:278-294."""
+    t = cfg.terrain
+    if t.mesh_type in ("heightfield", "trimesh"):
+        return ((-t.border_size + 1.0, t.border_size + t.num_rows * t.terrain_length - 1.0),
+                (-t.border_size + 1.0, t.border_size + t.num_cols * t.terrain_width - 1.0))
+    return ((-t.plane_length / 2 + 1, t.plane_length / 2 - 1),) * 2
+
+
+def soft_dof_limits(model, cfg):
+    """genesis_simulator.py:373-382."""
+    lo, hi = model.arrays["q_lo"].astype(np.float32), model.arrays["q_hi"].astype(np.float32)
+    m = (lo + hi) / 2
+    r = hi - lo
+    s = np.float32(cfg.rewards.soft_dof_pos_limit)
+    return np.stack([m - np.float32(0.5) * r * s, m + np.float32(0.5) * r * s], axis=1).astype(np.float32)

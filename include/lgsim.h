@@ -1,0 +1,259 @@
+/* lgsim.h -- C ABI of the MI355X-native legged-locomotion environment engine.
+ *
+ * This is the boundary a maintainer of the reference (LeggedGym-Ex,
+ * oscar-youngquist/HCR_Genesis_LR_CL) binds with ctypes to obtain a
+ * `SIMULATOR=hip` backend.  Every entry point replaces a piece of the
+ * reference's Python/Genesis path; the reference file:line each one stands in
+ * for is cited next to it.  No torch types cross this boundary: plain device
+ * pointers, sizes, and the caller's HIP stream (as void*).
+ *
+ * Ownership: the caller (PyTorch on the Python side) owns every per-env buffer
+ * named in LgBuffers; the library allocates only the small per-handle constant
+ * tables (model, options, task config).  All buffers are float32 row-major
+ * (N, ...) unless stated otherwise; quaternions are xyzw (reference
+ * legged_gym/envs/base/legged_robot_config.py:59-61).
+ *
+ * Error convention: every call returns 0 on success, non-zero on failure;
+ * lg_last_error() returns a thread-local message (reference raises Python
+ * exceptions: genesis_simulator.py:271,275,356).  Kernel launch errors surface
+ * on the call that enqueued them (hipGetLastError after launch).
+ */
+#ifndef LGSIM_H
+#define LGSIM_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LG_JPL 3          /* joints per leg (serial chain) */
+#define LG_MAX_LEGS 4
+#define LG_MAX_DOF 12
+#define LG_MAX_BODIES 13  /* floating base + one body per dof */
+#define LG_MAX_LINKS 24   /* reported links (bodies + kept fixed links such as feet) */
+#define LG_MAX_SPHERES 64
+#define LG_MAX_OBS 192    /* widest single observation frame handled in-kernel */
+#define LG_NUM_REWARDS 40
+#define LG_CMD_RANGE_FLOATS 8
+
+/* ---- robot model (output of hcr_genesis_lr_cl_amd/model_compiler.py) -------------------
+ * Stands in for gs.morphs.URDF(merge_fixed_links=True, links_to_keep=feet)
+ * (genesis_simulator.py:303-313).  Body 0 is the floating base, body 1+d carries dof d
+ * (policy order, cfg.asset.dof_names); leg l owns dofs 3l..3l+2. */
+typedef struct LgModelDesc {
+    int32_t n_legs, n_bodies, n_links, n_spheres;
+    float mass[LG_MAX_BODIES];
+    float com[LG_MAX_BODIES][3];      /* body frame */
+    float inertia[LG_MAX_BODIES][6];  /* about com, body axes: xx yy zz xy xz yz */
+    float jpos[LG_MAX_BODIES][3];     /* joint origin in parent body frame */
+    float jrot[LG_MAX_BODIES][9];     /* child->parent rotation at q=0, row-major */
+    float axis[LG_MAX_BODIES][3];     /* unit joint axis, child frame */
+    float q_lo[LG_MAX_DOF], q_hi[LG_MAX_DOF], effort[LG_MAX_DOF], vel_limit[LG_MAX_DOF];
+    float armature[LG_MAX_DOF], damping[LG_MAX_DOF], frictionloss[LG_MAX_DOF];
+    int32_t link_body[LG_MAX_LINKS];  /* body each reported link moves with */
+    float link_pos[LG_MAX_LINKS][3];  /* link frame origin in that body's frame */
+    int32_t sph_body[LG_MAX_SPHERES], sph_link[LG_MAX_SPHERES];
+    float sph_pos[LG_MAX_SPHERES][3]; /* body frame */
+    float sph_r[LG_MAX_SPHERES];
+    float sph_w[LG_MAX_SPHERES];      /* conservative point inverse mass [1/kg] */
+    int32_t body_sph_start[LG_MAX_BODIES + 1];
+    int32_t foot_link[LG_MAX_LEGS], foot_sphere[LG_MAX_LEGS];
+    uint32_t term_link_mask;          /* links whose |F|>10 terminates (legged_robot.py:81-83) */
+    uint32_t pen_link_mask;           /* links counted by _reward_collision (legged_robot.py:505-512) */
+    uint32_t state_link_mask;         /* links reported in link_contact_states (genesis_simulator.py:53-55) */
+} LgModelDesc;
+
+/* ---- physics options: gs.options.SimOptions/RigidOptions (genesis_simulator.py:231-257)
+ * plus the PD law of _compute_torques (genesis_simulator.py:630-642). */
+typedef struct LgSimOptions {
+    float dt;              /* physics sub-step, cfg.sim.dt = 0.005 */
+    int32_t decimation;    /* cfg.control.decimation = 4 */
+    float gravity_z;       /* -9.81 */
+    float contact_k;       /* penalty normal stiffness  [N/m] */
+    float contact_b;       /* penalty normal damping    [N s/m] */
+    float terrain_friction;/* cfg.terrain.static_friction (genesis_simulator.py:276) */
+    float limit_k;         /* joint-limit stop stiffness [N m/rad] */
+    float limit_b;         /* joint-limit stop damping   [N m s/rad] */
+    int32_t contact_iters; /* block-Jacobi sweeps over the feet (>=1) */
+    float contact_margin;  /* [m]  gap below which an approaching sphere is already decelerated */
+    float limit_margin;    /* [rad] same for joint-limit stops */
+    /* velocity sanitisation (the reference's asset options carry max_angular_velocity /
+     * max_linear_velocity = 1000, legged_robot_config.py:110-111; here tighter so that
+     * omega*dt stays inside the explicit integrator's stable range) */
+    float max_base_lin_vel, max_base_ang_vel, joint_vel_clamp; /* joint: multiple of URDF velocity limit */
+    float action_scale;    /* cfg.control.action_scale */
+    float kp[LG_MAX_DOF], kd[LG_MAX_DOF];
+    float default_dof_pos[LG_MAX_DOF];
+    float base_init_pos[3];
+    float bound_x[2], bound_y[2]; /* out-of-terrain teleport box (genesis_simulator.py:278-294,612-628) */
+    /* heightfield (genesis_simulator.py:765-778); mesh_type plane => terrain_rows = 0 */
+    int32_t terrain_rows, terrain_cols;
+    float hscale, vscale, border;
+    /* height sampling grid around the base (genesis_simulator.py:496-507,552-577) */
+    int32_t n_height_points;   /* 0 = measure_heights off */
+    int32_t feet_terrain_info; /* cfg.terrain.obtain_terrain_info_around_feet */
+} LgSimOptions;
+
+/* ---- reward term ids, in the alphabetical order the reference evaluates them
+ * (legged_gym/utils/helpers.py:10-25 class_to_dict iterates dir() => sorted names;
+ *  legged_robot.py:411-434).  scale 0 => term inactive. */
+enum LgReward {
+    LG_R_ACTION_RATE = 0, LG_R_ACTION_SMOOTHNESS, LG_R_ANG_VEL_XY, LG_R_BASE_HEIGHT,
+    LG_R_BIPED_PERIODIC_GAIT, LG_R_COLLISION, LG_R_DOF_ACC, LG_R_DOF_CLOSE_TO_DEFAULT,
+    LG_R_DOF_POS_LIMITS, LG_R_DOF_POS_STAND_STILL, LG_R_DOF_POWER, LG_R_DOF_VEL,
+    LG_R_DOF_VEL_STAND_STILL, LG_R_FEET_AIR_TIME, LG_R_FEET_CONTACT_STAND_STILL,
+    LG_R_FEET_DISTANCE, LG_R_FOOT_ACC, LG_R_FOOT_CLEARANCE, LG_R_FOOT_LANDING_VEL,
+    LG_R_HIP_POS, LG_R_KEEP_BALANCE, LG_R_LIN_VEL_Z, LG_R_ORIENTATION,
+    LG_R_QUAD_PERIODIC_GAIT, LG_R_TORQUES, LG_R_TRACKING_ANG_VEL, LG_R_TRACKING_BASE_HEIGHT,
+    LG_R_TRACKING_FOOT_CLEARANCE, LG_R_TRACKING_LIN_VEL, LG_R_TRACKING_ORIENTATION,
+    LG_R_TERMINATION, /* added after the positive clip (legged_robot.py:163-168) */
+    LG_R_COUNT
+};
+
+/* observation layouts (reference compute_observations overrides) */
+enum LgObsLayout {
+    LG_OBS_GO2 = 0,      /* go2.py:40-56        45 */
+    LG_OBS_GO2_WTW = 1,  /* go2_wtw.py:53-111   61x5 / 99x5 */
+    LG_OBS_GO2_EE = 2,   /* go2_ee.py:10-75     45x20 / 174x5 / 24 labels */
+    LG_OBS_TRON1_EE = 3  /* tron1_pf_ee.py:53-141 31x10 / 134x10 / 17 labels */
+};
+
+/* uniform-draw slot layout: every random number the reference draws per env per step has a
+ * fixed slot so that tests can inject the reference's own draws (rand_in) and the Philox
+ * stream is independent of which envs reset.  Slots are offsets into a per-env row. */
+typedef struct LgRandSlots {
+    int32_t n_slots;        /* row width of rand_in */
+    int32_t cb_cmd;         /* 3: lin_vel_x, lin_vel_y, heading|yaw  (legged_robot.py:317-330) */
+    int32_t push;           /* 2: push vel xy (genesis_simulator.py:150-158) */
+    int32_t reset_cmd;      /* 3 */
+    int32_t reset_dof;      /* A  (go2.py:17-37) */
+    int32_t reset_root_xy;  /* 2  (legged_robot.py:288) */
+    int32_t reset_lin_vel;  /* 3 */
+    int32_t reset_ang_vel;  /* 3 */
+    int32_t dr_friction;    /* 1 (genesis_simulator.py:665-675) */
+    int32_t dr_mass;        /* 1 */
+    int32_t dr_com;         /* 3 */
+    int32_t dr_kp;          /* A */
+    int32_t dr_kd;          /* A */
+    int32_t dr_joint;       /* 3: armature, frictionloss, damping */
+    int32_t terrain_level;  /* 1: randint for solved-last-level envs (genesis_simulator.py:143-146) */
+    int32_t task;           /* task specific block (wtw behaviour params ...) */
+    int32_t noise;          /* obs_frame floats: observation noise (go2.py:62-64) */
+} LgRandSlots;
+
+/* ---- MDP constants: everything LeggedRobot._parse_cfg/_init_buffers/_prepare_reward_function
+ * derive from the cfg (legged_robot.py:380-455) plus the task overrides. */
+typedef struct LgTaskCfg {
+    int32_t obs_layout;
+    int32_t num_obs, num_priv_obs;   /* total widths written per env (0 = none) */
+    int32_t obs_frame, priv_frame;   /* single-frame widths */
+    int32_t obs_stack, priv_stack;   /* history lengths */
+    float control_dt;                /* dt * decimation */
+    float clip_actions, clip_obs;
+    float max_episode_length;        /* ceil(episode_length_s / dt) as float (legged_robot.py:446) */
+    float fail_threshold;            /* fail_to_terminal_time_s / dt (legged_robot.py:90) */
+    float max_projected_gravity;
+    int32_t resample_steps;          /* int(resampling_time / dt) (legged_robot.py:305) */
+    int32_t push_interval;           /* ceil(push_interval_s / dt); 0 = no pushes */
+    float max_push_vel_xy;
+    int32_t heading_command;
+    float yaw_clip[2];               /* commands.ranges.ang_vel_yaw */
+    float reward_scales[LG_NUM_REWARDS]; /* already multiplied by dt (legged_robot.py:416-421) */
+    int32_t only_positive_rewards;
+    float tracking_sigma, base_height_target, foot_clearance_target, foot_height_offset;
+    float foot_clearance_sigma, about_landing_threshold, feet_air_time_threshold;
+    float base_height_sigma, euler_sigma, foot_distance_threshold;
+    float obs_scale_lin_vel, obs_scale_ang_vel, obs_scale_dof_pos, obs_scale_dof_vel, obs_scale_height;
+    int32_t add_noise;
+    float noise_vec[LG_MAX_OBS];     /* _get_noise_scale_vec (go2.py:92-117) */
+    /* reset distribution */
+    float reset_dof_lo[LG_MAX_DOF], reset_dof_span[LG_MAX_DOF]; /* q0 + lo + span*u (go2.py:30-35) */
+    float reset_root_xy_lo, reset_root_xy_span; int32_t custom_origins;
+    float reset_lin_vel_lo, reset_lin_vel_span, reset_ang_vel_lo, reset_ang_vel_span;
+    float base_init_quat[4];
+    /* domain randomisation (genesis_simulator.py:62-82, 665-739); span 0 & flag 0 = off */
+    int32_t dr_friction_on, dr_mass_on, dr_com_on, dr_pd_on, dr_joint_on;
+    float dr_friction_lo, dr_friction_span, dr_mass_lo, dr_mass_span;
+    float dr_com_lo[3], dr_com_span[3];
+    float dr_kp_lo, dr_kp_span, dr_kd_lo, dr_kd_span;
+    float dr_joint_lo[3], dr_joint_span[3];
+    float friction_offset, kp_offset, kd_offset; /* privileged-obs centring (legged_robot.py:448-453) */
+    /* terrain curriculum (legged_robot.py:254-272, genesis_simulator.py:140-148) */
+    int32_t terrain_curriculum, max_terrain_level, terrain_cols_n;
+    float terrain_env_length, episode_length_s;
+    LgRandSlots slots;
+    uint64_t seed;
+    int64_t env_id_offset;           /* global index of local env 0 (multi-GPU sharding) */
+} LgTaskCfg;
+
+/* ---- per-env device buffers.  Names follow the reference attributes they back
+ * (genesis_simulator.py:407-494 _init_buffers, legged_robot.py:380-409, base_task.py:29-37). */
+typedef struct LgBuffers {
+    int32_t n_envs;
+    /* engine state (what Genesis keeps internally; set by reset_dofs/reset_root_states :84-133) */
+    float *base_pos, *base_quat, *base_lin_vel_w, *base_ang_vel_w, *dof_pos, *dof_vel;
+    /* per-env dynamics parameters (genesis_simulator.py:644-663) */
+    float *friction_values, *added_base_mass, *base_com_bias, *kp_scale, *kd_scale;
+    float *joint_armature, *joint_friction, *joint_damping; /* (N,1) each, may be NULL */
+    float *rand_push_vels;   /* (N,3) */
+    float *env_origins;      /* (N,3) */
+    /* Simulator read-back properties (genesis_simulator.py:35-60) */
+    float *base_lin_vel, *base_ang_vel, *projected_gravity, *base_euler;
+    float *last_base_lin_vel, *last_base_ang_vel, *last_dof_vel, *last_feet_vel;
+    float *torques, *link_contact_forces, *feet_pos, *feet_vel;
+    float *link_contact_states;       /* (N,K) float 0/1, may be NULL */
+    float *measured_heights;          /* (N,P) may be NULL */
+    float *height_around_feet;        /* (N,F,9) may be NULL */
+    float *normal_vector_around_feet; /* (N,3F) may be NULL */
+    float *height_points;             /* (P,2) body-frame sample offsets, may be NULL */
+    int32_t *terrain_levels, *terrain_types; /* (N) may be NULL */
+    float *terrain_origins;           /* (rows, cols, 3) may be NULL */
+    /* MDP buffers (legged_robot.py:380-409, base_task.py:29-37) */
+    float *actions, *last_actions, *llast_actions, *commands;
+    float *feet_air_time; uint8_t *last_contacts;
+    int32_t *episode_length_buf; int64_t *fail_buf;
+    uint8_t *reset_buf, *time_out_buf;
+    float *rew_buf, *obs_buf, *priv_obs_buf, *labels_buf; /* priv/labels may be NULL */
+    float *obs_hist, *priv_hist;      /* (N, stack, frame) ring-free history, may be NULL */
+    float *episode_sums;              /* (LG_R_COUNT, N) */
+    float *episode_done_sums;         /* (LG_R_COUNT + 2): sums over envs reset this step, [R]=count, [R+1]=spare */
+    float *command_ranges;            /* (LG_CMD_RANGE_FLOATS): vx lo/hi, vy lo/hi, yaw lo/hi, heading lo/hi */
+    float *task_state;                /* task specific per-env block (gait phase ...), may be NULL */
+    const float *rand_in;             /* (N, slots.n_slots) injected uniforms, NULL => Philox */
+} LgBuffers;
+
+/* phases of one LeggedRobot.step (legged_robot.py:37-76) a launch may cover */
+#define LG_PHASE_PRE 1    /* _pre_sim_step: clip + action history (legged_robot.py:230-239) */
+#define LG_PHASE_SIM 2    /* simulator.step + simulator.post_physics_step (genesis_simulator.py:20-60) */
+#define LG_PHASE_POST 4   /* callback, check_termination, compute_reward (legged_robot.py:64-68) */
+#define LG_PHASE_RESET 8  /* reset_idx + compute_observations (legged_robot.py:69-73) */
+#define LG_PHASE_ALL 15
+
+typedef struct LgEngine *LgHandle;
+
+/* Build the per-handle constant tables on the current HIP device.
+ * Replaces Simulator.__init__ -> _create_sim/_create_envs (simulator.py:7-18). */
+int lg_create(const LgModelDesc *model, const LgSimOptions *opts, const LgTaskCfg *task, LgHandle *out);
+int lg_destroy(LgHandle h);
+/* Replace the task constants (reward scales after curriculum edits, seeds ...). */
+int lg_set_task(LgHandle h, const LgTaskCfg *task);
+/* Register the int16 heightfield already resident on the device
+ * (genesis_simulator.py:765-778 _create_heightfield; rows x cols, row-major [x][y]). */
+int lg_set_terrain(LgHandle h, const int16_t *height_samples_dev, int32_t rows, int32_t cols);
+/* Record the caller-owned device buffers (validated: required pointers non-NULL). */
+int lg_bind(LgHandle h, const LgBuffers *bufs);
+/* Enqueue one launch covering `phases` of a control step on `stream`.
+ * actions: (N,A) device pointer (required with LG_PHASE_PRE or LG_PHASE_SIM);
+ * common_step_counter: value AFTER this step's increment (legged_robot.py:61). */
+int lg_step(LgHandle h, uint32_t phases, const float *actions, int64_t common_step_counter, void *stream);
+/* Timing helper for bench.py: enqueue `count` fused steps reusing `actions`, bracketed by
+ * HIP events on `stream`; returns mean kernel-to-kernel milliseconds per step in *ms. */
+int lg_time_steps(LgHandle h, const float *actions, int64_t first_counter, int32_t count, void *stream, float *ms);
+const char *lg_last_error(void);
+int lg_abi_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LGSIM_H */

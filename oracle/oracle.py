@@ -1,0 +1,101 @@
+"""ctypes front-end of the C physics oracle (oracle/lg_oracle.c).
+
+TEST INFRASTRUCTURE ONLY -- imported by tests/, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg; never by hcr_genesis_lr_cl_amd/.  It reuses the product's ctypes struct
+definitions (abi.py mirrors include/lgsim.h) so both sides see identical models/options.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from hcr_genesis_lr_cl_amd import abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_LIBS = {}
+
+
+def build(force=False):
+    """Compile the oracle with gcc (Makefile next to this file)."""
+    need = force or not all(os.path.exists(os.path.join(_HERE, f"liblgoracle_{p}.so")) for p in ("f32", "f64"))
+    src = os.path.join(_HERE, "lg_oracle.c")
+    if not need:
+        need = any(os.path.getmtime(src) > os.path.getmtime(os.path.join(_HERE, f"liblgoracle_{p}.so"))
+                   for p in ("f32", "f64"))
+    if need:
+        subprocess.run(["make", "-C", _HERE, "-B"], check=True, capture_output=True)
+
+
+def lib(precision="f32"):
+    if precision not in _LIBS:
+        p = os.path.join(_HERE, f"liblgoracle_{precision}.so")
+        if not os.path.exists(p):
+            build()
+        L = C.CDLL(p)
+        L.lgo_sim_step.argtypes = [C.POINTER(abi.LgModelDesc), C.POINTER(abi.LgSimOptions), C.c_void_p,
+                                   C.POINTER(abi.LgBuffers), C.c_void_p, C.c_int]
+        L.lgo_forward_dynamics.argtypes = [C.POINTER(abi.LgModelDesc), C.POINTER(abi.LgSimOptions)] + \
+            [C.c_void_p] * 7 + [C.c_int, C.c_void_p, C.c_void_p]
+        _LIBS[precision] = L
+    return _LIBS[precision]
+
+
+# host-side allocation of every per-env buffer the physics touches -------------------------
+SIM_SHAPES = lambda A, L, F: dict(
+    base_pos=3, base_quat=4, base_lin_vel_w=3, base_ang_vel_w=3, dof_pos=A, dof_vel=A,
+    friction_values=1, added_base_mass=1, base_com_bias=3, kp_scale=A, kd_scale=A,
+    rand_push_vels=3, env_origins=3,
+    base_lin_vel=3, base_ang_vel=3, projected_gravity=3, base_euler=3,
+    last_base_lin_vel=3, last_base_ang_vel=3, last_dof_vel=A, last_feet_vel=3 * F,
+    torques=A, link_contact_forces=3 * L, feet_pos=3 * F, feet_vel=3 * F)
+
+
+class HostState:
+    """Numpy mirror of the LgBuffers fields used by simulator.step()."""
+
+    def __init__(self, model, n_envs, default_dof_pos, init_height):
+        self.model, self.n = model, n_envs
+        A, L, F = model.n_dof, model.n_links, model.n_legs
+        self.arr = {k: np.zeros((n_envs, w), np.float32) for k, w in SIM_SHAPES(A, L, F).items()}
+        a = self.arr
+        a["base_quat"][:, 3] = 1
+        a["base_pos"][:, 2] = init_height
+        a["dof_pos"][:] = np.asarray(default_dof_pos, np.float32)
+        a["friction_values"][:] = 1
+        a["kp_scale"][:] = 1
+        a["kd_scale"][:] = 1
+
+    def buffers(self):
+        b = abi.LgBuffers()
+        b.n_envs = self.n
+        for k, v in self.arr.items():
+            setattr(b, k, v.ctypes.data)
+        return b
+
+    def copy(self):
+        o = HostState.__new__(HostState)
+        o.model, o.n = self.model, self.n
+        o.arr = {k: v.copy() for k, v in self.arr.items()}
+        return o
+
+
+def sim_step(desc, opts, state: HostState, actions, precision="f32", threads=1, heightfield=None):
+    actions = np.ascontiguousarray(actions, np.float32)
+    b = state.buffers()
+    hf = None if heightfield is None else np.ascontiguousarray(heightfield, np.int16)
+    lib(precision).lgo_sim_step(C.byref(desc), C.byref(opts), None if hf is None else hf.ctypes.data,
+                                C.byref(b), actions.ctypes.data, threads)
+
+
+def forward_dynamics(desc, opts, pos, quat, vw, ww, q, qd, tau, method=0, precision="f64"):
+    f = lambda x: np.ascontiguousarray(x, np.float32)
+    pos, quat, vw, ww, q, qd, tau = map(f, (pos, quat, vw, ww, q, qd, tau))
+    nd = q.size
+    qdd, acc = np.zeros(nd), np.zeros(6)
+    lib(precision).lgo_forward_dynamics(C.byref(desc), C.byref(opts), pos.ctypes.data, quat.ctypes.data,
+                                        vw.ctypes.data, ww.ctypes.data, q.ctypes.data, qd.ctypes.data,
+                                        tau.ctypes.data, method, qdd.ctypes.data, acc.ctypes.data)
+    return qdd, acc
