@@ -19,6 +19,7 @@ MAX_SPHERES = 64
 MAX_OBS = 192
 NUM_REWARDS = 40
 CMD_RANGE_FLOATS = 8
+DONE_RING = 64
 
 PHASE_PRE, PHASE_SIM, PHASE_POST, PHASE_RESET, PHASE_ALL = 1, 2, 4, 8, 15
 
@@ -83,7 +84,8 @@ class LgTaskCfg(C.Structure):
         ("fail_threshold", f32), ("max_projected_gravity", f32),
         ("resample_steps", i32), ("push_interval", i32), ("max_push_vel_xy", f32), ("heading_command", i32),
         ("yaw_clip", f32 * 2),
-        ("reward_scales", f32 * NUM_REWARDS), ("only_positive_rewards", i32),
+        ("reward_scales", f32 * NUM_REWARDS), ("soft_dof_lo", f32 * MAX_DOF), ("soft_dof_hi", f32 * MAX_DOF),
+        ("only_positive_rewards", i32),
         ("tracking_sigma", f32), ("base_height_target", f32), ("foot_clearance_target", f32),
         ("foot_height_offset", f32), ("foot_clearance_sigma", f32), ("about_landing_threshold", f32),
         ("feet_air_time_threshold", f32), ("base_height_sigma", f32), ("euler_sigma", f32),

@@ -1,0 +1,34 @@
+"""Builds csrc/liblgsim.so with hipcc for gfx950 (in-tree, so it travels to the GPU box)."""
+import os
+import subprocess
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+CSRC = os.path.join(HERE, "csrc")
+SRC = ["lg_kernel.hip"]
+OUT = os.path.join(CSRC, "liblgsim.so")
+
+
+def needs_build():
+    if not os.path.exists(OUT):
+        return True
+    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
+    deps.append(os.path.join(HERE, "..", "include", "lgsim.h"))
+    return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
+
+
+def build(force=False, verbose=False):
+    if not force and not needs_build():
+        return OUT
+    hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
+    cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17",
+           "-o", OUT] + [os.path.join(CSRC, s) for s in SRC]
+    r = subprocess.run(cmd, capture_output=True, text=True)
+    if r.returncode != 0:
+        raise RuntimeError("hipcc failed:\n" + r.stderr)
+    if verbose:
+        print(r.stderr)
+    return OUT
+
+
+if __name__ == "__main__":
+    print(build(force=True, verbose=True))

@@ -110,6 +110,9 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
             raise NotImplementedError(f"reward term {name!r} has no kernel implementation")
         scales[abi.REWARD_ID[name]] = s * dt                          # legged_robot.py:421 (python float math)
     abi.fill_array(t.reward_scales, scales)
+    soft = cfgmod.soft_dof_limits(model, cfg)
+    abi.fill_array(t.soft_dof_lo, soft[:, 0])
+    abi.fill_array(t.soft_dof_hi, soft[:, 1])
     r = cfg.rewards
     t.only_positive_rewards = int(r.only_positive_rewards)
     t.tracking_sigma, t.base_height_target = r.tracking_sigma, r.base_height_target

@@ -1,0 +1,138 @@
+"""Thin host wrapper around the C ABI (include/lgsim.h): owns the torch device buffers, binds
+them, and enqueues launches on torch's current HIP stream.
+
+PyTorch is plumbing here (device memory + streams); every number is produced by the HIP
+kernels in csrc/.  There is no CPU path: constructing an Engine without the built library or
+without a GPU raises.
+"""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+import torch
+
+from . import abi
+
+
+def buffer_specs(A, L, F, K, P, num_obs, num_priv, num_labels, n_slots, hist, priv_hist, task_state):
+    """name -> (trailing shape, dtype).  Shapes follow genesis_simulator.py:407-494,
+    legged_robot.py:380-409 and base_task.py:29-37."""
+    f, i32, i64, u8 = torch.float32, torch.int32, torch.int64, torch.uint8
+    s = dict(
+        base_pos=((3,), f), base_quat=((4,), f), base_lin_vel_w=((3,), f), base_ang_vel_w=((3,), f),
+        dof_pos=((A,), f), dof_vel=((A,), f),
+        friction_values=((1,), f), added_base_mass=((1,), f), base_com_bias=((3,), f),
+        kp_scale=((A,), f), kd_scale=((A,), f),
+        joint_armature=((1,), f), joint_friction=((1,), f), joint_damping=((1,), f),
+        rand_push_vels=((3,), f), env_origins=((3,), f),
+        base_lin_vel=((3,), f), base_ang_vel=((3,), f), projected_gravity=((3,), f), base_euler=((3,), f),
+        last_base_lin_vel=((3,), f), last_base_ang_vel=((3,), f), last_dof_vel=((A,), f), last_feet_vel=((F, 3), f),
+        torques=((A,), f), link_contact_forces=((L, 3), f), feet_pos=((F, 3), f), feet_vel=((F, 3), f),
+        actions=((A,), f), last_actions=((A,), f), llast_actions=((A,), f), commands=((4,), f),
+        feet_air_time=((F,), f), last_contacts=((F,), u8), episode_length_buf=((), i32), fail_buf=((), i64),
+        reset_buf=((), u8), time_out_buf=((), u8), rew_buf=((), f), obs_buf=((num_obs,), f),
+    )
+    if K:
+        s["link_contact_states"] = ((K,), f)
+    if P:
+        s["measured_heights"] = ((P,), f)
+        s["height_around_feet"] = ((F, 9), f)
+        s["normal_vector_around_feet"] = ((3 * F,), f)
+        s["terrain_levels"] = ((), i32)
+        s["terrain_types"] = ((), i32)
+    if num_priv:
+        s["priv_obs_buf"] = ((num_priv,), f)
+    if num_labels:
+        s["labels_buf"] = ((num_labels,), f)
+    if hist:
+        s["obs_hist"] = (hist, f)
+    if priv_hist:
+        s["priv_hist"] = (priv_hist, f)
+    if task_state:
+        s["task_state"] = ((task_state,), f)
+    return s
+
+
+class Engine:
+    def __init__(self, model, desc, opts, task, n_envs, device="cuda:0", num_labels=0, task_state=0,
+                 inject_rand=False):
+        if not torch.cuda.is_available():
+            raise RuntimeError("hcr_genesis_lr_cl_amd needs a HIP device (no CPU fallback)")
+        self.lib = abi.load_lib()
+        self.device = torch.device(device)
+        torch.cuda.set_device(self.device)
+        self.model, self.desc, self.opts, self.task = model, desc, opts, task
+        self.n = int(n_envs)
+        A, L, F = model.n_dof, model.n_links, model.n_legs
+        K = bin(desc.state_link_mask).count("1")
+        P = int(opts.n_height_points)
+        hist = (task.obs_stack, task.obs_frame) if task.obs_stack > 1 else None
+        phist = (task.priv_stack, task.priv_frame) if task.priv_stack > 1 else None
+        specs = buffer_specs(A, L, F, K, P, task.num_obs, task.num_priv_obs, num_labels, task.slots.n_slots,
+                             hist, phist, task_state)
+        self.buf = {k: torch.zeros((self.n,) + tuple(shape), dtype=dt, device=self.device)
+                    for k, (shape, dt) in specs.items()}
+        self.buf["episode_sums"] = torch.zeros((abi.R_COUNT, self.n), device=self.device)
+        self.buf["episode_done_sums"] = torch.zeros((abi.DONE_RING, abi.R_COUNT + 2), device=self.device)
+        self.buf["command_ranges"] = torch.zeros(abi.CMD_RANGE_FLOATS, device=self.device)
+        if inject_rand:
+            self.buf["rand_in"] = torch.zeros((self.n, task.slots.n_slots), device=self.device)
+        b = self.buf
+        b["base_quat"][:, 3] = 1.0
+        b["friction_values"].fill_(1.0)
+        b["kp_scale"].fill_(1.0)
+        b["kd_scale"].fill_(1.0)
+        b["added_base_mass"].fill_(0.0)
+        self.handle = C.c_void_p()
+        abi.check(self.lib.lg_create(C.byref(desc), C.byref(opts), C.byref(task), C.byref(self.handle)), self.lib)
+        self.bind()
+
+    def bind(self):
+        lb = abi.LgBuffers()
+        lb.n_envs = self.n
+        for name in abi.BUFFER_NAMES:
+            t = self.buf.get(name)
+            if t is not None:
+                assert t.is_contiguous()
+                setattr(lb, name, t.data_ptr())
+        self._lb = lb
+        abi.check(self.lib.lg_bind(self.handle, C.byref(lb)), self.lib)
+
+    def set_task(self, task):
+        self.task = task
+        abi.check(self.lib.lg_set_task(self.handle, C.byref(task)), self.lib)
+
+    def set_terrain(self, height_samples: torch.Tensor):
+        hs = height_samples.to(self.device, torch.int16).contiguous()
+        self.buf["_height_samples"] = hs
+        abi.check(self.lib.lg_set_terrain(self.handle, hs.data_ptr(), hs.shape[0], hs.shape[1]), self.lib)
+
+    def step(self, phases, actions, counter):
+        a = 0
+        if actions is not None:
+            if actions.dtype != torch.float32 or not actions.is_contiguous() or actions.device != self.device:
+                actions = actions.to(self.device, torch.float32).contiguous()
+            if tuple(actions.shape) != (self.n, self.model.n_dof):
+                raise ValueError(f"actions must be ({self.n}, {self.model.n_dof}), got {tuple(actions.shape)}")
+            a = actions.data_ptr()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        abi.check(self.lib.lg_step(self.handle, phases, a, int(counter), stream), self.lib)
+
+    def time_steps(self, actions, first_counter, count):
+        ms = C.c_float()
+        stream = torch.cuda.current_stream(self.device).cuda_stream
+        abi.check(self.lib.lg_time_steps(self.handle, actions.data_ptr(), int(first_counter), int(count), stream,
+                                         C.byref(ms)), self.lib)
+        return ms.value
+
+    def close(self):
+        if getattr(self, "handle", None):
+            self.lib.lg_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

@@ -1,0 +1,15 @@
+"""Task registry mirroring legged_gym/envs/__init__.py:80-91 for the tasks in scope."""
+from .legged_robot import LeggedRobot
+from .go2 import GO2
+from ..config import GO2Cfg
+
+TASKS = {"go2": (GO2, GO2Cfg)}
+
+
+def make_env(name, num_envs=None, device="cuda:0", **kw):
+    """task_registry.make_env equivalent (task_registry.py:35-72) for this backend."""
+    cls, cfg_cls = TASKS[name]
+    cfg = cfg_cls()
+    if num_envs is not None:
+        cfg.env.num_envs = int(num_envs)
+    return cls(cfg, None, device, True, **kw), cfg

@@ -1,0 +1,200 @@
+"""LeggedRobot -- the rsl_rl ``VecEnv`` surface of the reference, with the whole control step
+(actions -> physics -> termination / rewards / resets / observations) fused into one HIP launch.
+
+API parity targets (reference file:line):
+  * ``step(actions) -> (obs, privileged_obs, rew, reset, extras)``  legged_robot.py:37-53
+  * ``reset()``                                                     base_task.py:60-64
+  * ``get_observations() / get_privileged_observations()``          base_task.py:50-54
+  * attributes rsl_rl reads: num_envs, num_obs, num_privileged_obs, num_actions,
+    max_episode_length, episode_length_buf, obs_buf, rew_buf, reset_buf, extras, device
+    (rsl_rl/env/vec_env.py:36-60, on_policy_runner.py:100-124)
+  * ``self.simulator`` is a HipSimulator exposing the reference's Simulator properties.
+
+Differences by design: data-dependent ``nonzero()`` host syncs of the reference
+(legged_robot.py:69,305) are replaced by masked in-kernel logic; random draws come from a
+counter-based Philox stream keyed on (seed, global env id, step, slot).
+"""
+from __future__ import annotations
+
+from collections.abc import Mapping
+
+import numpy as np
+import torch
+
+from .. import abi
+from .. import config as cfgmod
+from ..simulator import HipSimulator
+
+
+class _EpisodeExtras(Mapping):
+    """Lazy ``extras["episode"]`` (legged_robot.py:128-138): per-term mean of the episode sums over
+    the envs reset at one step, divided by episode_length_s.  Values are computed on access from
+    the kernel's per-step accumulator ring, so the hot loop issues no extra launches.  When a step
+    had no reset the reference leaves the previous dict in place; the same is done here by
+    walking back through the ring."""
+
+    def __init__(self, env, step):
+        self._env, self._step = env, step
+
+    def _row(self):
+        ring = self._env._engine.buf["episode_done_sums"]
+        R = abi.R_COUNT
+        for back in range(abi.DONE_RING - 2):
+            s = self._step - back
+            if s < 1:
+                break
+            row = ring[s % abi.DONE_RING]
+            if float(row[R]) > 0:
+                return row
+        return None
+
+    def __getitem__(self, key):
+        env = self._env
+        if key == "max_command_x":
+            return env.command_ranges["lin_vel_x"][1]
+        if key == "terrain_level":
+            return torch.mean(env.simulator.terrain_levels.float())
+        name = key[4:]
+        if not key.startswith("rew_") or name not in env.episode_sums:
+            raise KeyError(key)
+        row = self._row()
+        if row is None:
+            return torch.zeros((), device=env.device)
+        return row[abi.REWARD_ID[name]] / row[abi.R_COUNT] / env.max_episode_length_s
+
+    def __iter__(self):
+        env = self._env
+        for k in env.episode_sums:
+            yield "rew_" + k
+        if env.cfg.terrain.curriculum:
+            yield "terrain_level"
+        if env.cfg.commands.curriculum:
+            yield "max_command_x"
+
+    def __len__(self):
+        return sum(1 for _ in self)
+
+
+class LeggedRobot:
+    def __init__(self, cfg, sim_params=None, sim_device="cuda:0", headless=True, inject_rand=False,
+                 env_id_offset=0, global_num_envs=None):
+        self.cfg = cfg
+        self.init_done = False
+        self._parse_cfg(cfg)
+        self.device = sim_device
+        self.headless = headless
+        self.num_envs = cfg.env.num_envs
+        self.num_obs = cfg.env.num_observations
+        self.num_privileged_obs = cfg.env.num_privileged_obs
+        self.num_actions = cfg.env.num_actions
+        self.simulator = HipSimulator(cfg, sim_params or cfgmod.class_to_dict(cfg.sim), sim_device, headless,
+                                      inject_rand=inject_rand, env_id_offset=env_id_offset,
+                                      global_num_envs=global_num_envs)
+        self._engine = self.simulator._engine
+        b = self._engine.buf
+        # base_task.py:29-37
+        self.obs_buf, self.rew_buf = b["obs_buf"], b["rew_buf"]
+        self.reset_buf = b["reset_buf"].view(torch.bool)
+        self.time_out_buf = b["time_out_buf"].view(torch.bool)
+        self.episode_length_buf = b["episode_length_buf"]
+        self.privileged_obs_buf = b.get("priv_obs_buf")
+        self.reset_buf.fill_(True)
+        self.extras = {}
+        self._init_buffers()
+        self._prepare_reward_function()
+        self.init_done = True
+
+    # ------------------------------------------------------------------------------------------
+    def step(self, actions):
+        """legged_robot.py:37-53 in one launch (two on the rare command-curriculum steps)."""
+        self.common_step_counter += 1
+        c = self.common_step_counter
+        if self.cfg.commands.curriculum and (c % self.max_episode_length == 0):
+            # the curriculum decision needs the episode sums of the envs that reset at this very
+            # step, before they are zeroed (legged_robot.py:110-111, 336-348): split the launch
+            self._engine.step(abi.PHASE_PRE | abi.PHASE_SIM | abi.PHASE_POST, actions, c)
+            env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()
+            if len(env_ids) > 0:
+                self._update_command_curriculum(env_ids)
+            self._engine.step(abi.PHASE_RESET, None, c)
+        else:
+            self._engine.step(abi.PHASE_ALL, actions, c)
+        self.extras["episode"] = _EpisodeExtras(self, c)
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def reset(self):
+        """base_task.py:60-64: reset every env, then one zero-action step."""
+        self.reset_idx(torch.arange(self.num_envs, device=self.device))
+        obs, priv, _, _, _ = self.step(torch.zeros(self.num_envs, self.num_actions, device=self.device))
+        return obs, priv
+
+    def reset_idx(self, env_ids):
+        """legged_robot.py:94-148 for an explicit id list: flag the envs and run the RESET phase."""
+        if len(env_ids) == 0:
+            return
+        self.reset_buf.fill_(False)
+        self.reset_buf[env_ids] = True
+        self._engine.step(abi.PHASE_RESET, None, self.common_step_counter)
+
+    def get_observations(self):
+        return self.obs_buf
+
+    def get_privileged_observations(self):
+        return self.privileged_obs_buf
+
+    # ------------------------------------------------------------------------------------------
+    def _update_command_curriculum(self, env_ids):
+        """legged_robot.py:336-348."""
+        k = abi.REWARD_ID["tracking_lin_vel"]
+        mean = torch.mean(self._engine.buf["episode_sums"][k][env_ids]) / self.max_episode_length
+        if mean > self.cfg.commands.curriculum_threshold * self.reward_scales["tracking_lin_vel"]:
+            r = self.command_ranges["lin_vel_x"]
+            r[0] = float(np.clip(r[0] - 0.5, -self.cfg.commands.max_curriculum, 0.))
+            r[1] = float(np.clip(r[1] + 0.5, 0., self.cfg.commands.max_curriculum))
+            self._upload_command_ranges()
+
+    def _upload_command_ranges(self):
+        cr = self.command_ranges
+        vals = list(cr["lin_vel_x"]) + list(cr["lin_vel_y"]) + list(cr["ang_vel_yaw"]) + list(cr["heading"])
+        self._engine.buf["command_ranges"].copy_(torch.tensor(vals, dtype=torch.float32))
+
+    def _parse_cfg(self, cfg):
+        """legged_robot.py:436-455."""
+        self.dt = cfgmod.control_dt(cfg)
+        self.debug = cfg.env.debug
+        self.obs_scales = cfg.normalization.obs_scales
+        self.reward_scales = cfgmod.class_to_dict(cfg.rewards.scales)
+        self.command_ranges = cfgmod.class_to_dict(cfg.commands.ranges)
+        if cfg.terrain.mesh_type not in ("heightfield", "trimesh"):
+            cfg.terrain.curriculum = False
+        self.max_episode_length_s = cfg.env.episode_length_s
+        self.max_episode_length = np.ceil(self.max_episode_length_s / self.dt)
+        cfg.domain_rand.push_interval = np.ceil(cfg.domain_rand.push_interval_s / self.dt)
+
+    def _init_buffers(self):
+        """legged_robot.py:380-409: aliases onto the engine's device buffers."""
+        b = self._engine.buf
+        self.common_step_counter = 0
+        self.commands = b["commands"]
+        self.actions, self.last_actions, self.llast_actions = b["actions"], b["last_actions"], b["llast_actions"]
+        self.feet_air_time = b["feet_air_time"]
+        self.last_contacts = b["last_contacts"].view(torch.bool)
+        self.fail_buf = b["fail_buf"]
+        self.commands_scale = torch.tensor([self.obs_scales.lin_vel, self.obs_scales.lin_vel, self.obs_scales.ang_vel],
+                                           device=self.device)
+        self.noise_scale_vec = torch.tensor(np.ctypeslib.as_array(self._engine.task.noise_vec)[:self._engine.task.obs_frame].copy(),
+                                            device=self.device)
+        self.add_noise = self.cfg.noise.add_noise
+        self._upload_command_ranges()
+        self.extras["time_outs"] = self.time_out_buf
+
+    def _prepare_reward_function(self):
+        """legged_robot.py:411-434: drop zero scales, multiply by dt, per-term episode sums."""
+        for key in list(self.reward_scales.keys()):
+            if self.reward_scales[key] == 0:
+                self.reward_scales.pop(key)
+            else:
+                self.reward_scales[key] *= self.dt
+        self.reward_names = [n for n in self.reward_scales if n != "termination"]
+        es = self._engine.buf["episode_sums"]
+        self.episode_sums = {name: es[abi.REWARD_ID[name]] for name in self.reward_scales}

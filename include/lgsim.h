@@ -36,6 +36,7 @@ extern "C" {
 #define LG_MAX_OBS 192    /* widest single observation frame handled in-kernel */
 #define LG_NUM_REWARDS 40
 #define LG_CMD_RANGE_FLOATS 8
+#define LG_DONE_RING 64
 
 /* ---- robot model (output of hcr_genesis_lr_cl_amd/model_compiler.py) -------------------
  * Stands in for gs.morphs.URDF(merge_fixed_links=True, links_to_keep=feet)
@@ -160,6 +161,7 @@ typedef struct LgTaskCfg {
     int32_t heading_command;
     float yaw_clip[2];               /* commands.ranges.ang_vel_yaw */
     float reward_scales[LG_NUM_REWARDS]; /* already multiplied by dt (legged_robot.py:416-421) */
+    float soft_dof_lo[LG_MAX_DOF], soft_dof_hi[LG_MAX_DOF]; /* dof_pos_limits property (genesis_simulator.py:373-382) */
     int32_t only_positive_rewards;
     float tracking_sigma, base_height_target, foot_clearance_target, foot_height_offset;
     float foot_clearance_sigma, about_landing_threshold, feet_air_time_threshold;
@@ -217,7 +219,9 @@ typedef struct LgBuffers {
     float *rew_buf, *obs_buf, *priv_obs_buf, *labels_buf; /* priv/labels may be NULL */
     float *obs_hist, *priv_hist;      /* (N, stack, frame) ring-free history, may be NULL */
     float *episode_sums;              /* (LG_R_COUNT, N) */
-    float *episode_done_sums;         /* (LG_R_COUNT + 2): sums over envs reset this step, [R]=count, [R+1]=spare */
+    float *episode_done_sums;         /* (LG_DONE_RING, LG_R_COUNT + 2): per-step sums of episode_sums over the envs
+                                         reset at that step (legged_robot.py:128-132); row = counter % LG_DONE_RING,
+                                         [R] = number of resets, [R+1] spare; the kernel clears the next row */
     float *command_ranges;            /* (LG_CMD_RANGE_FLOATS): vx lo/hi, vy lo/hi, yaw lo/hi, heading lo/hi */
     float *task_state;                /* task specific per-env block (gait phase ...), may be NULL */
     const float *rand_in;             /* (N, slots.n_slots) injected uniforms, NULL => Philox */

@@ -1,0 +1,100 @@
+"""GPU parity, physics phase: HIP SIM launch (through the C ABI) vs. the f64 CPU oracle on the
+same seeded states.  Tolerances are stated per quantity: the kernel computes in f32 in a
+different formulation (world-aligned axes about the base origin, leg-per-lane) from the oracle
+(body coordinates, dense 6x6), so agreement is to f32 round-off amplified by the stiff contact
+(k = 4e4 N/m: 1e-6 m of position noise is 0.04 N)."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+SIM_OUT = ["base_pos", "base_quat", "base_lin_vel_w", "base_ang_vel_w", "dof_pos", "dof_vel", "torques",
+           "link_contact_forces", "feet_pos", "feet_vel", "base_lin_vel", "base_ang_vel", "projected_gravity",
+           "base_euler", "last_dof_vel", "last_feet_vel", "last_base_lin_vel", "last_base_ang_vel"]
+TOL = dict(base_pos=2e-5, base_quat=2e-5, base_lin_vel_w=2e-3, base_ang_vel_w=1e-2, dof_pos=2e-4, dof_vel=3e-2,
+           torques=5e-3, link_contact_forces=None, feet_pos=1e-4, feet_vel=2e-2, base_lin_vel=2e-3,
+           base_ang_vel=1e-2, projected_gravity=2e-5, base_euler=5e-5, last_dof_vel=0, last_feet_vel=0,
+           last_base_lin_vel=0, last_base_ang_vel=0)
+
+
+@pytest.fixture(scope="module")
+def engine(go2):
+    import torch
+    from hcr_genesis_lr_cl_amd import builders
+    from hcr_genesis_lr_cl_amd.engine import Engine
+    task = builders.make_task_cfg(go2["model"], go2["cfg"])
+    return Engine(go2["model"], go2["desc"], go2["opts"], task, 512, "cuda:0")
+
+
+def _run_both(go2, engine, seed, steps=1, airborne_frac=0.3, z_offset=0.0):
+    import torch
+    from hcr_genesis_lr_cl_amd import abi
+    from oracle import oracle as orc
+    from tests.util import random_sim_state, load_state_into_engine, engine_arrays
+    st, actions = random_sim_state(go2["model"], go2["cfg"], engine.n, seed, airborne_frac, z_offset)
+    load_state_into_engine(engine, st)
+    act = torch.from_numpy(actions).cuda()
+    for _ in range(steps):
+        engine.step(abi.PHASE_SIM, act, 0)
+        orc.sim_step(go2["desc"], go2["opts"], st, actions, "f64", threads=8)
+    return engine_arrays(engine, SIM_OUT), st
+
+
+@pytest.mark.parametrize("seed", [0, 1, 2])
+def test_one_control_step_matches_oracle(go2, engine, seed):
+    got, st = _run_both(go2, engine, seed)
+    for k in SIM_OUT:
+        ref = st.arr[k].reshape(engine.n, -1)
+        assert np.all(np.isfinite(got[k])), k
+        if k == "link_contact_forces":
+            # forces: 1% + 0.3 N (last sub-step force of a stiff implicit contact)
+            err = np.abs(got[k] - ref)
+            assert np.all(err <= 0.3 + 0.01 * np.abs(ref)), (k, err.max())
+        else:
+            np.testing.assert_allclose(got[k], ref, atol=TOL[k], rtol=1e-4, err_msg=k)
+
+
+def test_free_flight_matches_oracle_tightly(go2, engine):
+    """No contacts at all: pure ABA + PD + integration, four sub-steps -> near round-off."""
+    got, st = _run_both(go2, engine, 5, airborne_frac=1.1, z_offset=2.0)
+    for k, tol in (("dof_pos", 2e-5), ("dof_vel", 2e-3), ("base_pos", 2e-6), ("base_ang_vel_w", 1e-3), ("base_lin_vel_w", 2e-4)):
+        np.testing.assert_allclose(got[k], st.arr[k].reshape(engine.n, -1), atol=tol, rtol=2e-5, err_msg=k)
+    assert np.abs(got["link_contact_forces"]).max() == 0.0
+
+
+def test_static_stance_on_gpu(go2):
+    """The kernel alone (no oracle): stiff stance settles with sum Fz = m g on the feet."""
+    import copy, torch
+    from hcr_genesis_lr_cl_amd import abi, builders, config as cfgmod
+    from hcr_genesis_lr_cl_amd.engine import Engine
+    opts = copy.copy(go2["opts"])
+    for k in range(12):
+        opts.kp[k] = 80.0; opts.kd[k] = 1.0
+    task = builders.make_task_cfg(go2["model"], go2["cfg"])
+    eng = Engine(go2["model"], go2["desc"], opts, task, 64, "cuda:0")
+    eng.buf["dof_pos"][:] = torch.tensor(cfgmod.default_dof_pos(go2["cfg"])).cuda()
+    eng.buf["base_pos"][:, 2] = 0.335
+    act = torch.zeros(64, 12, device="cuda")
+    for _ in range(200):
+        eng.step(abi.PHASE_SIM, act, 0)
+    torch.cuda.synchronize()
+    f = eng.buf["link_contact_forces"].cpu().numpy()
+    mg = go2["model"].total_mass * 9.81
+    assert np.allclose(f[:, :, 2].sum(1), mg, rtol=0.02)
+    assert np.all(f[:, [4, 8, 12, 16], 2].sum(1) > 0.98 * f[:, :, 2].sum(1))
+    assert np.abs(eng.buf["dof_vel"].cpu().numpy()).max() < 0.05
+
+
+def test_extreme_actions_stay_finite(go2, engine):
+    import torch
+    from hcr_genesis_lr_cl_amd import abi
+    from tests.util import random_sim_state, load_state_into_engine
+    st, _ = random_sim_state(go2["model"], go2["cfg"], engine.n, 9)
+    load_state_into_engine(engine, st)
+    act = torch.full((engine.n, 12), 100.0, device="cuda")
+    act[::2] *= -1
+    for _ in range(50):
+        engine.step(abi.PHASE_SIM, act, 0)
+    torch.cuda.synchronize()
+    for k in ("dof_pos", "dof_vel", "base_pos", "base_quat", "link_contact_forces"):
+        assert torch.isfinite(engine.buf[k]).all(), k
