@@ -123,11 +123,11 @@ struct RandSrc {
     }
 };
 
-// torch.remainder(a, b) for b > 0, then math_utils.py:50-53
+// math_utils.py:50-53 as TorchScript executes it: `angles %= 2*pi` lowers to aten::fmod_
+// (C remainder, sign of the dividend), so negative angles are NOT wrapped; only m > pi shifts.
 LG_DEV float wrap_to_pi(float a) {
     const float two_pi = 6.283185307179586f;
     float m = fmodf(a, two_pi);
-    if (m != 0.f && m < 0.f) m += two_pi;
     if (m > 3.141592653589793f) m -= two_pi;
     return m;
 }
@@ -1053,7 +1053,9 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
     case LG_PHASE_PRE | LG_PHASE_SIM | LG_PHASE_POST:
         hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_PRE | LG_PHASE_SIM | LG_PHASE_POST>), grid, block, 0, st, p); break;
     case LG_PHASE_RESET: hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_RESET>), grid, block, 0, st, p); break;
-    default: return fail("lg_step: unsupported phase combination (ALL, SIM, PRE|POST|RESET, PRE|SIM|POST, RESET)");
+    case LG_PHASE_PRE | LG_PHASE_POST:
+        hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_PRE | LG_PHASE_POST>), grid, block, 0, st, p); break;
+    default: return fail("lg_step: unsupported phase combination (ALL, SIM, PRE|POST|RESET, PRE|SIM|POST, PRE|POST, RESET)");
     }
     HIPCHK(hipGetLastError());
     return 0;

@@ -1,0 +1,288 @@
+"""numpy restatement of the MDP part of one control step (everything LeggedRobot.step does
+around the physics).  TEST INFRASTRUCTURE ONLY (see oracle/lg_oracle.c header).
+
+Pinned by golden vectors generated from the reference's own env classes
+(tests/golden/gen_mdp_fixtures.py -> tests/golden/*_mdp.npz; tests/test_mdp_oracle.py).
+Each block cites the reference lines it follows.  All arithmetic is float32 like torch's.
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from hcr_genesis_lr_cl_amd import abi
+from hcr_genesis_lr_cl_amd import config as cfgmod
+
+f32 = np.float32
+
+
+def quat_rotate_inverse(q, v):
+    """math_utils.py:64-76."""
+    qw = q[:, 3:4]
+    qv = q[:, :3]
+    a = v * (f32(2.0) * qw ** 2 - f32(1.0))
+    b = np.cross(qv, v) * (f32(2.0) * qw)
+    c = qv * (f32(2.0) * np.sum(qv * v, axis=1, keepdims=True))
+    return (a - b + c).astype(f32)
+
+
+def quat_apply(q, v):
+    """math_utils.py:34-40."""
+    xyz = q[:, :3]
+    t = np.cross(xyz, v) * f32(2)
+    return (v + q[:, 3:4] * t + np.cross(xyz, t)).astype(f32)
+
+
+def wrap_to_pi(a):
+    """math_utils.py:50-53.  Under TorchScript the in-place ``angles %= 2*pi`` lowers to
+    aten::fmod_ (C-style remainder, sign of the dividend), NOT torch.remainder: negative angles
+    are left in (-2*pi, 0] and only values above +pi are shifted.  Verified on the scripted
+    function's graph; reproduced here because the heading command depends on it."""
+    two_pi = f32(2 * np.pi)
+    a = np.fmod(a.astype(f32), two_pi)
+    return (a - two_pi * (a > f32(np.pi))).astype(f32)
+
+
+def get_euler_xyz(q):
+    """math_utils.py:90-109."""
+    qx, qy, qz, qw = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    roll = np.arctan2(f32(2) * (qw * qx + qy * qz), qw * qw - qx * qx - qy * qy + qz * qz)
+    sinp = f32(2) * (qw * qy - qz * qx)
+    pitch = np.where(np.abs(sinp) >= 1, np.copysign(f32(np.pi / 2), sinp), np.arcsin(np.clip(sinp, -1, 1)))
+    yaw = np.arctan2(f32(2) * (qw * qz + qx * qy), qw * qw + qx * qx - qy * qy - qz * qz)
+    return np.stack([roll, pitch, yaw], 1).astype(f32)
+
+
+class MdpOracle:
+    def __init__(self, model, cfg, task, n_envs, env_origins=None):
+        self.model, self.cfg, self.task, self.N = model, cfg, task, n_envs
+        N, A, F = n_envs, model.n_dof, model.n_legs
+        self.A, self.F, self.L = A, F, model.n_links
+        self.dt = f32(task.control_dt)
+        self.q0 = cfgmod.default_dof_pos(cfg)
+        self.soft = cfgmod.soft_dof_limits(model, cfg)
+        self.feet = [int(i) for i in sorted(model.arrays["foot_link"][:F])]
+        self.term = model.find_link_indices(cfg.asset.terminate_after_contacts_on)
+        self.pen = model.find_link_indices(cfg.asset.penalize_contacts_on)
+        self.scales = np.ctypeslib.as_array(task.reward_scales).copy()
+        self.noise_vec = np.ctypeslib.as_array(task.noise_vec)[:task.obs_frame].copy()
+        z = lambda *s: np.zeros(s, f32)
+        self.actions, self.last_actions, self.llast_actions = z(N, A), z(N, A), z(N, A)
+        self.commands = z(N, 4)
+        self.feet_air_time = z(N, F)
+        self.last_contacts = np.zeros((N, F), bool)
+        self.episode_length_buf = np.zeros(N, np.int32)
+        self.fail_buf = np.zeros(N, np.int64)
+        self.reset_buf = np.zeros(N, bool)
+        self.time_out_buf = np.zeros(N, bool)
+        self.rew_buf = z(N)
+        self.obs_buf = z(N, task.num_obs)
+        self.episode_sums = z(abi.R_COUNT, N)
+        self.env_origins = z(N, 3) if env_origins is None else env_origins.astype(f32)
+        cr = cfg.commands.ranges
+        self.command_ranges = np.array(list(cr.lin_vel_x) + list(cr.lin_vel_y) + list(cr.ang_vel_yaw) + list(cr.heading), f32)
+        # DR / engine-side per-env values written at reset
+        self.friction_values, self.added_base_mass = np.ones((N, 1), f32), z(N, 1)
+        self.base_com_bias, self.rand_push_vels = z(N, 3), z(N, 3)
+        self.kp_scale, self.kd_scale = np.ones((N, A), f32), np.ones((N, A), f32)
+
+    # ---------------------------------------------------------------------------------------
+    def _resample(self, ids, R, slot):
+        """legged_robot.py:317-334."""
+        cr, c = self.command_ranges, self.commands
+        c[ids, 0] = (cr[1] - cr[0]) * R[ids, slot] + cr[0]
+        c[ids, 1] = (cr[3] - cr[2]) * R[ids, slot + 1] + cr[2]
+        if self.task.heading_command:
+            c[ids, 3] = (cr[7] - cr[6]) * R[ids, slot + 2] + cr[6]
+        else:
+            c[ids, 2] = (cr[5] - cr[4]) * R[ids, slot + 2] + cr[4]
+        keep = np.sqrt(np.sum(c[ids, :3] ** 2, axis=1)) > f32(0.2)
+        c[ids, :3] *= keep[:, None]
+
+    def step(self, sim, actions, R, counter):
+        """sim: dict of physics read-backs AFTER the physics of this step (modified in place for
+        resets / pushes, like the engine state).  R: (N, n_slots) uniforms.  counter: value of
+        common_step_counter after this step's increment."""
+        T, S, N, A, F = self.task, self.task.slots, self.N, self.A, self.F
+        sc = self.scales
+        # ---- _pre_sim_step: legged_robot.py:230-239
+        a = np.clip(actions.astype(f32), -f32(T.clip_actions), f32(T.clip_actions))
+        self.llast_actions[:] = self.last_actions
+        self.last_actions[:] = self.actions
+        self.actions[:] = a
+        # ---- read-back: genesis_simulator.py:40-46
+        q = sim["base_quat"]
+        blv = quat_rotate_inverse(q, sim["base_lin_vel_w"])
+        bav = quat_rotate_inverse(q, sim["base_ang_vel_w"])
+        g = np.tile(np.array([0, 0, -1], f32), (N, 1))
+        pg = quat_rotate_inverse(q, g)
+        # ---- post_physics_step: legged_robot.py:55-76
+        self.episode_length_buf += 1
+        ids = np.nonzero(self.episode_length_buf % T.resample_steps == 0)[0]
+        self._resample(ids, R, S.cb_cmd)
+        if T.heading_command:                                              # :307-312
+            fwd = quat_apply(q, np.tile(np.array([1, 0, 0], f32), (N, 1)))
+            heading = np.arctan2(fwd[:, 1], fwd[:, 0]).astype(f32)
+            self.commands[:, 2] = np.clip(f32(0.5) * wrap_to_pi(self.commands[:, 3] - heading), f32(T.yaw_clip[0]), f32(T.yaw_clip[1]))
+        if T.push_interval > 0 and counter % T.push_interval == 0:       # :314-315, genesis_simulator.py:150-158
+            m = f32(T.max_push_vel_xy)
+            push = (m + m) * R[:, S.push:S.push + 2] - m
+            self.rand_push_vels[:, :2] = push
+            sim["base_lin_vel_w"][:, :2] += push
+        # ---- check_termination: :78-92
+        F_l = sim["link_contact_forces"].reshape(N, self.L, 3)
+        fail = np.zeros(N, bool)
+        if self.term:
+            fail = np.any(np.linalg.norm(F_l[:, self.term], axis=-1) > 10.0, axis=1)
+        fail |= pg[:, 2] > f32(T.max_projected_gravity)
+        self.fail_buf += fail
+        self.time_out_buf = self.episode_length_buf > T.max_episode_length
+        self.reset_buf = (self.fail_buf > T.fail_threshold) | self.time_out_buf
+        # ---- compute_reward: :150-168 (alphabetical)
+        total = np.zeros(N, f32)
+        cmd = self.commands
+        dof_pos, dof_vel = sim["dof_pos"], sim["dof_vel"]
+        feet_f = F_l[:, self.feet]
+        feet_pos, feet_vel = sim["feet_pos"].reshape(N, F, 3), sim["feet_vel"].reshape(N, F, 3)
+        cmd_xy = np.sqrt(np.sum(cmd[:, :2] ** 2, axis=1))
+        cmd_xyz = np.sqrt(np.sum(cmd[:, :3] ** 2, axis=1))
+
+        def add(name, r):
+            k = abi.REWARD_ID[name]
+            if sc[k] == 0:
+                return
+            rew = (r.astype(f32) * sc[k]).astype(f32)
+            total[:] = total + rew
+            self.episode_sums[k] += rew
+        R_ = abi.REWARD_ID
+        on = lambda n: sc[R_[n]] != 0
+        if on("action_rate"):
+            add("action_rate", np.sum((self.last_actions - self.actions) ** 2, axis=1))
+        if on("action_smoothness"):
+            add("action_smoothness", np.sum((self.actions - f32(2) * self.last_actions + self.llast_actions) ** 2, axis=1))
+        if on("ang_vel_xy"):
+            add("ang_vel_xy", np.sum(bav[:, :2] ** 2, axis=1))
+        if on("base_height"):
+            add("base_height", (sim["base_pos"][:, 2] - f32(T.base_height_target)) ** 2)
+        if on("collision"):
+            add("collision", np.sum(1.0 * (np.linalg.norm(F_l[:, self.pen], axis=-1) > 0.1), axis=1))
+        if on("dof_acc"):
+            add("dof_acc", np.sum(((sim["last_dof_vel"] - dof_vel) / self.dt) ** 2, axis=1))
+        if on("dof_close_to_default"):
+            add("dof_close_to_default", np.sum((dof_pos - self.q0) ** 2, axis=1))
+        if on("dof_pos_limits"):
+            out = -np.clip(dof_pos - self.soft[:, 0], None, 0) + np.clip(dof_pos - self.soft[:, 1], 0, None)
+            add("dof_pos_limits", np.sum(out, axis=1))
+        if on("dof_pos_stand_still"):
+            add("dof_pos_stand_still", np.sum((dof_pos - self.q0) ** 2, axis=1) * (cmd_xyz < 0.1))
+        if on("dof_power"):
+            add("dof_power", np.sum(np.abs(sim["torques"] * dof_vel), axis=1))
+        if on("dof_vel"):
+            add("dof_vel", np.sum(dof_vel ** 2, axis=1))
+        if on("dof_vel_stand_still"):
+            add("dof_vel_stand_still", np.sum(np.abs(dof_vel), axis=1) * (cmd_xyz < 0.1))
+        if on("feet_air_time"):                                            # :545-555
+            contact = feet_f[:, :, 2] > 1.0
+            filt = contact | self.last_contacts
+            self.last_contacts = contact
+            first = (self.feet_air_time > 0) * filt
+            self.feet_air_time += self.dt
+            r = np.sum((self.feet_air_time - f32(T.feet_air_time_threshold)) * first, axis=1)
+            r = r * (cmd_xy > 0.1)
+            self.feet_air_time *= ~filt
+            add("feet_air_time", r)
+        if on("feet_contact_stand_still"):
+            full = np.sum(1.0 * (feet_f[:, :, 2] > 0.1), axis=1) == F
+            add("feet_contact_stand_still", 1.0 * full * (cmd_xyz < 0.1))
+        if on("foot_acc"):
+            acc = (feet_vel - sim["last_feet_vel"].reshape(N, F, 3)) / self.dt
+            add("foot_acc", np.sum(acc ** 2, axis=(1, 2)))
+        if on("foot_clearance"):                                           # :575-588
+            vxy = np.linalg.norm(feet_vel[:, :, :2], axis=-1)
+            err = np.sum(vxy * (feet_pos[:, :, 2] - f32(T.foot_clearance_target) - f32(T.foot_height_offset)) ** 2, axis=-1)
+            add("foot_clearance", np.exp(-err / f32(T.foot_clearance_sigma)))
+        if on("foot_landing_vel"):
+            zv = feet_vel[:, :, 2]
+            land = ((feet_pos[:, :, 2] - f32(T.foot_height_offset)) < f32(T.about_landing_threshold)) & ~(feet_f[:, :, 2] > 0.1) & (zv < 0)
+            add("foot_landing_vel", np.sum(np.where(land, zv, 0) ** 2, axis=1))
+        if on("hip_pos"):
+            add("hip_pos", np.sum((dof_pos[:, 0::3] - self.q0[0::3]) ** 2, axis=1))
+        if on("keep_balance"):
+            add("keep_balance", np.ones(N, f32))
+        if on("lin_vel_z"):
+            add("lin_vel_z", blv[:, 2] ** 2)
+        if on("orientation"):
+            add("orientation", np.sum(pg[:, :2] ** 2, axis=1))
+        if on("torques"):
+            add("torques", np.sum(sim["torques"] ** 2, axis=1))
+        if on("tracking_ang_vel"):
+            add("tracking_ang_vel", np.exp(-((cmd[:, 2] - bav[:, 2]) ** 2) / f32(T.tracking_sigma)))
+        if on("tracking_lin_vel"):
+            add("tracking_lin_vel", np.exp(-np.sum((cmd[:, :2] - blv[:, :2]) ** 2, axis=1) / f32(T.tracking_sigma)))
+        if T.only_positive_rewards:
+            total = np.clip(total, 0, None)
+        if on("termination"):
+            k = R_["termination"]
+            rew = (1.0 * (self.reset_buf & ~self.time_out_buf) * sc[k]).astype(f32)
+            total = total + rew
+            self.episode_sums[k] += rew
+        self.rew_buf = total.astype(f32)
+        # ---- reset_idx: :94-148 (command curriculum is applied by the caller beforehand on gate steps)
+        ids = np.nonzero(self.reset_buf)[0]
+        self.done_sums = None
+        if len(ids):
+            if self.cfg.commands.curriculum and counter % int(T.max_episode_length) == 0:   # :110-111
+                self.update_command_curriculum(ids)
+            self._resample(ids, R, S.reset_cmd)
+            lo = np.ctypeslib.as_array(T.reset_dof_lo)[:A]
+            span = np.ctypeslib.as_array(T.reset_dof_span)[:A]
+            sim["dof_pos"][ids] = self.q0 + (span * R[ids, S.reset_dof:S.reset_dof + A] + lo)   # go2.py:30-35
+            sim["dof_vel"][ids] = 0
+            pos = np.array(self.cfg.init_state.pos, f32) + self.env_origins[ids]
+            if T.custom_origins:
+                pos[:, :2] += f32(T.reset_root_xy_span) * R[ids, S.reset_root_xy:S.reset_root_xy + 2] + f32(T.reset_root_xy_lo)
+            sim["base_pos"][ids] = pos
+            sim["base_quat"][ids] = np.ctypeslib.as_array(T.base_init_quat)
+            lv = f32(T.reset_lin_vel_span) * R[ids, S.reset_lin_vel:S.reset_lin_vel + 3] + f32(T.reset_lin_vel_lo)
+            av = f32(T.reset_ang_vel_span) * R[ids, S.reset_ang_vel:S.reset_ang_vel + 3] + f32(T.reset_ang_vel_lo)
+            sim["base_lin_vel_w"][ids], sim["base_ang_vel_w"][ids] = lv, av
+            blv[ids], bav[ids] = lv, av                                    # genesis_simulator.py:128-129
+            pg = quat_rotate_inverse(sim["base_quat"], g)                  # :125
+            if T.dr_friction_on:
+                self.friction_values[ids, 0] = f32(T.dr_friction_span) * R[ids, S.dr_friction] + f32(T.dr_friction_lo)
+            if T.dr_mass_on:
+                self.added_base_mass[ids, 0] = f32(T.dr_mass_span) * R[ids, S.dr_mass] + f32(T.dr_mass_lo)
+            if T.dr_com_on:
+                for k in range(3):
+                    self.base_com_bias[ids, k] = f32(T.dr_com_span[k]) * R[ids, S.dr_com + k] + f32(T.dr_com_lo[k])
+            if T.dr_pd_on:
+                self.kp_scale[ids] = f32(T.dr_kp_span) * R[ids, S.dr_kp:S.dr_kp + A] + f32(T.dr_kp_lo)
+                self.kd_scale[ids] = f32(T.dr_kd_span) * R[ids, S.dr_kd:S.dr_kd + A] + f32(T.dr_kd_lo)
+            sim["last_dof_vel"][ids] = 0
+            sim["last_feet_vel"].reshape(N, F, 3)[ids] = 0
+            self.llast_actions[ids] = 0; self.last_actions[ids] = 0; self.actions[ids] = 0
+            self.feet_air_time[ids] = 0
+            self.episode_length_buf[ids] = 0
+            self.fail_buf[ids] = 0
+            self.done_sums = (self.episode_sums[:, ids].sum(1), len(ids))
+            self.episode_sums[:, ids] = np.where((sc[:abi.R_COUNT] != 0)[:, None], 0, self.episode_sums[:, ids])
+        # ---- compute_observations: go2.py:40-64, clip legged_robot.py:48-49
+        if T.obs_layout == abi.OBS_GO2:
+            cs = np.array([T.obs_scale_lin_vel, T.obs_scale_lin_vel, T.obs_scale_ang_vel], f32)
+            obs = np.concatenate([self.commands[:, :3] * cs, pg, bav * f32(T.obs_scale_ang_vel),
+                                  (sim["dof_pos"] - self.q0) * f32(T.obs_scale_dof_pos),
+                                  sim["dof_vel"] * f32(T.obs_scale_dof_vel), self.actions], axis=1).astype(f32)
+            if T.add_noise:
+                obs = obs + (f32(2) * R[:, S.noise:S.noise + obs.shape[1]] - f32(1)) * self.noise_vec
+            self.obs_buf = np.clip(obs, -f32(T.clip_obs), f32(T.clip_obs)).astype(f32)
+        else:
+            raise NotImplementedError
+        self.base_lin_vel, self.base_ang_vel, self.projected_gravity = blv, bav, pg
+        return self.obs_buf, self.rew_buf, self.reset_buf
+
+    def update_command_curriculum(self, ids):
+        """legged_robot.py:336-348."""
+        k = abi.REWARD_ID["tracking_lin_vel"]
+        c = self.cfg.commands
+        if np.mean(self.episode_sums[k][ids]) / self.task.max_episode_length > c.curriculum_threshold * self.scales[k]:
+            self.command_ranges[0] = np.clip(self.command_ranges[0] - 0.5, -c.max_curriculum, 0.)
+            self.command_ranges[1] = np.clip(self.command_ranges[1] + 0.5, 0., c.max_curriculum)

@@ -1,0 +1,323 @@
+"""Generates golden vectors for the MDP part of the hot path by RUNNING THE REFERENCE'S OWN
+env classes (legged_gym/envs/...) on CPU against a fake simulator that feeds scripted physics
+read-backs.  Output: tests/golden/<task>_mdp.npz (inputs + expected outputs per step).
+
+Run in the build container only:   PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_mdp_fixtures.py
+
+What is pinned: everything LeggedRobot.step does around the physics -- action clip/history
+(legged_robot.py:230-239), command resampling + heading command + push schedule (:300-334),
+termination (:78-92), every active reward term and the alphabetical sum (:150-168, 458-608),
+reset_idx bookkeeping incl. command curriculum (:94-148, 336-348), task reset distributions
+and observation layout/noise/clip (go2.py:17-134, legged_robot.py:48-49).
+Uniform draws of the reference are intercepted (DrawRecorder) and stored per env in the slot
+layout of include/lgsim.h's LgRandSlots, so the kernel can be fed the very same numbers.
+"""
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_harness as rh  # noqa: E402
+
+rh.load_reference()
+import torch  # noqa: E402
+
+from hcr_genesis_lr_cl_amd import builders  # noqa: E402
+from hcr_genesis_lr_cl_amd.model_compiler import load_model  # noqa: E402
+
+torch.set_num_threads(2)
+
+
+def rand_quat(rng, n, tilt):
+    rpy = rng.normal(size=(n, 3)) * [tilt, tilt, 1.5]
+    cr, sr = np.cos(rpy[:, 0] / 2), np.sin(rpy[:, 0] / 2)
+    cp, sp = np.cos(rpy[:, 1] / 2), np.sin(rpy[:, 1] / 2)
+    cy, sy = np.cos(rpy[:, 2] / 2), np.sin(rpy[:, 2] / 2)
+    q = np.stack([cy * sr * cp - sy * cr * sp, cy * cr * sp + sy * sr * cp, sy * cr * cp - cy * sr * sp,
+                  cy * cr * cp + sy * sr * sp], 1)
+    return q.astype(np.float32)
+
+
+class FakeSimulator:
+    """Duck-typed stand-in for GenesisSimulator: serves scripted read-backs, records writes."""
+
+    def __init__(self, cfg, sim_params, device, headless):
+        from legged_gym.utils.math_utils import quat_rotate_inverse
+        self._qri = quat_rotate_inverse
+        self._cfg, self._device = cfg, device
+        N = self._num_envs = cfg.env.num_envs
+        A = self._num_actions = cfg.env.num_actions
+        self.model = load_model(cfg.asset.name)
+        m = self.model
+        L, F = m.n_links, m.n_legs
+        z = lambda *s: torch.zeros(*s)
+        self._base_pos, self._base_quat, self._base_euler = z(N, 3), z(N, 4), z(N, 3)
+        self._base_quat[:, 3] = 1
+        self._base_lin_vel, self._base_ang_vel, self._projected_gravity = z(N, 3), z(N, 3), z(N, 3)
+        self._base_lin_vel_w, self._base_ang_vel_w = z(N, 3), z(N, 3)
+        self._dof_pos, self._dof_vel, self._last_dof_vel, self._torques = z(N, A), z(N, A), z(N, A), z(N, A)
+        self._link_contact_forces = z(N, L, 3)
+        self._feet_pos, self._feet_vel, self._last_feet_vel = z(N, F, 3), z(N, F, 3), z(N, F, 3)
+        self._feet_indices = m.find_link_indices([n for n in m.link_names if cfg.asset.foot_name in n])
+        self._termination_contact_indices = m.find_link_indices(cfg.asset.terminate_after_contacts_on)
+        self._penalized_contact_indices = m.find_link_indices(cfg.asset.penalize_contacts_on)
+        self._default_dof_pos = torch.tensor([cfg.init_state.default_joint_angles[n] for n in cfg.asset.dof_names]).unsqueeze(0)
+        lim = torch.tensor(np.stack([m.arrays["q_lo"], m.arrays["q_hi"]], 1), dtype=torch.float)
+        for i in range(A):  # genesis_simulator.py:373-382
+            mid = (lim[i, 0] + lim[i, 1]) / 2
+            r = lim[i, 1] - lim[i, 0]
+            lim[i, 0] = mid - 0.5 * r * cfg.rewards.soft_dof_pos_limit
+            lim[i, 1] = mid + 0.5 * r * cfg.rewards.soft_dof_pos_limit
+        self._dof_pos_limits = lim
+        self._base_init_pos = torch.tensor(cfg.init_state.pos)
+        self._base_init_quat = torch.tensor(cfg.init_state.rot)
+        self._custom_origins = cfg.terrain.mesh_type in ("heightfield", "trimesh")
+        self._env_origins = z(N, 3)
+        self._env_origins[:, :2] = torch.from_numpy(np.random.default_rng(5).uniform(-5, 5, (N, 2)).astype(np.float32))
+        self._measured_heights = z(N, 187)
+        self._friction_values, self._added_base_mass = z(N, 1), torch.ones(N, 1)
+        self._base_com_bias, self._rand_push_vels = z(N, 3), z(N, 3)
+        self._kp_scale, self._kd_scale = torch.ones(N, A), torch.ones(N, A)
+        self._global_gravity = torch.tensor([0., 0., -1.]).repeat(N, 1)
+        self.script, self.t, self.rec = None, -1, None
+
+    # -- scripted physics ------------------------------------------------------------------
+    def step(self, actions):
+        self._last_dof_vel[:] = self._dof_vel
+        self._last_feet_vel[:] = self._feet_vel
+        self.t += 1
+
+    def post_physics_step(self):
+        s = {k: torch.from_numpy(v[self.t]) for k, v in self.script.items()}
+        for k in ("base_pos", "base_quat", "base_lin_vel_w", "base_ang_vel_w", "dof_pos", "dof_vel", "torques",
+                  "link_contact_forces", "feet_pos", "feet_vel"):
+            getattr(self, "_" + k)[:] = s[k].reshape(getattr(self, "_" + k).shape)
+        self._base_lin_vel[:] = self._qri(self._base_quat, self._base_lin_vel_w)
+        self._base_ang_vel[:] = self._qri(self._base_quat, self._base_ang_vel_w)
+        self._projected_gravity = self._qri(self._base_quat, self._global_gravity)
+        from legged_gym.utils.math_utils import get_euler_xyz
+        self._base_euler[:] = get_euler_xyz(self._base_quat)
+
+    # -- writes (semantics of genesis_simulator.py:62-158) ---------------------------------------
+    def reset_idx(self, env_ids):
+        d = self._cfg.domain_rand
+        n = len(env_ids)
+        if d.randomize_friction:
+            lo, hi = d.friction_range
+            self._friction_values[env_ids] = self.rec.rand_float(0., 1., (n, 1), "cpu") * (hi - lo) + lo
+        if d.randomize_base_mass:
+            lo, hi = d.added_mass_range
+            self._added_base_mass[env_ids] = self.rec.rand_float(0., 1., (n, 1), "cpu") * (hi - lo) + lo
+        if d.randomize_com_displacement:
+            for k, (lo, hi) in enumerate((d.com_pos_x_range, d.com_pos_y_range, d.com_pos_z_range)):
+                self._base_com_bias[env_ids, k] = self.rec.rand_float(0., 1., (n, 1), "cpu").squeeze(1) * (hi - lo) + lo
+        if d.randomize_pd_gain:
+            self._kp_scale[env_ids] = self.rec.rand_float(d.kp_range[0], d.kp_range[1], (n, self._num_actions), "cpu")
+            self._kd_scale[env_ids] = self.rec.rand_float(d.kd_range[0], d.kd_range[1], (n, self._num_actions), "cpu")
+        self._last_dof_vel[env_ids] = 0.
+        self._last_feet_vel[env_ids] = 0.
+
+    def reset_dofs(self, env_ids, dof_pos, dof_vel):
+        self._dof_pos[env_ids] = dof_pos[:]
+        self._dof_vel[env_ids] = dof_vel[:]
+
+    def reset_root_states(self, env_ids, base_pos, base_quat, base_lin_vel, base_ang_vel):
+        self._base_pos[env_ids, :] = base_pos[:]
+        self._base_quat[env_ids, :] = base_quat[:]
+        self._projected_gravity = self._qri(self._base_quat, self._global_gravity)
+        self._base_lin_vel[env_ids] = base_lin_vel[:]
+        self._base_ang_vel[env_ids] = base_ang_vel[:]
+        self._base_lin_vel_w[env_ids] = base_lin_vel[:]
+        self._base_ang_vel_w[env_ids] = base_ang_vel[:]
+
+    def push_robots(self):
+        m = self._cfg.domain_rand.max_push_vel_xy
+        env_ids = torch.arange(self._num_envs)  # noqa: F841  (picked up by the recorder)
+        push = self.rec.rand_float(-m, m, (self._num_envs, 2), "cpu")
+        self._rand_push_vels[:, :2] = push.clone()
+        self._base_lin_vel_w[:, :2] += push
+
+    def update_sensors(self):
+        pass
+
+    def draw_debug_vis(self):
+        pass
+
+    def set_viewer_camera(self, eye, target):
+        pass
+
+
+for _p in ("feet_indices", "termination_contact_indices", "penalized_contact_indices", "dof_pos_limits",
+           "base_init_pos", "base_init_quat", "base_lin_vel", "base_ang_vel", "projected_gravity", "dof_pos",
+           "dof_vel", "last_dof_vel", "feet_pos", "feet_vel", "last_feet_vel", "base_pos", "base_quat",
+           "base_euler", "measured_heights", "link_contact_forces", "torques", "default_dof_pos", "custom_origins",
+           "env_origins"):
+    setattr(FakeSimulator, _p, property(lambda s, _n="_" + _p: getattr(s, _n)))
+FakeSimulator.feet_contact_indices = property(lambda s: s._feet_indices)
+FakeSimulator.dr_friction_values = property(lambda s: s._friction_values)
+FakeSimulator.dr_added_base_mass = property(lambda s: s._added_base_mass)
+FakeSimulator.dr_base_com_bias = property(lambda s: s._base_com_bias)
+FakeSimulator.dr_rand_push_vels = property(lambda s: s._rand_push_vels)
+
+
+def make_script(rng, model, cfg, N, T):
+    """Scripted read-backs: independent plausible states per step, biased to exercise branches."""
+    A, L, F = model.n_dof, model.n_links, model.n_legs
+    q0 = np.array([cfg.init_state.default_joint_angles[n] for n in cfg.asset.dof_names], np.float32)
+    s = {}
+    s["base_pos"] = (rng.normal(size=(T, N, 3)) * [2, 2, 0.03] + [0, 0, 0.32]).astype(np.float32)
+    tilt = np.where(rng.random((T, N)) < 0.08, 1.2, 0.15)
+    s["base_quat"] = np.stack([rand_quat(rng, N, tilt[t][:, None] * np.ones((N, 1)))[:, :] if False else rand_quat(rng, N, 0.15) for t in range(T)])
+    big = rng.random((T, N)) < 0.08
+    for t in range(T):
+        if big[t].any():
+            s["base_quat"][t][big[t]] = rand_quat(rng, int(big[t].sum()), 1.3)
+    s["base_lin_vel_w"] = (rng.normal(size=(T, N, 3)) * [0.6, 0.4, 0.15]).astype(np.float32)
+    s["base_ang_vel_w"] = (rng.normal(size=(T, N, 3)) * [0.5, 0.5, 0.8]).astype(np.float32)
+    s["dof_pos"] = (q0 + rng.normal(size=(T, N, A)) * 0.35).astype(np.float32)
+    s["dof_vel"] = (rng.normal(size=(T, N, A)) * 3.0).astype(np.float32)
+    s["torques"] = (rng.normal(size=(T, N, A)) * 8.0).astype(np.float32)
+    f = np.zeros((T, N, L, 3), np.float32)
+    feet = [int(i) for i in model.arrays["foot_link"][:F]]
+    for l in range(L):
+        if l in feet:
+            on = rng.random((T, N)) < 0.6
+            f[:, :, l, 2] = on * rng.uniform(0.05, 80, (T, N))
+            f[:, :, l, :2] = on[..., None] * rng.normal(size=(T, N, 2)) * 10
+        else:
+            on = rng.random((T, N)) < (0.06 if l == 0 else 0.1)
+            f[:, :, l] = on[..., None] * rng.normal(size=(T, N, 3)) * (12 if l == 0 else 3)
+    s["link_contact_forces"] = f
+    s["feet_pos"] = (rng.normal(size=(T, N, F, 3)) * [0.2, 0.15, 0.03] + [0, 0, 0.05]).astype(np.float32)
+    s["feet_vel"] = (rng.normal(size=(T, N, F, 3)) * [0.8, 0.4, 0.5]).astype(np.float32)
+    return s
+
+
+def slots_from_calls(calls, slots, N, A, policy_dof_groups):
+    """Scatter the recorded draws of one step into the (N, n_slots) row layout."""
+    R = np.zeros((N, slots.n_slots), np.float32)
+    seen = {}
+    for c in calls:
+        key = (c["caller"], c["parent"])
+        k = seen.get(key, 0)
+        seen[key] = k + 1
+        u = c["u"].numpy()
+        ids = None if c["env_ids"] is None else c["env_ids"].numpy()
+        if c["caller"] == "_resample_commands":
+            base = slots.cb_cmd if c["parent"] == "_post_physics_step_callback" else slots.reset_cmd
+            R[ids, base + k] = u[:, 0]
+        elif c["caller"] == "push_robots":
+            R[:, slots.push:slots.push + 2] = u
+        elif c["caller"] == "_reset_dofs":
+            cols = policy_dof_groups[k]
+            for j, col in enumerate(cols):
+                R[ids, slots.reset_dof + col] = u[:, j]
+        elif c["caller"] == "_reset_root_states":
+            base = [slots.reset_lin_vel, slots.reset_ang_vel][k] if u.shape[1] == 3 else slots.reset_root_xy
+            R[ids, base:base + u.shape[1]] = u
+        elif c["caller"] == "reset_idx":     # FakeSimulator.reset_idx: friction, mass, com x/y/z, kp, kd
+            order = [(slots.dr_friction, 1), (slots.dr_mass, 1), (slots.dr_com, 1), (slots.dr_com + 1, 1),
+                     (slots.dr_com + 2, 1), (slots.dr_kp, A), (slots.dr_kd, A)]
+            base, w = order[k]
+            R[ids, base:base + w] = u.reshape(len(ids), -1)
+        elif c["caller"] == "rand_like":
+            R[:, slots.noise:slots.noise + u.shape[1]] = u
+        else:
+            raise RuntimeError(f"unmapped draw from {c['caller']} <- {c['parent']}")
+    return R
+
+
+def gen_go2(N=24, T=64, seed=7):
+    import legged_gym.envs.base.base_task as base_task
+    import legged_gym.envs.base.legged_robot as lr_mod
+    import legged_gym.envs.go2.go2 as go2_mod
+    from legged_gym.envs.go2.go2_config import GO2Cfg
+    from legged_gym.utils.helpers import class_to_dict
+    from hcr_genesis_lr_cl_amd.config import GO2Cfg as MyCfg
+
+    rec = rh.DrawRecorder(seed)
+    base_task.GenesisSimulator = FakeSimulator
+    lr_mod.torch_rand_float = rec.rand_float
+    go2_mod.torch_rand_float = rec.rand_float
+    orig_rand_like = torch.rand_like
+    torch.rand_like = rec.rand_like
+    try:
+        cfg = GO2Cfg()
+        cfg.env.num_envs = N
+        env = go2_mod.GO2(cfg, class_to_dict(cfg.sim), "cpu", True)
+        sim = env.simulator
+        sim.rec = rec
+        rng = np.random.default_rng(seed + 1)
+        model = sim.model
+        sim.script = make_script(rng, model, cfg, N, T)
+        mycfg = MyCfg()
+        task = builders.make_task_cfg(model, mycfg)
+        slots = task.slots
+        groups = [[0, 3, 6, 9], [1, 4, 7, 10], [2, 5, 8, 11]]      # go2.py:30-35
+        # initial MDP state: as after construction, with episode clocks spread so that resampling
+        # (ep_len % 500 == 0) and time-outs (ep_len > 1000) occur inside the window
+        env.episode_length_buf[:] = torch.from_numpy(rng.choice(
+            [3, 120, 470, 480, 495, 498, 499, 960, 985, 995, 998, 999, 1000], N).astype(np.int32))
+        env.commands[:] = torch.from_numpy((rng.normal(size=(N, 4)) * [0.4, 0.4, 0.5, 1.5]).astype(np.float32))
+        env.common_step_counter = 745                                   # push at 750
+        env.reset_buf[:] = 0
+        rec.take()
+        init = dict(episode_length_buf=env.episode_length_buf.numpy().copy(), commands=env.commands.numpy().copy(),
+                    env_origins=sim._env_origins.numpy().copy(), default_dof_pos=sim._default_dof_pos.numpy().copy())
+        out = {k: [] for k in ("actions_in", "rand", "counter", "obs", "rew", "reset", "time_out", "commands", "ep_len",
+                               "fail_buf", "feet_air_time", "last_contacts", "episode_sums", "act_hist", "sim_dof_pos",
+                               "sim_dof_vel", "sim_base_pos", "sim_base_quat", "sim_base_lin_vel_w", "sim_projected_gravity",
+                               "sim_base_lin_vel", "dr", "cmd_range_x", "last_dof_vel_in", "last_feet_vel_in", "esum_override")}
+        names = env.reward_names
+        for t in range(T):
+            override = 0.0
+            if t == 30:
+                env.common_step_counter = 995                            # command curriculum gate at 1000
+            if env.common_step_counter + 1 == 1000:
+                override = 18.5                                          # > 0.8 * scale * max_len = 16
+                env.episode_sums["tracking_lin_vel"][:] = override
+                # make sure somebody resets at this step
+                env.episode_length_buf[:4] = 1000
+            act = torch.from_numpy((rng.normal(size=(N, 12)) * (1.0 if t % 7 else 60.0)).astype(np.float32))
+            # what the kernel is given as "last" values for this step
+            out["last_dof_vel_in"].append(sim._dof_vel.numpy().copy())
+            out["last_feet_vel_in"].append(sim._feet_vel.numpy().copy())
+            obs, priv, rew, reset, extras = env.step(act)
+            calls = rec.take()
+            out["actions_in"].append(act.numpy().copy())
+            out["rand"].append(slots_from_calls(calls, slots, N, 12, groups))
+            out["counter"].append(env.common_step_counter)
+            out["esum_override"].append(override)
+            out["obs"].append(obs.numpy().copy()); out["rew"].append(rew.numpy().copy())
+            out["reset"].append(reset.numpy().astype(np.uint8)); out["time_out"].append(env.time_out_buf.numpy().astype(np.uint8))
+            out["commands"].append(env.commands.numpy().copy()); out["ep_len"].append(env.episode_length_buf.numpy().copy())
+            out["fail_buf"].append(env.fail_buf.numpy().copy()); out["feet_air_time"].append(env.feet_air_time.numpy().copy())
+            out["last_contacts"].append(env.last_contacts.numpy().astype(np.uint8))
+            out["episode_sums"].append(np.stack([env.episode_sums[n].numpy().copy() for n in names]))
+            out["act_hist"].append(np.stack([env.actions.numpy(), env.last_actions.numpy(), env.llast_actions.numpy()]).copy())
+            out["sim_dof_pos"].append(sim._dof_pos.numpy().copy()); out["sim_dof_vel"].append(sim._dof_vel.numpy().copy())
+            out["sim_base_pos"].append(sim._base_pos.numpy().copy()); out["sim_base_quat"].append(sim._base_quat.numpy().copy())
+            out["sim_base_lin_vel_w"].append(sim._base_lin_vel_w.numpy().copy())
+            out["sim_projected_gravity"].append(sim._projected_gravity.numpy().copy())
+            out["sim_base_lin_vel"].append(sim._base_lin_vel.numpy().copy())
+            out["dr"].append(np.concatenate([sim._friction_values.numpy(), sim._added_base_mass.numpy(), sim._base_com_bias.numpy(),
+                                             sim._rand_push_vels.numpy()[:, :2]], 1).copy())
+            out["cmd_range_x"].append(np.array(env.command_ranges["lin_vel_x"], np.float32))
+        arrays = {k: np.stack(v) for k, v in out.items()}
+        arrays.update({"script_" + k: v for k, v in sim.script.items()})
+        arrays.update({"init_" + k: v for k, v in init.items()})
+        arrays["reward_names"] = np.array(names)
+        path = os.path.join(HERE, "go2_mdp.npz")
+        np.savez_compressed(path, **arrays)
+        print("wrote", path, {k: v.shape for k, v in arrays.items() if k in ("obs", "rand", "episode_sums")},
+              "resets/step", arrays["reset"].sum(1)[:40], "cmd_range_x", arrays["cmd_range_x"][-1])
+    finally:
+        torch.rand_like = orig_rand_like
+
+
+if __name__ == "__main__":
+    gen_go2()

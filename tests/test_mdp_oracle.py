@@ -1,0 +1,86 @@
+"""Pins the numpy MDP oracle (oracle/mdp_oracle.py) against golden vectors produced by running
+the reference's own GO2 task class (tests/golden/gen_mdp_fixtures.py).  Tolerances: float sums of
+12 squares etc. may associate differently than torch -> rtol 2e-6 / atol 2e-6 on floats;
+integers, booleans and counters are exact."""
+import os
+
+import numpy as np
+import pytest
+
+from hcr_genesis_lr_cl_amd import abi, builders
+from hcr_genesis_lr_cl_amd.config import GO2Cfg
+from hcr_genesis_lr_cl_amd.model_compiler import load_model
+from oracle.mdp_oracle import MdpOracle
+
+GOLD = os.path.join(os.path.dirname(__file__), "golden", "go2_mdp.npz")
+
+
+def replay(make_stepper, check):
+    """Drive an MDP implementation through the fixture; `make_stepper(fx, N)` returns an object
+    with .load_init(fx), .apply_override(t, fx), .step(t, sim_in, actions, R, counter) -> dict."""
+    fx = np.load(GOLD)
+    T, N = fx["obs"].shape[:2]
+    st = make_stepper(fx, N)
+    for t in range(T):
+        sim_in = {k[len("script_"):]: fx[k][t].copy() for k in fx.files if k.startswith("script_")}
+        sim_in["last_dof_vel"] = fx["last_dof_vel_in"][t].copy()
+        sim_in["last_feet_vel"] = fx["last_feet_vel_in"][t].copy()
+        out = st.step(t, sim_in, fx["actions_in"][t], fx["rand"][t], int(fx["counter"][t]), float(fx["esum_override"][t]))
+        check(t, fx, out)
+
+
+class OracleStepper:
+    def __init__(self, fx, N):
+        model, cfg = load_model("go2"), GO2Cfg()
+        task = builders.make_task_cfg(model, cfg)
+        self.o = MdpOracle(model, cfg, task, N, fx["init_env_origins"])
+        self.o.episode_length_buf[:] = fx["init_episode_length_buf"]
+        self.o.commands[:] = fx["init_commands"]
+        self.names = [str(n) for n in fx["reward_names"]]
+
+    def step(self, t, sim, actions, R, counter, override):
+        o = self.o
+        if override:
+            o.episode_sums[abi.REWARD_ID["tracking_lin_vel"]][:] = override
+            o.episode_length_buf[:4] = 1000
+        o.step(sim, actions, R, counter)
+        return dict(obs=o.obs_buf, rew=o.rew_buf, reset=o.reset_buf, time_out=o.time_out_buf, commands=o.commands,
+                    ep_len=o.episode_length_buf, fail_buf=o.fail_buf, feet_air_time=o.feet_air_time,
+                    last_contacts=o.last_contacts,
+                    episode_sums=np.stack([o.episode_sums[abi.REWARD_ID[n]] for n in self.names]),
+                    act_hist=np.stack([o.actions, o.last_actions, o.llast_actions]),
+                    sim_dof_pos=sim["dof_pos"], sim_dof_vel=sim["dof_vel"], sim_base_pos=sim["base_pos"],
+                    sim_base_quat=sim["base_quat"], sim_base_lin_vel_w=sim["base_lin_vel_w"],
+                    sim_projected_gravity=o.projected_gravity, sim_base_lin_vel=o.base_lin_vel,
+                    dr=np.concatenate([o.friction_values, o.added_base_mass, o.base_com_bias, o.rand_push_vels[:, :2]], 1),
+                    cmd_range_x=o.command_ranges[:2])
+
+
+EXACT = ("reset", "time_out", "ep_len", "fail_buf", "last_contacts")
+FLOAT = ("obs", "rew", "commands", "feet_air_time", "episode_sums", "act_hist", "sim_dof_pos", "sim_dof_vel",
+         "sim_base_pos", "sim_base_quat", "sim_base_lin_vel_w", "sim_projected_gravity", "sim_base_lin_vel", "cmd_range_x")
+
+
+def check_against_fixture(t, fx, out, rtol=2e-6, atol=2e-6):
+    for k in EXACT:
+        np.testing.assert_array_equal(np.asarray(out[k]).astype(np.int64), fx[k][t].astype(np.int64), err_msg=f"{k} @ step {t}")
+    for k in FLOAT:
+        np.testing.assert_allclose(out[k], fx[k][t], rtol=rtol, atol=atol, err_msg=f"{k} @ step {t}")
+    # DR values: friction/mass/com from the fake simulator's draws; added mass starts at 1 in the
+    # reference's buffer (genesis_simulator.py:648) but 0 here until the first reset of an env
+    dr_ref, dr = fx["dr"][t], np.asarray(out["dr"])
+    touched = np.abs(dr_ref[:, 1] - 1.0) > 0
+    np.testing.assert_allclose(dr[touched], dr_ref[touched], rtol=rtol, atol=atol, err_msg=f"dr @ step {t}")
+
+
+def test_fixture_exercises_the_branches():
+    fx = np.load(GOLD)
+    assert fx["reset"].sum() >= 8 and fx["time_out"].sum() >= 3
+    assert (fx["reset"].astype(bool) & ~fx["time_out"].astype(bool)).sum() >= 2      # failure terminations
+    assert (fx["counter"] % 750 == 0).any() and (fx["counter"] % 1000 == 0).any()   # push + curriculum steps
+    assert fx["cmd_range_x"][-1][1] == 1.0 and fx["cmd_range_x"][0][1] == 0.5        # curriculum fired
+    assert np.abs(fx["actions_in"]).max() > 100                                        # action clip exercised
+
+
+def test_mdp_oracle_reproduces_reference_go2():
+    replay(OracleStepper, check_against_fixture)
