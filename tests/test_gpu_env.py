@@ -1,0 +1,110 @@
+"""GPU: the LeggedRobot/VecEnv surface, determinism, env-shard invariance, fused == split launches."""
+import numpy as np
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _mk(n, **kw):
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    return make_env("go2", n, "cuda:0", **kw)[0]
+
+
+def _rollout(env, steps, seed=3, scale=1.0):
+    import torch
+    g = torch.Generator(device="cuda"); g.manual_seed(seed)
+    env.reset()
+    out = []
+    for _ in range(steps):
+        a = torch.randn(env.num_envs, 12, generator=g, device="cuda") * scale
+        obs, priv, rew, done, extras = env.step(a)
+        out.append((obs.clone(), rew.clone(), done.clone()))
+    torch.cuda.synchronize()
+    return out
+
+
+def test_vecenv_surface():
+    import torch
+    env = _mk(128)
+    assert (env.num_envs, env.num_obs, env.num_privileged_obs, env.num_actions) == (128, 45, None, 12)
+    assert env.max_episode_length == 1000 and abs(env.dt - 0.02) < 1e-12
+    obs, priv = env.reset()
+    assert obs.shape == (128, 45) and priv is None and obs is env.get_observations()
+    obs, priv, rew, done, extras = env.step(torch.zeros(128, 12, device="cuda"))
+    assert rew.shape == (128,) and done.dtype == torch.bool and done.shape == (128,)
+    assert extras["time_outs"].dtype == torch.bool and "episode" in extras
+    keys = list(extras["episode"])
+    assert "rew_tracking_lin_vel" in keys and "max_command_x" in keys and len(keys) == 16
+    assert torch.isfinite(obs).all() and obs.abs().max() <= 100.0
+    # properties of the Simulator ABC (simulator.py:243-613) are live tensors of the right shape
+    s = env.simulator
+    assert s.link_contact_forces.shape == (128, 17, 3) and s.feet_pos.shape == (128, 4, 3)
+    assert s.dof_pos_limits.shape == (12, 2) and s.default_dof_pos.shape == (1, 12)
+    assert s.feet_indices == [4, 8, 12, 16] and s.termination_contact_indices == [0]
+    assert len(s.penalized_contact_indices) == 8 and s.measured_heights.shape == (128, 187)
+
+
+def test_deterministic_and_shard_invariant():
+    import torch
+    a = _rollout(_mk(256), 30)
+    b = _rollout(_mk(256), 30)
+    for (o1, r1, d1), (o2, r2, d2) in zip(a, b):
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+    # a rank owning envs [128, 256) of a 256-env job reproduces that slice bit for bit
+    env = _mk(128, env_id_offset=128, global_num_envs=256)
+    g = torch.Generator(device="cuda"); g.manual_seed(3)
+    env.reset()
+    for t in range(30):
+        act = torch.randn(256, 12, generator=g, device="cuda")[128:].contiguous()
+        obs, _, rew, done, _ = env.step(act)
+        assert torch.equal(obs, a[t][0][128:]) and torch.equal(rew, a[t][1][128:]) and torch.equal(done, a[t][2][128:])
+
+
+def test_fused_launch_equals_split_launches():
+    """Same state in, one control step through (a) the fused launch and (b) PRE|SIM|POST + RESET:
+    identical integers, floats to 1e-5 (the two template instantiations may contract FMAs
+    differently; contact dynamics would amplify that over many steps, so states are re-synced
+    every step)."""
+    import torch
+    from hcr_genesis_lr_cl_amd import abi
+    e1, e2 = _mk(256), _mk(256)
+    e1.reset(); e2.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(5)
+    for t in range(40):
+        for k, v in e1._engine.buf.items():
+            e2._engine.buf[k].copy_(v)
+        e2.common_step_counter = e1.common_step_counter
+        act = torch.randn(256, 12, generator=g, device="cuda")
+        e1.step(act)
+        e2.common_step_counter += 1
+        e2._engine.step(abi.PHASE_PRE | abi.PHASE_SIM | abi.PHASE_POST, act, e2.common_step_counter)
+        e2._engine.step(abi.PHASE_RESET, None, e2.common_step_counter)
+        torch.cuda.synchronize()
+        # velocities through a stiff contact solve carry ~1e-4 of instantiation-dependent round-off
+        for k, tol in (("obs_buf", 2e-4), ("rew_buf", 1e-5), ("dof_pos", 1e-5), ("dof_vel", 2e-3), ("base_pos", 1e-5),
+                       ("commands", 1e-6), ("episode_sums", 1e-5), ("feet_air_time", 0)):
+            np.testing.assert_allclose(e1._engine.buf[k].cpu().numpy(), e2._engine.buf[k].cpu().numpy(), rtol=1e-5, atol=tol, err_msg=f"{k} @ {t}")
+        assert torch.equal(e1._engine.buf["reset_buf"], e2._engine.buf["reset_buf"])
+        assert torch.equal(e1._engine.buf["episode_length_buf"], e2._engine.buf["episode_length_buf"])
+
+
+def test_long_random_rollout_is_sane():
+    """600 control steps of N(0,1) actions: nothing diverges, failures terminate and reset,
+    episode bookkeeping behaves (quirk 7/8 of SURVEY.md: fail_buf accumulates, reset > 5)."""
+    import torch
+    env = _mk(1024)
+    env.reset()
+    env.episode_length_buf[:] = torch.randint(0, 1000, (1024,), device="cuda", dtype=torch.int32)
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    n_reset = 0
+    for t in range(600):
+        obs, _, rew, done, extras = env.step(torch.randn(1024, 12, generator=g, device="cuda"))
+        n_reset += int(done.sum())
+    assert torch.isfinite(obs).all() and torch.isfinite(rew).all() and (rew >= 0).all()   # only_positive_rewards
+    assert n_reset > 600          # random policies fall over (and time out) regularly
+    assert int(env.episode_length_buf.max()) <= 1001 and int(env.fail_buf.max()) <= 6
+    s = env.simulator
+    assert float(s.base_pos[:, 2].min()) > -0.05 and float(s.base_pos[:, 2].max()) < 1.5
+    assert float(s.dof_vel.abs().max()) <= 2 * 30.1 + 1e-3
+    ep = extras["episode"]
+    assert torch.isfinite(torch.as_tensor(float(ep["rew_tracking_lin_vel"])))
