@@ -44,6 +44,7 @@ template <int LEGS> struct LegCtx;
 LG_DEV V3 ld3(const float *p) { return v3(p[0], p[1], p[2]); }
 LG_DEV void st3(float *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
 LG_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+LG_DEV float rcp(float x) { return __builtin_amdgcn_rcpf(x); }  // 1 ulp; physics only, never the MDP arithmetic
 
 // math_utils.py:64-76
 LG_DEV V3 quat_rotate_inverse(float qx, float qy, float qz, float qw, V3 v) {
@@ -121,6 +122,13 @@ struct RandSrc {
         unsigned v = (slot & 3) == 0 ? r.x : ((slot & 3) == 1 ? r.y : ((slot & 3) == 2 ? r.z : r.w));
         return u01(v);
     }
+    // a whole Philox block (4 uniforms) from a counter space disjoint from the slot space; used
+    // where a lane needs several draws per step (observation noise)
+    LG_DEV void block3(int id, float &a, float &b, float &c) const {
+        U4 ctr = {e_lo, e_hi, step, 0x80000000u + (unsigned)id};
+        U4 r = philox4x32_10(ctr, k0, k1);
+        a = u01(r.x); b = u01(r.y); c = u01(r.z);
+    }
 };
 
 // math_utils.py:50-53 as TorchScript executes it: `angles %= 2*pi` lowers to aten::fmod_
@@ -138,7 +146,16 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     constexpr bool DO_PRE = (PH & LG_PHASE_PRE) != 0, DO_SIM = (PH & LG_PHASE_SIM) != 0;
     constexpr bool DO_POST = (PH & LG_PHASE_POST) != 0, DO_RESET = (PH & LG_PHASE_RESET) != 0;
     constexpr int A = LEGS * 3;
-    const LgModelDesc *__restrict__ M = p.M;
+    // model table -> LDS once per workgroup: per-lane (leg-indexed) reads then cost an LDS access
+    // instead of an L2 round trip with a single wave per SIMD to hide it
+    __shared__ LgModelDesc sM;
+    {
+        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.M);
+        uint32_t *dst = reinterpret_cast<uint32_t *>(&sM);
+        for (int i = threadIdx.x; i < (int)(sizeof(LgModelDesc) / 4); i += BLOCK) dst[i] = src[i];
+    }
+    __syncthreads();
+    const LgModelDesc *M = &sM;
     const LgSimOptions *__restrict__ O = p.O;
     const LgTaskCfg *__restrict__ T = p.T;
     const LgBuffers &B = p.B;
@@ -288,13 +305,13 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 if (depth > -margin) {
                     const V3 v = V.l + cross(V.a, r);
                     const float vn = dot(v, n), wi = M->sph_w[s];
-                    const float fn = (kc * depth - kappa * vn) / (1.f + kappa * dt * wi);
+                    const float fn = (kc * depth - kappa * vn) * rcp(1.f + kappa * dt * wi);
                     if (fn > 0.f) {
                         const V3 vt = v - n * vn;
                         const float vtn = norm(vt);
-                        const float ft = fminf(vtn / (dt * wi), mu * fn);
+                        const float ft = fminf(vtn * rcp(dt * wi), mu * fn);
                         V3 f = n * fn;
-                        if (vtn > 1e-9f) f -= vt * (ft / vtn);
+                        if (vtn > 1e-9f) f -= vt * (ft * rcp(vtn));
                         const V3 cp = r - n * rad;
                         pacc.a += cross(cp, f);
                         pacc.l += f;
@@ -355,7 +372,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                     }
                 }
                 J[j].U = mul(IAacc, J[j].S);
-                J[j].dinv = 1.f / (dot(J[j].S, J[j].U) + arm[j]);
+                J[j].dinv = rcp(dot(J[j].S, J[j].U) + arm[j]);
                 J[j].u = tau[j] - dot(J[j].S, pacc);
                 const V6 Ic6 = mul(IAacc, J[j].c);
                 const float k = (J[j].u - dot(J[j].U, J[j].c)) * J[j].dinv;
@@ -461,8 +478,8 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                         if (solve3(M3x, v3(rn, -vo.y, -vo.z), fsol) && fsol.x > 0.f) {
                             const float ftn = sqrtf(fsol.y * fsol.y + fsol.z * fsol.z);
                             if (ftn > mu * fsol.x) {
-                                const float e1 = fsol.y / ftn, e2 = fsol.z / ftn;
-                                const float fn = rn / (1.f + kappa * (Ac.xx + mu * (Ac.xy * e1 + Ac.xz * e2)));
+                                const float iftn = rcp(ftn), e1 = fsol.y * iftn, e2 = fsol.z * iftn;
+                                const float fn = rn * rcp(1.f + kappa * (Ac.xx + mu * (Ac.xy * e1 + Ac.xz * e2)));
                                 fsol = fn > 0.f ? v3(fn, mu * fn * e1, mu * fn * e2) : v3(0, 0, 0);
                             }
                             fnew = fsol;
@@ -475,7 +492,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                         tl[j] = 0.f;
                         if (lim_s[j] != 0.f) {
                             const float vin = -lim_s[j] * (qd[j] + dt * (qdd[j] + dqdd[j])) + dt * lim_T[j] * J[j].dinv;
-                            const float Tn = (kl * lim_e[j] + kapl * vin) / (1.f + kapl * dt * J[j].dinv);
+                            const float Tn = (kl * lim_e[j] + kapl * vin) * rcp(1.f + kapl * dt * J[j].dinv);
                             lim_T[j] = fmaxf(Tn, 0.f);
                             tl[j] = lim_s[j] * lim_T[j];
                         }
@@ -509,7 +526,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 const float wn = norm(ww), half = 0.5f * wn * dt;
                 float sh, chh;
                 __sincosf(half, &sh, &chh);
-                const float sc = wn > 1e-12f ? sh / wn : 0.5f * dt;
+                const float sc = wn > 1e-12f ? sh * rcp(wn) : 0.5f * dt;
                 const float dx = ww.x * sc, dy = ww.y * sc, dz = ww.z * sc, dw = chh;
                 const float nw = dw * qw - dx * qx - dy * qy - dz * qz;
                 const float nx = dw * qx + qw * dx + dy * qz - dz * qy;
@@ -907,22 +924,39 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             const float co = T->clip_obs;
             const bool nz = T->add_noise != 0;
             const int ns = T->slots.noise;
-            auto put = [&](int idx, float v) {
-                if (nz) v += (2.f * rs.draw(ns + idx) - 1.f) * T->noise_vec[idx];
+            // uniforms for the noisy entries only (commands and actions carry zero noise scale,
+            // go2.py:104-113): q, qd per lane, gravity + ang vel on the lead lane
+            float uq[3] = {0.5f, 0.5f, 0.5f}, uqd[3] = {0.5f, 0.5f, 0.5f}, ub[6] = {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f};
+            if (nz) {
+                if (rs.in) {
+#pragma unroll
+                    for (int j = 0; j < 3; j++) { uq[j] = rs.in[ns + 9 + d0 + j]; uqd[j] = rs.in[ns + 9 + A + d0 + j]; }
+                    if (lead) {
+#pragma unroll
+                        for (int k = 0; k < 6; k++) ub[k] = rs.in[ns + 3 + k];
+                    }
+                } else {
+                    rs.block3(2 * leg, uq[0], uq[1], uq[2]);
+                    rs.block3(2 * leg + 1, uqd[0], uqd[1], uqd[2]);
+                    if (lead) { rs.block3(2 * LEGS, ub[0], ub[1], ub[2]); rs.block3(2 * LEGS + 1, ub[3], ub[4], ub[5]); }
+                }
+            }
+            auto put = [&](int idx, float v, float u) {
+                if (nz) v += (2.f * u - 1.f) * T->noise_vec[idx];
                 o[idx] = clampf(v, -co, co);
             };
             if (live) {
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
-                    put(9 + d0 + j, (q[j] - O->default_dof_pos[d0 + j]) * T->obs_scale_dof_pos);
-                    put(9 + A + d0 + j, qd[j] * T->obs_scale_dof_vel);
-                    put(9 + 2 * A + d0 + j, act[j]);
+                    put(9 + d0 + j, (q[j] - O->default_dof_pos[d0 + j]) * T->obs_scale_dof_pos, uq[j]);
+                    put(9 + A + d0 + j, qd[j] * T->obs_scale_dof_vel, uqd[j]);
+                    put(9 + 2 * A + d0 + j, act[j], 0.5f);
                 }
             }
             if (lead) {
-                put(0, cmd0 * T->obs_scale_lin_vel); put(1, cmd1 * T->obs_scale_lin_vel); put(2, cmd2 * T->obs_scale_ang_vel);
-                put(3, pg.x); put(4, pg.y); put(5, pg.z);
-                put(6, bav.x * T->obs_scale_ang_vel); put(7, bav.y * T->obs_scale_ang_vel); put(8, bav.z * T->obs_scale_ang_vel);
+                put(0, cmd0 * T->obs_scale_lin_vel, 0.5f); put(1, cmd1 * T->obs_scale_lin_vel, 0.5f); put(2, cmd2 * T->obs_scale_ang_vel, 0.5f);
+                put(3, pg.x, ub[0]); put(4, pg.y, ub[1]); put(5, pg.z, ub[2]);
+                put(6, bav.x * T->obs_scale_ang_vel, ub[3]); put(7, bav.y * T->obs_scale_ang_vel, ub[4]); put(8, bav.z * T->obs_scale_ang_vel, ub[5]);
             }
         }
     }

@@ -178,7 +178,7 @@ LG_DEV bool solve3(const M3 &m, V3 b, V3 &x) {
     float c0 = m.yy * m.zz - m.yz * m.zy, c1 = m.yz * m.zx - m.yx * m.zz, c2 = m.yx * m.zy - m.yy * m.zx;
     float det = m.xx * c0 + m.xy * c1 + m.xz * c2;
     if (fabsf(det) < 1e-30f) return false;
-    float inv = 1.f / det;
+    float inv = __builtin_amdgcn_rcpf(det);
     x.x = (b.x * c0 + m.xy * (m.yz * b.z - b.y * m.zz) + m.xz * (b.y * m.zy - m.yy * b.z)) * inv;
     x.y = (m.xx * (b.y * m.zz - m.yz * b.z) + b.x * c1 + m.xz * (m.yx * b.z - b.y * m.zx)) * inv;
     x.z = (m.xx * (m.yy * b.z - b.y * m.zy) + m.xy * (b.y * m.zx - m.yx * b.z) + b.x * c2) * inv;
