@@ -18,7 +18,9 @@ MAX_LINKS = 24
 MAX_SPHERES = 64
 MAX_OBS = 192
 NUM_REWARDS = 40
-CMD_RANGE_FLOATS = 8
+CMD_RANGE_FLOATS = 24
+TASK_STATE_WTW = 22
+TASK_STATE_BIPED = 12
 DONE_RING = 64
 
 PHASE_PRE, PHASE_SIM, PHASE_POST, PHASE_RESET, PHASE_ALL = 1, 2, 4, 8, 15
@@ -73,7 +75,7 @@ class LgRandSlots(C.Structure):
     _fields_ = [(n, i32) for n in (
         "n_slots", "cb_cmd", "push", "reset_cmd", "reset_dof", "reset_root_xy", "reset_lin_vel",
         "reset_ang_vel", "dr_friction", "dr_mass", "dr_com", "dr_kp", "dr_kd", "dr_joint",
-        "terrain_level", "task", "noise")]
+        "terrain_level", "task_cb", "task_reset", "noise")]
 
 
 class LgTaskCfg(C.Structure):
@@ -105,6 +107,8 @@ class LgTaskCfg(C.Structure):
         ("friction_offset", f32), ("kp_offset", f32), ("kd_offset", f32),
         ("terrain_curriculum", i32), ("max_terrain_level", i32), ("terrain_cols_n", i32),
         ("terrain_env_length", f32), ("episode_length_s", f32),
+        ("gait_mode", i32), ("double_shift", i32), ("behavior_resample_steps", i32), ("num_gait_max", i32),
+        ("b_swing", f32), ("gait_period_fixed", f32), ("theta_table", f32 * 4 * 4), ("task_state_width", i32),
         ("slots", LgRandSlots), ("seed", u64), ("env_id_offset", i64),
     ]
 

@@ -66,7 +66,7 @@ def go2_slots(A=12, obs_frame=45):
     off = 0
     for name, w in (("cb_cmd", 3), ("push", 2), ("reset_cmd", 3), ("reset_dof", A), ("reset_root_xy", 2),
                     ("reset_lin_vel", 3), ("reset_ang_vel", 3), ("dr_friction", 1), ("dr_mass", 1), ("dr_com", 3),
-                    ("dr_kp", A), ("dr_kd", A), ("dr_joint", 3), ("terrain_level", 1), ("task", 8),
+                    ("dr_kp", A), ("dr_kd", A), ("dr_joint", 3), ("terrain_level", 1), ("task_cb", 5), ("task_reset", 5),
                     ("noise", obs_frame)):
         setattr(s, name, off)
         off += w
@@ -91,6 +91,23 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
         t.num_priv_obs = t.priv_frame = t.priv_stack = 0
         abi.fill_array(t.noise_vec, go2_noise_vec(cfg))
         t.slots = go2_slots(A, 45)
+    elif layout == "go2_wtw":
+        e = cfg.env
+        t.obs_frame, t.obs_stack, t.num_obs = e.num_single_obs, e.frame_stack, e.num_observations
+        t.priv_frame, t.priv_stack, t.num_priv_obs = e.single_num_privileged_obs, e.c_frame_stack, e.num_privileged_obs
+        nv = np.zeros(e.num_single_obs, np.float32)          # go2_wtw.py:266-293
+        nv[:45] = go2_noise_vec(cfg)
+        abi.fill_array(t.noise_vec, nv)
+        t.slots = go2_slots(A, e.num_single_obs)
+        prf, bp = cfg.rewards.periodic_reward_framework, cfg.rewards.behavior_params_range
+        t.gait_mode, t.double_shift = 1, 1
+        t.behavior_resample_steps = int(bp.resampling_time / dt)           # go2_wtw.py:260-261
+        t.num_gait_max = len(prf.theta_fl_list)
+        t.b_swing = prf.b_swing
+        for g in range(t.num_gait_max):   # feet_indices order FL, FR, RL, RR (go2_wtw.py:382-407)
+            for k, lst in enumerate((prf.theta_fl_list, prf.theta_fr_list, prf.theta_rl_list, prf.theta_rr_list)):
+                t.theta_table[g][k] = lst[g]
+        t.task_state_width = abi.TASK_STATE_WTW
     else:
         raise NotImplementedError(layout)
     t.control_dt = dt

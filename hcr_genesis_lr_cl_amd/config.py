@@ -207,3 +207,45 @@ def soft_dof_limits(model, cfg):
     r = hi - lo
     s = np.float32(cfg.rewards.soft_dof_pos_limit)
     return np.stack([m - np.float32(0.5) * r * s, m + np.float32(0.5) * r * s], axis=1).astype(np.float32)
+
+
+# go2/go2_wtw/go2_wtw_config.py:5-104 (GO2WTWCfg): flat terrain, periodic-gait rewards, PD-gain DR,
+# 5-frame observation / critic histories
+class GO2WTWCfg(LeggedRobotCfg):
+    env = section(LeggedRobotCfg.env, num_envs=4096, num_actions=12, frame_stack=5, c_frame_stack=5,
+                  num_single_obs=61, num_observations=61 * 5, single_num_privileged_obs=61 + 38,
+                  num_privileged_obs=5 * (61 + 38), env_spacing=1.0)
+    terrain = section(GO2Cfg.terrain)
+    init_state = section(GO2Cfg.init_state)
+    control = section(GO2Cfg.control)
+    asset = section(GO2Cfg.asset)
+    rewards = section(
+        LeggedRobotCfg.rewards, soft_dof_pos_limit=0.9, base_height_tracking_sigma=0.01, foot_height_offset=0.022,
+        foot_clearance_tracking_sigma=0.01, euler_tracking_sigma=0.1, about_landing_threshold=0.03,
+        only_positive_rewards=True,
+        scales=section(
+            LeggedRobotCfg.rewards.scales, dof_pos_limits=-10.0, collision=-1.0, tracking_lin_vel=1.0,
+            tracking_ang_vel=0.5, tracking_base_height=0.6, tracking_orientation=0.6, tracking_foot_clearance=0.9,
+            quad_periodic_gait=1.5, lin_vel_z=-0.5, ang_vel_xy=-0.05, dof_vel=-5.0e-4, dof_acc=-2.0e-7,
+            action_rate=-0.01, action_smoothness=-0.01, torques=-2.0e-4, foot_landing_vel=-0.1, hip_pos=-1.0),
+        periodic_reward_framework=section(
+            gait_function_type="step", kappa=20, b_swing=0.5,
+            # trot, pronk, pace, bound
+            theta_fl_list=[0.0, 0.0, 0.5, 0.0], theta_fr_list=[0.5, 0.0, 0.0, 0.0],
+            theta_rl_list=[0.5, 0.0, 0.5, 0.5], theta_rr_list=[0.0, 0.0, 0.0, 0.5]),
+        behavior_params_range=section(
+            resampling_time=5.0, gait_period_range=[0.3, 0.6], foot_clearance_target_range=[0.04, 0.12],
+            base_height_target_range=[0.2, 0.34], pitch_target_range=[-0.3, 0.3]))
+    commands = section(
+        LeggedRobotCfg.commands, curriculum=True, max_curriculum=1.0, num_commands=4, resampling_time=8.0,
+        heading_command=True,
+        ranges=section(LeggedRobotCfg.commands.ranges, lin_vel_x=[-0.5, 0.5], lin_vel_y=[-1.0, 1.0],
+                       ang_vel_yaw=[-1, 1], heading=[-3.14, 3.14]))
+    domain_rand = section(
+        LeggedRobotCfg.domain_rand, randomize_friction=True, friction_range=[0.2, 1.7], randomize_base_mass=True,
+        added_mass_range=[-1.0, 1.0], push_robots=True, push_interval_s=15, max_push_vel_xy=1.0,
+        randomize_com_displacement=True, com_pos_x_range=[-0.03, 0.03], com_pos_y_range=[-0.03, 0.03],
+        com_pos_z_range=[-0.03, 0.03], randomize_pd_gain=True, kp_range=[0.8, 1.2], kd_range=[0.8, 1.2])
+    # GO2WTW derives from LeggedRobot, not GO2: base-class reset distribution (legged_robot.py:274-298)
+    reset = section(dof_ranges={"joint": 0.2}, root_vel_range=0.5, robot="go2", obs_layout="go2_wtw",
+                    feet_air_time_threshold=0.3)

@@ -55,8 +55,7 @@ def buffer_specs(A, L, F, K, P, num_obs, num_priv, num_labels, n_slots, hist, pr
 
 
 class Engine:
-    def __init__(self, model, desc, opts, task, n_envs, device="cuda:0", num_labels=0, task_state=0,
-                 inject_rand=False):
+    def __init__(self, model, desc, opts, task, n_envs, device="cuda:0", num_labels=0, inject_rand=False):
         if not torch.cuda.is_available():
             raise RuntimeError("hcr_genesis_lr_cl_amd needs a HIP device (no CPU fallback)")
         self.lib = abi.load_lib()
@@ -70,7 +69,7 @@ class Engine:
         hist = (task.obs_stack, task.obs_frame) if task.obs_stack > 1 else None
         phist = (task.priv_stack, task.priv_frame) if task.priv_stack > 1 else None
         specs = buffer_specs(A, L, F, K, P, task.num_obs, task.num_priv_obs, num_labels, task.slots.n_slots,
-                             hist, phist, task_state)
+                             hist, phist, int(task.task_state_width))
         self.buf = {k: torch.zeros((self.n,) + tuple(shape), dtype=dt, device=self.device)
                     for k, (shape, dt) in specs.items()}
         self.buf["episode_sums"] = torch.zeros((abi.R_COUNT, self.n), device=self.device)

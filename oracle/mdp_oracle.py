@@ -84,6 +84,52 @@ class MdpOracle:
         self.friction_values, self.added_base_mass = np.ones((N, 1), f32), z(N, 1)
         self.base_com_bias, self.rand_push_vels = z(N, 3), z(N, 3)
         self.kp_scale, self.kd_scale = np.ones((N, A), f32), np.ones((N, A), f32)
+        self.priv_obs_buf = z(N, max(task.num_priv_obs, 1))
+        if task.gait_mode == 1:
+            self._init_wtw()
+
+    def _init_wtw(self):
+        """go2_wtw.py:295-376 (_init_buffers + _parse_cfg)."""
+        N, T = self.N, self.task
+        bp = self.cfg.rewards.behavior_params_range
+        mid = lambda r: [(r[0] + r[1]) / 2] * 2
+        self.gait_period_range = mid(bp.gait_period_range)
+        self.foot_clearance_target_range = [bp.foot_clearance_target_range[0]] * 2
+        self.base_height_target_range = mid(bp.base_height_target_range)
+        self.pitch_target_range = mid(bp.pitch_target_range)
+        self.num_gaits = 1
+        self.theta_table = np.ctypeslib.as_array(T.theta_table).reshape(4, 4).copy()
+        z = lambda *s: np.zeros(s, f32)
+        self.theta = np.tile(self.theta_table[0], (N, 1)).astype(f32)
+        self.gait_time, self.phi = z(N, 1), z(N, 1)
+        self.gait_period = np.full((N, 1), self.gait_period_range[0], f32)
+        self.clock_input = z(N, 8)
+        self.base_height_target = np.full((N, 1), self.base_height_target_range[0], f32)
+        self.foot_clearance_target = np.full((N, 1), self.foot_clearance_target_range[0], f32)
+        self.pitch_target = np.full((N, 1), self.pitch_target_range[0], f32)
+        self.exp_C_frc = z(N, 4)
+        self.obs_hist = z(N, T.obs_stack, T.obs_frame)
+        self.priv_hist = z(N, T.priv_stack, T.priv_frame)
+
+    def behavior_ranges(self):
+        return np.array(self.gait_period_range + self.base_height_target_range + self.foot_clearance_target_range
+                        + self.pitch_target_range + [self.num_gaits], f32)
+
+    def _resample_behavior(self, ids, R, slot):
+        """go2_wtw.py:180-218.  One gait index per call for the whole batch (quirk 6); the pronk/bound
+        clearance clamp is idempotent per env because the lower clearance bound never moves."""
+        if len(ids) == 0:
+            return
+        u = lambda k: R[ids, slot + k][:, None]
+        rg = self.gait_period_range, self.base_height_target_range, self.foot_clearance_target_range, self.pitch_target_range
+        for k, (arr, r) in enumerate(zip((self.gait_period, self.base_height_target, self.foot_clearance_target, self.pitch_target), rg)):
+            arr[ids] = f32(r[1] - r[0]) * u(k) + f32(r[0])
+        sel = min(int(np.floor(R[ids[0], slot + 4] * self.num_gaits)), self.num_gaits - 1)
+        self.theta[ids] = self.theta_table[sel]
+        th = self.theta
+        pronk = (th[:, 0] == 0) & (th[:, 1] == 0) & (th[:, 2] == 0) & (th[:, 3] == 0)
+        bound = (th[:, 0] == 0) & (th[:, 1] == 0) & (th[:, 2] == 0.5) & (th[:, 3] == 0.5)
+        self.foot_clearance_target[pronk | bound] = f32(self.foot_clearance_target_range[0])
 
     # ---------------------------------------------------------------------------------------
     def _resample(self, ids, R, slot):
@@ -128,6 +174,9 @@ class MdpOracle:
             push = (m + m) * R[:, S.push:S.push + 2] - m
             self.rand_push_vels[:, :2] = push
             sim["base_lin_vel_w"][:, :2] += push
+        if T.gait_mode == 1 and T.behavior_resample_steps > 0:           # go2_wtw.py:258-263
+            ids = np.nonzero(self.episode_length_buf % T.behavior_resample_steps == 0)[0]
+            self._resample_behavior(ids, R, S.task_cb)
         # ---- check_termination: :78-92
         F_l = sim["link_contact_forces"].reshape(N, self.L, 3)
         fail = np.zeros(N, bool)
@@ -212,12 +261,43 @@ class MdpOracle:
             add("lin_vel_z", blv[:, 2] ** 2)
         if on("orientation"):
             add("orientation", np.sum(pg[:, :2] ** 2, axis=1))
+        if on("quad_periodic_gait"):                                       # go2_wtw.py:377-484 ("step" indicator)
+            acc = np.zeros(N, f32)
+            b_swing = f32(T.b_swing) * f32(2 * np.pi)
+            for i in range(4):
+                q_frc = np.linalg.norm(feet_f[:, i], axis=-1)
+                q_spd = np.linalg.norm(feet_vel[:, i], axis=-1)
+                ph = np.remainder(self.phi[:, 0] + self.theta[:, i], f32(1.0)).astype(f32) * f32(2 * np.pi)
+                swing = (ph >= 0) & (ph < b_swing)
+                stance = (ph >= b_swing) & (ph < f32(2 * np.pi))
+                c_frc = np.where(swing, -1.0, 0.0).astype(f32)
+                c_spd = np.where(stance, -1.0, 0.0).astype(f32)
+                # reference bug reproduced (go2_wtw.py:455-462): `(mask of shape (N,1)).nonzero().flatten()`
+                # interleaves row and COLUMN indices, so index 0 is in both index lists whenever they are
+                # non-empty: env 0 is overwritten as "swing", then as "stance" if any env is in stance.
+                if swing.any():
+                    c_frc[0], c_spd[0] = -1.0, 0.0
+                if stance.any():
+                    c_frc[0], c_spd[0] = 0.0, -1.0
+                self.exp_C_frc[:, i] = c_frc
+                acc = acc + (c_spd * q_spd + c_frc * q_frc).astype(f32)
+            add("quad_periodic_gait", np.exp(acc))
         if on("torques"):
             add("torques", np.sum(sim["torques"] ** 2, axis=1))
         if on("tracking_ang_vel"):
             add("tracking_ang_vel", np.exp(-((cmd[:, 2] - bav[:, 2]) ** 2) / f32(T.tracking_sigma)))
+        if on("tracking_base_height"):                                     # go2_wtw.py:495-500 (plane: heights are 0)
+            d = sim["base_pos"][:, 2] - self.base_height_target[:, 0]
+            add("tracking_base_height", np.exp(-(d ** 2) / f32(T.base_height_sigma)))
+        if on("tracking_foot_clearance"):                                  # go2_wtw.py:507-519
+            vxy = np.linalg.norm(feet_vel[:, :, :2], axis=-1)
+            err = np.sum(vxy * (feet_pos[:, :, 2] - self.foot_clearance_target - f32(T.foot_height_offset)) ** 2, axis=-1)
+            add("tracking_foot_clearance", np.exp(-err / f32(T.foot_clearance_sigma)))
         if on("tracking_lin_vel"):
             add("tracking_lin_vel", np.exp(-np.sum((cmd[:, :2] - blv[:, :2]) ** 2, axis=1) / f32(T.tracking_sigma)))
+        if on("tracking_orientation"):                                     # go2_wtw.py:502-505
+            eul = get_euler_xyz(q)
+            add("tracking_orientation", np.exp(-(eul[:, 0] ** 2 + (eul[:, 1] - self.pitch_target[:, 0]) ** 2) / f32(T.euler_sigma)))
         if T.only_positive_rewards:
             total = np.clip(total, 0, None)
         if on("termination"):
@@ -226,12 +306,21 @@ class MdpOracle:
             total = total + rew
             self.episode_sums[k] += rew
         self.rew_buf = total.astype(f32)
+        if T.gait_mode == 1:                                               # go2_wtw.py:29-36
+            self.gait_time += self.dt
+            over = self.gait_time >= (self.gait_period - self.dt / f32(2))
+            self.gait_time[over] = 0
+            if over.any():      # same (N,1)-mask .nonzero().flatten() bug as in the gait indicator (go2_wtw.py:33-34):
+                self.gait_time[0] = 0   # env 0's clock restarts whenever ANY env's does
+            self.phi = (self.gait_time / self.gait_period).astype(f32)
         # ---- reset_idx: :94-148 (command curriculum is applied by the caller beforehand on gate steps)
         ids = np.nonzero(self.reset_buf)[0]
         self.done_sums = None
         if len(ids):
             if self.cfg.commands.curriculum and counter % int(T.max_episode_length) == 0:   # :110-111
                 self.update_command_curriculum(ids)
+            if T.gait_mode == 1:
+                self._resample_behavior(ids, R, S.task_reset)
             self._resample(ids, R, S.reset_cmd)
             lo = np.ctypeslib.as_array(T.reset_dof_lo)[:A]
             span = np.ctypeslib.as_array(T.reset_dof_span)[:A]
@@ -263,6 +352,9 @@ class MdpOracle:
             self.feet_air_time[ids] = 0
             self.episode_length_buf[ids] = 0
             self.fail_buf[ids] = 0
+            if T.gait_mode == 1:                                           # go2_wtw.py:139-142, 174-178
+                self.gait_time[ids] = 0; self.phi[ids] = 0; self.clock_input[ids] = 0
+                self.obs_hist[ids] = 0; self.priv_hist[ids] = 0
             self.done_sums = (self.episode_sums[:, ids].sum(1), len(ids))
             self.episode_sums[:, ids] = np.where((sc[:abi.R_COUNT] != 0)[:, None], 0, self.episode_sums[:, ids])
         # ---- compute_observations: go2.py:40-64, clip legged_robot.py:48-49
@@ -274,8 +366,33 @@ class MdpOracle:
             if T.add_noise:
                 obs = obs + (f32(2) * R[:, S.noise:S.noise + obs.shape[1]] - f32(1)) * self.noise_vec
             self.obs_buf = np.clip(obs, -f32(T.clip_obs), f32(T.clip_obs)).astype(f32)
+        elif T.obs_layout == abi.OBS_GO2_WTW:                                # go2_wtw.py:53-111, 251-256
+            for i in range(4):
+                ang = f32(2 * np.pi) * (self.phi[:, 0] + self.theta[:, i])
+                self.clock_input[:, i] = np.sin(ang)
+                self.clock_input[:, i + 4] = np.cos(ang)
+            cs = np.array([T.obs_scale_lin_vel, T.obs_scale_lin_vel, T.obs_scale_ang_vel], f32)
+            frame = np.concatenate([self.commands[:, :3] * cs, pg, bav * f32(T.obs_scale_ang_vel),
+                                    (sim["dof_pos"] - self.q0) * f32(T.obs_scale_dof_pos),
+                                    sim["dof_vel"] * f32(T.obs_scale_dof_vel), self.actions, self.clock_input,
+                                    self.gait_period, self.base_height_target, self.foot_clearance_target,
+                                    self.pitch_target, self.theta], axis=1).astype(f32)
+            priv = np.concatenate([frame, blv * f32(T.obs_scale_lin_vel), self.rand_push_vels[:, :2], self.added_base_mass,
+                                   self.friction_values, self.base_com_bias, self.kp_scale, self.kd_scale,
+                                   self.exp_C_frc], axis=1).astype(f32)
+            now = frame
+            if T.add_noise:
+                now = frame + (f32(2) * R[:, S.noise:S.noise + frame.shape[1]] - f32(1)) * self.noise_vec
+            self.obs_hist = np.concatenate([self.obs_hist[:, 1:], now[:, None]], axis=1)
+            self.priv_hist = np.concatenate([self.priv_hist[:, 1:], priv[:, None]], axis=1)
+            co = f32(T.clip_obs)
+            self.obs_buf = np.clip(self.obs_hist.reshape(N, -1), -co, co).astype(f32)
+            self.priv_obs_buf = np.clip(self.priv_hist.reshape(N, -1), -co, co).astype(f32)
         else:
             raise NotImplementedError
+        if T.double_shift:                                                   # go2_wtw.py:45-46
+            self.llast_actions[:] = self.last_actions
+            self.last_actions[:] = self.actions
         self.base_lin_vel, self.base_ang_vel, self.projected_gravity = blv, bav, pg
         return self.obs_buf, self.rew_buf, self.reset_buf
 

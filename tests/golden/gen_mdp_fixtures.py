@@ -224,6 +224,12 @@ def slots_from_calls(calls, slots, N, A, policy_dof_groups):
                      (slots.dr_com + 2, 1), (slots.dr_kp, A), (slots.dr_kd, A)]
             base, w = order[k]
             R[ids, base:base + w] = u.reshape(len(ids), -1)
+        elif c["caller"] == "_resample_behavior_params":
+            base = slots.task_cb if c["parent"] == "_post_physics_step_callback" else slots.task_reset
+            R[ids, base + k] = u[:, 0]
+        elif c["caller"] == "randint:_resample_behavior_params":
+            base = slots.task_cb if c["parent"] == "_post_physics_step_callback" else slots.task_reset
+            R[ids, base + 4] = float(u[0])
         elif c["caller"] == "rand_like":
             R[:, slots.noise:slots.noise + u.shape[1]] = u
         else:
@@ -319,5 +325,98 @@ def gen_go2(N=24, T=64, seed=7):
         torch.rand_like = orig_rand_like
 
 
+def gen_wtw(N=24, T=64, seed=11):
+    """GO2WTW (go2_wtw.py): periodic-gait rewards, behaviour parameters, 5-frame histories.
+    The command-curriculum gate step is NOT crossed: the reference calls a method that does not
+    exist there (`self.update_command_curriculum`, go2_wtw.py:121) and would raise."""
+    import legged_gym.envs.base.base_task as base_task
+    import legged_gym.envs.base.legged_robot as lr_mod
+    import legged_gym.envs.go2.go2_wtw.go2_wtw as wtw_mod
+    from legged_gym.envs.go2.go2_wtw.go2_wtw_config import GO2WTWCfg
+    from legged_gym.utils.helpers import class_to_dict
+    from hcr_genesis_lr_cl_amd.config import GO2WTWCfg as MyCfg
+
+    rec = rh.DrawRecorder(seed)
+    base_task.GenesisSimulator = FakeSimulator
+    lr_mod.torch_rand_float = rec.rand_float
+    wtw_mod.torch_rand_float = rec.rand_float
+    orig_rand_like, orig_randint = torch.rand_like, torch.randint
+    torch.rand_like, torch.randint = rec.rand_like, rec.randint
+    try:
+        cfg = GO2WTWCfg()
+        cfg.env.num_envs = N
+        env = wtw_mod.GO2WTW(cfg, class_to_dict(cfg.sim), "cpu", True)
+        sim = env.simulator
+        sim.rec = rec
+        rng = np.random.default_rng(seed + 1)
+        model = sim.model
+        sim.script = make_script(rng, model, cfg, N, T)
+        task = builders.make_task_cfg(model, MyCfg())
+        slots = task.slots
+        groups = [list(range(12))]                                        # legged_robot.py:279-280: one (n,12) draw
+        env.episode_length_buf[:] = torch.from_numpy(rng.choice(
+            [3, 120, 245, 248, 249, 395, 398, 399, 498, 499, 748, 960, 985, 995, 998, 999, 1000], N).astype(np.int32))
+        env.commands[:] = torch.from_numpy((rng.normal(size=(N, 4)) * [0.4, 0.4, 0.5, 1.5]).astype(np.float32))
+        env.common_step_counter = 745
+        env.reset_buf[:] = 0
+        # widen the behaviour ranges / gait set as the curriculum would, so every table entry is exercised
+        env.num_gaits = 4
+        env.gait_period_range = [0.3, 0.6]
+        env.base_height_target_range = [0.2, 0.34]
+        env.foot_clearance_target_range = [0.04, 0.12]
+        env.pitch_target_range = [-0.3, 0.3]
+        env.theta[:] = torch.from_numpy(rng.choice([0.0, 0.5], (N, 4)).astype(np.float32))
+        env.gait_period[:] = torch.from_numpy(rng.uniform(0.3, 0.6, (N, 1)).astype(np.float32))
+        env.gait_time[:] = torch.from_numpy(rng.uniform(0.0, 0.3, (N, 1)).astype(np.float32))
+        env.phi[:] = env.gait_time / env.gait_period
+        rec.take()
+        init = dict(episode_length_buf=env.episode_length_buf.numpy().copy(), commands=env.commands.numpy().copy(),
+                    env_origins=sim._env_origins.numpy().copy(), theta=env.theta.numpy().copy(),
+                    gait_period=env.gait_period.numpy().copy(), gait_time=env.gait_time.numpy().copy(), phi=env.phi.numpy().copy(),
+                    behavior_ranges=np.array(env.gait_period_range + env.base_height_target_range +
+                                             env.foot_clearance_target_range + env.pitch_target_range + [env.num_gaits], np.float32))
+        keys = ("actions_in", "rand", "counter", "obs", "priv", "rew", "reset", "time_out", "commands", "ep_len", "fail_buf",
+                "episode_sums", "act_hist", "sim_dof_pos", "sim_base_pos", "sim_base_lin_vel_w", "dr_pd", "task_state",
+                "last_dof_vel_in", "last_feet_vel_in", "esum_override")
+        out = {k: [] for k in keys}
+        names = env.reward_names
+        for t in range(T):
+            act = torch.from_numpy((rng.normal(size=(N, 12)) * (1.0 if t % 7 else 60.0)).astype(np.float32))
+            out["last_dof_vel_in"].append(sim._dof_vel.numpy().copy())
+            out["last_feet_vel_in"].append(sim._feet_vel.numpy().copy())
+            obs, priv, rew, reset, extras = env.step(act)
+            calls = rec.take()
+            out["actions_in"].append(act.numpy().copy())
+            out["rand"].append(slots_from_calls(calls, slots, N, 12, groups))
+            out["counter"].append(env.common_step_counter); out["esum_override"].append(0.0)
+            out["obs"].append(obs.numpy().copy()); out["priv"].append(priv.numpy().copy()); out["rew"].append(rew.numpy().copy())
+            out["reset"].append(reset.numpy().astype(np.uint8)); out["time_out"].append(env.time_out_buf.numpy().astype(np.uint8))
+            out["commands"].append(env.commands.numpy().copy()); out["ep_len"].append(env.episode_length_buf.numpy().copy())
+            out["fail_buf"].append(env.fail_buf.numpy().copy())
+            out["episode_sums"].append(np.stack([env.episode_sums[n].numpy().copy() for n in names]))
+            out["act_hist"].append(np.stack([env.actions.numpy(), env.last_actions.numpy(), env.llast_actions.numpy()]).copy())
+            out["sim_dof_pos"].append(sim._dof_pos.numpy().copy()); out["sim_base_pos"].append(sim._base_pos.numpy().copy())
+            out["sim_base_lin_vel_w"].append(sim._base_lin_vel_w.numpy().copy())
+            out["dr_pd"].append(np.concatenate([sim._kp_scale.numpy(), sim._kd_scale.numpy()], 1).copy())
+            out["task_state"].append(np.concatenate([env.gait_time.numpy(), env.phi.numpy(), env.gait_period.numpy(),
+                                                     env.base_height_target.numpy(), env.foot_clearance_target.numpy(),
+                                                     env.pitch_target.numpy(), env.theta.numpy(), env.clock_input.numpy(),
+                                                     env.exp_C_frc_fl.numpy(), env.exp_C_frc_fr.numpy(), env.exp_C_frc_rl.numpy(),
+                                                     env.exp_C_frc_rr.numpy()], 1).copy())
+        arrays = {k: np.stack(v) for k, v in out.items()}
+        arrays.update({"script_" + k: v for k, v in sim.script.items()})
+        arrays.update({"init_" + k: v for k, v in init.items()})
+        arrays["reward_names"] = np.array(names)
+        path = os.path.join(HERE, "go2_wtw_mdp.npz")
+        np.savez_compressed(path, **arrays)
+        print("wrote", path, arrays["obs"].shape, arrays["priv"].shape, "resets/step", arrays["reset"].sum(1)[:40])
+    finally:
+        torch.rand_like, torch.randint = orig_rand_like, orig_randint
+
+
 if __name__ == "__main__":
-    gen_go2()
+    which = sys.argv[1:] or ["go2", "wtw"]
+    if "go2" in which:
+        gen_go2()
+    if "wtw" in which:
+        gen_wtw()

@@ -91,6 +91,16 @@ class DrawRecorder:
         self.calls.append(dict(caller="rand_like", parent="", env_ids=None, u=u.clone()))
         return u
 
+    def randint(self, low, high, size, **kw):
+        import torch
+        st = inspect.stack()
+        caller, parent = st[1].function, st[2].function
+        env_ids = st[1].frame.f_locals.get("env_ids")
+        idx = int(self.rng.integers(low, high))
+        self.calls.append(dict(caller="randint:" + caller, parent=parent, env_ids=None if env_ids is None else env_ids.clone(),
+                               u=torch.tensor([(idx + 0.5) / high], dtype=torch.float32)))
+        return torch.full(tuple(size), idx, dtype=torch.long)
+
     def take(self):
         c, self.calls = self.calls, []
         return c

@@ -15,10 +15,13 @@ from oracle.mdp_oracle import MdpOracle
 GOLD = os.path.join(os.path.dirname(__file__), "golden", "go2_mdp.npz")
 
 
-def replay(make_stepper, check):
+GOLD_WTW = os.path.join(os.path.dirname(__file__), "golden", "go2_wtw_mdp.npz")
+
+
+def replay(make_stepper, check, gold=GOLD):
     """Drive an MDP implementation through the fixture; `make_stepper(fx, N)` returns an object
-    with .load_init(fx), .apply_override(t, fx), .step(t, sim_in, actions, R, counter) -> dict."""
-    fx = np.load(GOLD)
+    with .step(t, sim_in, actions, R, counter, override) -> dict of outputs."""
+    fx = np.load(gold)
     T, N = fx["obs"].shape[:2]
     st = make_stepper(fx, N)
     for t in range(T):
@@ -84,3 +87,60 @@ def test_fixture_exercises_the_branches():
 
 def test_mdp_oracle_reproduces_reference_go2():
     replay(OracleStepper, check_against_fixture)
+
+
+# ------------------------------- go2_wtw ------------------------------------------------------
+class WtwOracleStepper:
+    def __init__(self, fx, N):
+        from hcr_genesis_lr_cl_amd.config import GO2WTWCfg
+        model, cfg = load_model("go2"), GO2WTWCfg()
+        task = builders.make_task_cfg(model, cfg)
+        o = self.o = MdpOracle(model, cfg, task, N, fx["init_env_origins"])
+        o.episode_length_buf[:] = fx["init_episode_length_buf"]
+        o.commands[:] = fx["init_commands"]
+        o.theta[:], o.gait_period[:], o.gait_time[:], o.phi[:] = fx["init_theta"], fx["init_gait_period"], fx["init_gait_time"], fx["init_phi"]
+        br = fx["init_behavior_ranges"]
+        o.gait_period_range, o.base_height_target_range = list(br[0:2]), list(br[2:4])
+        o.foot_clearance_target_range, o.pitch_target_range, o.num_gaits = list(br[4:6]), list(br[6:8]), int(br[8])
+        # the fake simulator of the generator starts with friction 0 / added mass 1 (genesis_simulator.py:646-649
+        # before the create-time randomisation, which the fake does not perform)
+        o.friction_values[:] = 0; o.added_base_mass[:] = 1
+        self.names = [str(n) for n in fx["reward_names"]]
+
+    def step(self, t, sim, actions, R, counter, override):
+        o = self.o
+        o.step(sim, actions, R, counter)
+        ts = np.concatenate([o.gait_time, o.phi, o.gait_period, o.base_height_target, o.foot_clearance_target,
+                             o.pitch_target, o.theta, o.clock_input, o.exp_C_frc], 1)
+        return dict(obs=o.obs_buf, priv=o.priv_obs_buf, rew=o.rew_buf, reset=o.reset_buf, time_out=o.time_out_buf,
+                    commands=o.commands, ep_len=o.episode_length_buf, fail_buf=o.fail_buf,
+                    episode_sums=np.stack([o.episode_sums[abi.REWARD_ID[n]] for n in self.names]),
+                    act_hist=np.stack([o.actions, o.last_actions, o.llast_actions]),
+                    sim_dof_pos=sim["dof_pos"], sim_base_pos=sim["base_pos"], sim_base_lin_vel_w=sim["base_lin_vel_w"],
+                    dr_pd=np.concatenate([o.kp_scale, o.kd_scale], 1), task_state=ts)
+
+
+WTW_EXACT = ("reset", "time_out", "ep_len", "fail_buf")
+WTW_FLOAT = ("obs", "priv", "rew", "commands", "episode_sums", "act_hist", "sim_dof_pos", "sim_base_pos",
+             "sim_base_lin_vel_w", "dr_pd", "task_state")
+
+
+def check_wtw(t, fx, out, rtol=2e-6, atol=2e-6):
+    for k in WTW_EXACT:
+        np.testing.assert_array_equal(np.asarray(out[k]).astype(np.int64), fx[k][t].astype(np.int64), err_msg=f"{k} @ step {t}")
+    for k in WTW_FLOAT:
+        ref, got = fx[k][t], np.asarray(out[k])
+        np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol, err_msg=f"{k} @ step {t}")
+
+
+def test_wtw_fixture_exercises_the_branches():
+    fx = np.load(GOLD_WTW)
+    assert fx["reset"].sum() >= 6
+    th = fx["task_state"][:, :, 6:10]
+    assert len({tuple(r) for r in th.reshape(-1, 4)}) >= 4            # several gaits from the table
+    assert (fx["task_state"][1:, :, 0] < fx["task_state"][:-1, :, 0]).any()   # gait clock wrapped
+    assert (fx["counter"] % 750 == 0).any()
+
+
+def test_mdp_oracle_reproduces_reference_go2_wtw():
+    replay(WtwOracleStepper, check_wtw, GOLD_WTW)
