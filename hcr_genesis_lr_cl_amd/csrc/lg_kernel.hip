@@ -652,6 +652,32 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     const float *cr = B.command_ranges;
     float *esum = B.episode_sums;
 
+    // ---- periodic-gait task state (go2_wtw.py:295-346): per-env scalars + this lane's foot entries
+    const bool WTW = T->gait_mode == 1;
+    float *ts = B.task_state ? B.task_state + (size_t)e * T->task_state_width : nullptr;
+    float gait_time = 0.f, phi = 0.f, gait_period = 1.f, bh_tgt = 0.f, fc_tgt = 0.f, pitch_tgt = 0.f, theta = 0.f, expC = 0.f;
+    if (WTW) {
+        gait_time = ts[0]; phi = ts[1]; gait_period = ts[2]; bh_tgt = ts[3]; fc_tgt = ts[4]; pitch_tgt = ts[5];
+        theta = ts[6 + foot_slot]; expC = ts[18 + foot_slot];
+    }
+    auto resample_behavior = [&](int slot) {   // go2_wtw.py:180-218
+        gait_period = (cr[9] - cr[8]) * rs.draw(slot) + cr[8];
+        bh_tgt = (cr[11] - cr[10]) * rs.draw(slot + 1) + cr[10];
+        fc_tgt = (cr[13] - cr[12]) * rs.draw(slot + 2) + cr[12];
+        pitch_tgt = (cr[15] - cr[14]) * rs.draw(slot + 3) + cr[14];
+        // one gait index per call for the whole batch (quirk 6): env-independent Philox counter
+        float ug;
+        if (rs.in) ug = rs.in[slot + 4];
+        else { RandSrc g = rs; g.e_lo = 0xFFFFFFFFu; g.e_hi = 0xFFFFFFFFu; ug = g.draw(slot + 4); }
+        const int ng = (int)cr[16];
+        const int sel = min((int)floorf(ug * (float)ng), ng - 1);
+        theta = T->theta_table[sel][foot_slot];
+        // pronk / bound gaits keep the lowest clearance target (go2_wtw.py:212-218); the lower bound
+        // never moves, so clamping at the env's own resample is equivalent to the reference's all-env pass
+        const float t0 = T->theta_table[sel][0], t1 = T->theta_table[sel][1], t2 = T->theta_table[sel][2], t3 = T->theta_table[sel][3];
+        if (t0 == 0.f && t1 == 0.f && ((t2 == 0.f && t3 == 0.f) || (t2 == 0.5f && t3 == 0.5f))) fc_tgt = cr[12];
+    };
+
     auto resample_commands = [&](int slot) {  // legged_robot.py:317-334
         cmd0 = (cr[1] - cr[0]) * rs.draw(slot) + cr[0];
         cmd1 = (cr[3] - cr[2]) * rs.draw(slot + 1) + cr[2];
@@ -682,6 +708,8 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 B.base_lin_vel_w[3 * e] = vw.x; B.base_lin_vel_w[3 * e + 1] = vw.y;
             }
         }
+        if (WTW && T->behavior_resample_steps > 0 && ep_len % T->behavior_resample_steps == 0)   // go2_wtw.py:258-263
+            resample_behavior(T->slots.task_cb);
         // ---- check_termination (legged_robot.py:78-92) ----
         const int l0 = foot_link - 3;
         int fail = 0;
@@ -814,6 +842,16 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         if (sc[LG_R_KEEP_BALANCE] != 0.f) add(LG_R_KEEP_BALANCE, 1.f);                      // :601-603
         if (sc[LG_R_LIN_VEL_Z] != 0.f) add(LG_R_LIN_VEL_Z, blv.z * blv.z);                  // :458-460
         if (sc[LG_R_ORIENTATION] != 0.f) add(LG_R_ORIENTATION, pg.x * pg.x + pg.y * pg.y);  // :466-468
+        if (sc[LG_R_QUAD_PERIODIC_GAIT] != 0.f) {                       // go2_wtw.py:377-484, "step" indicator
+            const float two_pi = 6.283185307179586f;
+            float ph = phi + theta;
+            ph = (ph - floorf(ph)) * two_pi;                             // (phi + theta) % 1.0, operands >= 0
+            const float b_sw = T->b_swing * two_pi;
+            const float c_frc = (ph >= 0.f && ph < b_sw) ? -1.f : 0.f;
+            const float c_spd = (ph >= b_sw && ph < two_pi) ? -1.f : 0.f;
+            expC = c_frc;
+            add(LG_R_QUAD_PERIODIC_GAIT, expf(quad_sum<LEGS>(c_spd * norm(foot_v) + c_frc * norm(f_link[3]))));
+        }
         if (sc[LG_R_TORQUES] != 0.f) {                                  // :478-480
             float s = 0.f;
 #pragma unroll
@@ -824,12 +862,31 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             const float d = cmd2 - bav.z;
             add(LG_R_TRACKING_ANG_VEL, expf(-(d * d) / T->tracking_sigma));
         }
+        if (sc[LG_R_TRACKING_BASE_HEIGHT] != 0.f) {                     // go2_wtw.py:495-500 (plane: heights are zero)
+            const float d = pos.z - bh_tgt;
+            add(LG_R_TRACKING_BASE_HEIGHT, expf(-(d * d) / T->base_height_sigma));
+        }
+        if (sc[LG_R_TRACKING_FOOT_CLEARANCE] != 0.f) {                  // go2_wtw.py:507-519
+            const float vxy = sqrtf(foot_v.x * foot_v.x + foot_v.y * foot_v.y);
+            const float d = foot_p.z - fc_tgt - T->foot_height_offset;
+            add(LG_R_TRACKING_FOOT_CLEARANCE, expf(-quad_sum<LEGS>(vxy * (d * d)) / T->foot_clearance_sigma));
+        }
         if (sc[LG_R_TRACKING_LIN_VEL] != 0.f) {                         // :533-537
             const float dx = cmd0 - blv.x, dy = cmd1 - blv.y;
             add(LG_R_TRACKING_LIN_VEL, expf(-(dx * dx + dy * dy) / T->tracking_sigma));
         }
+        if (sc[LG_R_TRACKING_ORIENTATION] != 0.f) {                     // go2_wtw.py:502-505
+            const float dp = eul.y - pitch_tgt;
+            add(LG_R_TRACKING_ORIENTATION, expf(-(eul.x * eul.x + dp * dp) / T->euler_sigma));
+        }
         if (T->only_positive_rewards) total = fmaxf(total, 0.f);        // :161-162
         if (sc[LG_R_TERMINATION] != 0.f) add(LG_R_TERMINATION, (reset && !time_out) ? 1.f : 0.f);  // :163-168
+        if (WTW) {   // gait clock (go2_wtw.py:29-36).  The reference additionally restarts env 0's clock whenever
+                     // ANY env wraps (index-flatten bug); that grid-wide coupling is deliberately not reproduced.
+            gait_time += cdt;
+            if (gait_time >= gait_period - cdt / 2.f) gait_time = 0.f;
+            phi = gait_time / gait_period;
+        }
     } else {
         reset = B.reset_buf[e] != 0;
         time_out = B.time_out_buf[e] != 0;
@@ -843,6 +900,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             for (int k = 0; k < LG_R_COUNT + 2; k++) nxt[k] = 0.f;
         }
         if (reset) {
+            if (WTW) { resample_behavior(T->slots.task_reset); gait_time = 0.f; phi = 0.f; }   // go2_wtw.py:124-142
             resample_commands(T->slots.reset_cmd);
             // _reset_dofs (go2.py:17-37): default + U(range) per joint, zero velocity
 #pragma unroll
@@ -958,6 +1016,85 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 put(3, pg.x, ub[0]); put(4, pg.y, ub[1]); put(5, pg.z, ub[2]);
                 put(6, bav.x * T->obs_scale_ang_vel, ub[3]); put(7, bav.y * T->obs_scale_ang_vel, ub[4]); put(8, bav.z * T->obs_scale_ang_vel, ub[5]);
             }
+        }
+    }
+    if (DO_RESET && T->obs_layout == LG_OBS_GO2_WTW) {
+        // ---- go2_wtw.py:53-111: 61-wide actor frame (+noise) and 99-wide critic frame pushed into
+        //      5-frame histories kept oldest -> newest inside obs_buf / priv_obs_buf themselves
+        const int FR = T->obs_frame, PF = T->priv_frame, ST = T->obs_stack, PST = T->priv_stack;
+        float *o = B.obs_buf + (size_t)e * T->num_obs;
+        float *pv = B.priv_obs_buf + (size_t)e * T->num_priv_obs;
+        const float co = T->clip_obs;
+        if (live) {   // shift this lane's columns one frame towards the past (zeros after a reset: go2_wtw.py:174-178)
+            for (int f = 0; f + 1 < ST; f++)
+                for (int i = leg; i < FR; i += LEGS) o[f * FR + i] = reset ? 0.f : o[(f + 1) * FR + i];
+            for (int f = 0; f + 1 < PST; f++)
+                for (int i = leg; i < PF; i += LEGS) pv[f * PF + i] = reset ? 0.f : pv[(f + 1) * PF + i];
+        }
+        float *on = o + (ST - 1) * FR, *pn = pv + (PST - 1) * PF;
+        const bool nz = T->add_noise != 0;
+        const int ns = T->slots.noise;
+        float uq[3] = {0.5f, 0.5f, 0.5f}, uqd[3] = {0.5f, 0.5f, 0.5f}, ub[6] = {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f};
+        if (nz) {
+            if (rs.in) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) { uq[j] = rs.in[ns + 9 + d0 + j]; uqd[j] = rs.in[ns + 9 + A + d0 + j]; }
+                if (lead) {
+#pragma unroll
+                    for (int k = 0; k < 6; k++) ub[k] = rs.in[ns + 3 + k];
+                }
+            } else {
+                rs.block3(2 * leg, uq[0], uq[1], uq[2]);
+                rs.block3(2 * leg + 1, uqd[0], uqd[1], uqd[2]);
+                if (lead) { rs.block3(2 * LEGS, ub[0], ub[1], ub[2]); rs.block3(2 * LEGS + 1, ub[3], ub[4], ub[5]); }
+            }
+        }
+        auto put = [&](int idx, float v, float u) {        // critic copy is noise-free (go2_wtw.py:78-80)
+            pn[idx] = clampf(v, -co, co);
+            if (nz) v += (2.f * u - 1.f) * T->noise_vec[idx];
+            on[idx] = clampf(v, -co, co);
+        };
+        auto putp = [&](int idx, float v) { pn[idx] = clampf(v, -co, co); };
+        // clock inputs (go2_wtw.py:251-256)
+        const float ang = 6.283185307179586f * (phi + theta);
+        if (live) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                put(9 + d0 + j, (q[j] - O->default_dof_pos[d0 + j]) * T->obs_scale_dof_pos, uq[j]);
+                put(9 + A + d0 + j, qd[j] * T->obs_scale_dof_vel, uqd[j]);
+                put(9 + 2 * A + d0 + j, act[j], 0.5f);
+                putp(FR + 10 + d0 + j, B.kp_scale[e * A + d0 + j]);
+                putp(FR + 10 + A + d0 + j, B.kd_scale[e * A + d0 + j]);
+            }
+            const float sn = sinf(ang), cs = cosf(ang);
+            put(45 + foot_slot, sn, 0.5f);
+            put(49 + foot_slot, cs, 0.5f);
+            put(57 + foot_slot, theta, 0.5f);
+            putp(FR + 10 + 2 * A + foot_slot, expC);
+            ts[6 + foot_slot] = theta; ts[10 + foot_slot] = sn; ts[14 + foot_slot] = cs; ts[18 + foot_slot] = expC;
+        }
+        if (lead) {
+            put(0, cmd0 * T->obs_scale_lin_vel, 0.5f); put(1, cmd1 * T->obs_scale_lin_vel, 0.5f); put(2, cmd2 * T->obs_scale_ang_vel, 0.5f);
+            put(3, pg.x, ub[0]); put(4, pg.y, ub[1]); put(5, pg.z, ub[2]);
+            put(6, bav.x * T->obs_scale_ang_vel, ub[3]); put(7, bav.y * T->obs_scale_ang_vel, ub[4]); put(8, bav.z * T->obs_scale_ang_vel, ub[5]);
+            put(53, gait_period, 0.5f); put(54, bh_tgt, 0.5f); put(55, fc_tgt, 0.5f); put(56, pitch_tgt, 0.5f);
+            putp(FR + 0, blv.x * T->obs_scale_lin_vel); putp(FR + 1, blv.y * T->obs_scale_lin_vel); putp(FR + 2, blv.z * T->obs_scale_lin_vel);
+            putp(FR + 3, B.rand_push_vels[3 * e]); putp(FR + 4, B.rand_push_vels[3 * e + 1]);
+            putp(FR + 5, B.added_base_mass[e]); putp(FR + 6, B.friction_values[e]);
+            putp(FR + 7, B.base_com_bias[3 * e]); putp(FR + 8, B.base_com_bias[3 * e + 1]); putp(FR + 9, B.base_com_bias[3 * e + 2]);
+        }
+    }
+    if (WTW && lead) {
+        ts[0] = gait_time; ts[1] = phi; ts[2] = gait_period; ts[3] = bh_tgt; ts[4] = fc_tgt; ts[5] = pitch_tgt;
+    }
+    if (WTW && live && !(DO_RESET && T->obs_layout == LG_OBS_GO2_WTW)) { ts[6 + foot_slot] = theta; ts[18 + foot_slot] = expC; }
+    // second action-history shift of the wtw / tron1_ee tasks (go2_wtw.py:45-46): afterwards
+    // last == llast == a_t, which makes action_smoothness == action_rate
+    if (DO_RESET && T->double_shift && live) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            B.llast_actions[e * A + d0 + j] = reset ? 0.f : last_act[j];
+            B.last_actions[e * A + d0 + j] = act[j];
         }
     }
     // ---- persistent MDP state ----

@@ -1,9 +1,10 @@
 """Task registry mirroring legged_gym/envs/__init__.py:80-91 for the tasks in scope."""
 from .legged_robot import LeggedRobot
 from .go2 import GO2
-from ..config import GO2Cfg
+from .go2_wtw import GO2WTW
+from ..config import GO2Cfg, GO2WTWCfg
 
-TASKS = {"go2": (GO2, GO2Cfg)}
+TASKS = {"go2": (GO2, GO2Cfg), "go2_wtw": (GO2WTW, GO2WTWCfg)}
 
 
 def make_env(name, num_envs=None, device="cuda:0", **kw):

@@ -86,6 +86,7 @@ class LeggedRobot:
         self.num_envs = cfg.env.num_envs
         self.num_obs = cfg.env.num_observations
         self.num_privileged_obs = cfg.env.num_privileged_obs
+        self.num_privileged_obs = cfg.env.num_privileged_obs
         self.num_actions = cfg.env.num_actions
         self.simulator = HipSimulator(cfg, sim_params or cfgmod.class_to_dict(cfg.sim), sim_device, headless,
                                       inject_rand=inject_rand, env_id_offset=env_id_offset,
@@ -116,6 +117,7 @@ class LeggedRobot:
             env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()
             if len(env_ids) > 0:
                 self._update_command_curriculum(env_ids)
+                self._on_curriculum_gate(env_ids)
             self._engine.step(abi.PHASE_RESET, None, c)
         else:
             self._engine.step(abi.PHASE_ALL, actions, c)
@@ -153,9 +155,17 @@ class LeggedRobot:
             r[1] = float(np.clip(r[1] + 0.5, 0., self.cfg.commands.max_curriculum))
             self._upload_command_ranges()
 
+    def _on_curriculum_gate(self, env_ids):
+        """Task hook on command-curriculum gate steps (go2_wtw.py:119-122)."""
+
+    def _extra_ranges(self):
+        return []
+
     def _upload_command_ranges(self):
         cr = self.command_ranges
         vals = list(cr["lin_vel_x"]) + list(cr["lin_vel_y"]) + list(cr["ang_vel_yaw"]) + list(cr["heading"])
+        vals = vals + list(self._extra_ranges())
+        vals = vals + [0.0] * (abi.CMD_RANGE_FLOATS - len(vals))
         self._engine.buf["command_ranges"].copy_(torch.tensor(vals, dtype=torch.float32))
 
     def _parse_cfg(self, cfg):
