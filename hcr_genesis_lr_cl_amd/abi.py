@@ -106,6 +106,7 @@ class LgTaskCfg(C.Structure):
         ("dr_joint_lo", f32 * 3), ("dr_joint_span", f32 * 3),
         ("friction_offset", f32), ("kp_offset", f32), ("kd_offset", f32),
         ("terrain_curriculum", i32), ("max_terrain_level", i32), ("terrain_cols_n", i32),
+        ("num_labels", i32), ("heights_offset", f32), ("heights_clip_scale", i32),
         ("terrain_env_length", f32), ("episode_length_s", f32),
         ("gait_mode", i32), ("double_shift", i32), ("behavior_resample_steps", i32), ("num_gait_max", i32),
         ("b_swing", f32), ("gait_period_fixed", f32), ("theta_table", f32 * 4 * 4), ("task_state_width", i32),

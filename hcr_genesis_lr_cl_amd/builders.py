@@ -108,6 +108,14 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
             for k, lst in enumerate((prf.theta_fl_list, prf.theta_fr_list, prf.theta_rl_list, prf.theta_rr_list)):
                 t.theta_table[g][k] = lst[g]
         t.task_state_width = abi.TASK_STATE_WTW
+    elif layout == "go2_ee":
+        e = cfg.env
+        t.obs_frame, t.obs_stack, t.num_obs = e.num_single_obs, e.frame_stack, e.num_estimator_features
+        t.priv_frame, t.priv_stack, t.num_priv_obs = e.single_critic_obs_len, e.c_frame_stack, e.num_privileged_obs
+        t.num_labels = e.num_estimator_labels
+        abi.fill_array(t.noise_vec, go2_noise_vec(cfg))            # go2_ee.py:100-122
+        t.slots = go2_slots(A, e.num_single_obs)
+        t.heights_offset, t.heights_clip_scale = 0.5, 1             # go2_ee.py:45-46
     else:
         raise NotImplementedError(layout)
     t.control_dt = dt

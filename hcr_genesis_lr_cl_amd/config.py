@@ -249,3 +249,45 @@ class GO2WTWCfg(LeggedRobotCfg):
     # GO2WTW derives from LeggedRobot, not GO2: base-class reset distribution (legged_robot.py:274-298)
     reset = section(dof_ranges={"joint": 0.2}, root_vel_range=0.5, robot="go2", obs_layout="go2_wtw",
                     feet_air_time_threshold=0.3)
+
+
+# common_cfgs.py:74-128 (Go2RoughCommonCfg) + go2/go2_ee/go2_ee_config.py:5-66 (Go2EECfg, experiment "go2_rough")
+class GO2EECfg(LeggedRobotCfg):
+    env = section(LeggedRobotCfg.env, num_envs=4096, num_single_obs=45, frame_stack=20, num_estimator_features=45 * 20,
+                  num_estimator_labels=24, c_frame_stack=5, single_critic_obs_len=45 + 31 + 81 + 17,
+                  num_privileged_obs=5 * (45 + 31 + 81 + 17), num_observations=45 * 20, num_actions=12, env_spacing=2.0)
+    terrain = section(
+        LeggedRobotCfg.terrain, mesh_type="heightfield", border_size=20.0, curriculum=True,
+        obtain_terrain_info_around_feet=True, measure_heights=True,
+        measured_points_x=[-0.4, -0.3, -0.2, -0.1, 0., 0.1, 0.2, 0.3, 0.4],
+        measured_points_y=[-0.4, -0.3, -0.2, -0.1, 0., 0.1, 0.2, 0.3, 0.4],
+        terrain_length=8.0, terrain_width=8.0, platform_size=4.0, num_rows=10, num_cols=10,
+        terrain_proportions=[0.2, 0.1, 0.25, 0.25, 0.2])
+    init_state = section(GO2Cfg.init_state)
+    control = section(GO2Cfg.control)
+    asset = section(GO2Cfg.asset, obtain_link_contact_states=True,
+                    contact_state_link_names=["thigh", "calf", "foot", "base", "hip"],
+                    penalize_contacts_on=["thigh", "calf", "base", "Head", "hip"], terminate_after_contacts_on=[])
+    rewards = section(
+        LeggedRobotCfg.rewards, soft_dof_pos_limit=0.9, foot_clearance_target=0.09, foot_height_offset=0.022,
+        foot_clearance_tracking_sigma=0.01, only_positive_rewards=True,
+        scales=section(
+            LeggedRobotCfg.rewards.scales, dof_pos_limits=-2.0, collision=-1.0, tracking_lin_vel=1.0,
+            tracking_ang_vel=0.5, lin_vel_z=-2.0, ang_vel_xy=-0.05, dof_power=-2.0e-4, dof_acc=-2.0e-7,
+            action_rate=-0.01, action_smoothness=-0.01, feet_air_time=1.0, foot_clearance=0.2, hip_pos=-0.05,
+            feet_contact_stand_still=0.5))
+    commands = section(
+        LeggedRobotCfg.commands, curriculum=True, max_curriculum=1.0, num_commands=4, resampling_time=10.0,
+        heading_command=True,
+        ranges=section(LeggedRobotCfg.commands.ranges, lin_vel_x=[-0.5, 0.5], lin_vel_y=[-1.0, 1.0],
+                       ang_vel_yaw=[-1, 1], heading=[-3.14, 3.14]))
+    domain_rand = section(
+        LeggedRobotCfg.domain_rand, randomize_friction=True, friction_range=[0.2, 1.7], randomize_base_mass=True,
+        added_mass_range=[-1.0, 1.0], push_robots=True, push_interval_s=10, max_push_vel_xy=1.0,
+        randomize_com_displacement=True, com_pos_x_range=[-0.03, 0.03], com_pos_y_range=[-0.03, 0.03],
+        com_pos_z_range=[-0.03, 0.03], randomize_pd_gain=True, kp_range=[0.8, 1.2], kd_range=[0.8, 1.2],
+        randomize_joint_armature=False, randomize_joint_friction=False, randomize_joint_damping=False,
+        joint_armature_range=[0.015, 0.025], joint_friction_range=[0.01, 0.02], joint_damping_range=[0.25, 0.3])
+    # go2_ee.py:77-98 (per-joint reset ranges), legged_robot.py:283-298 (base-class root reset), :124-134 (air time 0.25)
+    reset = section(dof_ranges={"hip": 0.2, "thigh": 0.4, "calf": 0.4}, root_vel_range=0.5, robot="go2",
+                    obs_layout="go2_ee", feet_air_time_threshold=0.25)

@@ -73,6 +73,16 @@ LG_DEV void terrain_at(const LgSimOptions *O, const int16_t *hf, float x, float 
     n = v3(-hx * inv, -hy * inv, inv);
 }
 
+// genesis_simulator.py:565-575: cell index by truncation, clipped, min over three neighbours
+LG_DEV float sample_min3(const LgSimOptions *O, const int16_t *hf, float wx, float wy) {
+    int px = (int)((wx + O->border) / O->hscale), py = (int)((wy + O->border) / O->hscale);
+    px = min(max(px, 0), O->terrain_rows - 2);
+    py = min(max(py, 0), O->terrain_cols - 2);
+    const int C = O->terrain_cols;
+    const int h1 = hf[px * C + py], h2 = hf[(px + 1) * C + py], h3 = hf[px * C + py + 1];
+    return (float)min(min(h1, h2), h3) * O->vscale;
+}
+
 // one joint of the lane's chain, everything pass 3 / the response passes need
 struct Joint {
     V6 S;       // motion subspace [s; P x s] about O, world axes
@@ -215,6 +225,9 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     V3 f_link[4];                    // net contact force on this leg's hip, thigh, calf, foot (world)
     V3 f_base = v3(0, 0, 0);         // net contact force on the base (whole env)
     V3 foot_p, foot_v, last_foot_v = v3(0, 0, 0);
+    float foot_hmean = 0.f;          // mean of the 9 terrain heights around this lane's foot (a8)
+    float mean_height = 0.f;         // mean over the height-sample grid of (base_z - h) is formed from this (a7)
+    const int P = O->n_height_points;
 
     if (DO_SIM) {
         // "last" snapshots (genesis_simulator.py:21-24)
@@ -614,6 +627,58 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 st3(B.link_contact_forces + (e * L) * 3, f_base);
             }
         }
+        // ---- terrain sampling around the base and the feet (genesis_simulator.py:552-610) ----
+        if (P > 0) {
+            // yaw-only quaternion (math_utils.py:43-47) applied to the body-frame sample grid
+            const float yn = rcp(fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f));
+            const float yz = qz * yn, yw = qw * yn;
+            float acc = 0.f;
+            for (int k = leg; k < P; k += LEGS) {
+                const float vx = B.height_points[2 * k], vy = B.height_points[2 * k + 1];
+                // quat_apply with xyz = (0, 0, yz): t = 2 xyz x v; r = v + w t + xyz x t
+                const float tx = -2.f * yz * vy, ty = 2.f * yz * vx;
+                const float rx = vx + yw * tx - yz * ty, ry = vy + yw * ty + yz * tx;
+                const float h = sample_min3(O, p.hf, rx + pos.x, ry + pos.y);
+                acc += pos.z - h;
+                if (live) B.measured_heights[(size_t)e * P + k] = h;
+            }
+            mean_height = quad_sum<LEGS>(acc) / (float)P;
+            if (O->feet_terrain_info) {
+                int px = (int)((foot_p.x + O->border) / O->hscale), py = (int)((foot_p.y + O->border) / O->hscale);
+                px = min(max(px, 0), O->terrain_rows - 2);
+                py = min(max(py, 0), O->terrain_cols - 2);
+                const int C = O->terrain_cols, xm = max(px - 1, 0), ym = max(py - 1, 0);
+                const int16_t *hf = p.hf;
+                // order of genesis_simulator.py:591-599
+                const int hh[9] = {hf[xm * C + py], hf[(px + 1) * C + py], hf[px * C + ym], hf[px * C + py + 1], hf[px * C + py],
+                                   hf[xm * C + ym], hf[(px + 1) * C + py + 1], hf[xm * C + py + 1], hf[(px + 1) * C + ym]};
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; k++) {
+                    const float hv = (float)hh[k] * O->vscale;
+                    sum += hv;
+                    if (live) B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k] = hv;
+                }
+                foot_hmean = sum / 9.f;
+                // normal from RAW int16 differences over 2*hscale -- the reference does not apply the
+                // vertical scale here (genesis_simulator.py:601-606); reproduced
+                const float dx = (float)(hh[1] - hh[0]) / (O->hscale * 2.f), dy = (float)(hh[3] - hh[2]) / (O->hscale * 2.f);
+                const float nn = sqrtf(dx * dx + dy * dy + 1.f);
+                if (live) st3(B.normal_vector_around_feet + ((size_t)e * F + foot_slot) * 3, v3(dx / nn, dy / nn, -1.f / nn));
+            }
+        }
+        if (B.link_contact_states && live) {   // genesis_simulator.py:53-55
+            const int l0 = foot_link - 3;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                const int l = l0 + k;
+                if ((M->state_link_mask >> l) & 1u) {
+                    const int idx = __popc(M->state_link_mask & ((1u << l) - 1u));
+                    B.link_contact_states[(size_t)e * __popc(M->state_link_mask) + idx] = norm(f_link[k]) > 1.f ? 1.f : 0.f;
+                }
+            }
+            if (lead && (M->state_link_mask & 1u)) B.link_contact_states[(size_t)e * __popc(M->state_link_mask)] = norm(f_base) > 1.f ? 1.f : 0.f;
+        }
     } else {
         // SIM not in this launch: pick the read-back up from HBM
         blv = ld3(B.base_lin_vel + 3 * e); bav = ld3(B.base_ang_vel + 3 * e);
@@ -627,6 +692,17 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         last_foot_v = ld3(B.last_feet_vel + (e * F + foot_slot) * 3);
 #pragma unroll
         for (int j = 0; j < 3; j++) { last_qd[j] = B.last_dof_vel[e * A + d0 + j]; torque[j] = B.torques[e * A + d0 + j]; }
+        if (P > 0) {
+            float acc = 0.f;
+            for (int k = leg; k < P; k += LEGS) acc += pos.z - B.measured_heights[(size_t)e * P + k];
+            mean_height = quad_sum<LEGS>(acc) / (float)P;
+            if (O->feet_terrain_info) {
+                float sum = 0.f;
+#pragma unroll
+                for (int k = 0; k < 9; k++) sum += B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k];
+                foot_hmean = sum / 9.f;
+            }
+        }
     }
 
     if (!DO_POST && !DO_RESET) return;
@@ -750,7 +826,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         if (sc[LG_R_ANG_VEL_XY] != 0.f) add(LG_R_ANG_VEL_XY, bav.x * bav.x + bav.y * bav.y);   // :462-464
         if (sc[LG_R_BASE_HEIGHT] != 0.f) {                              // :470-476
             // plane: measured_heights is the all-zero buffer of genesis_simulator.py:494 -> base z
-            const float d = pos.z - T->base_height_target;
+            const float d = (P > 0 ? mean_height : pos.z) - T->base_height_target;
             add(LG_R_BASE_HEIGHT, d * d);
         }
         if (sc[LG_R_COLLISION] != 0.f) {                                // :505-512
@@ -828,7 +904,8 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         }
         if (sc[LG_R_FOOT_CLEARANCE] != 0.f) {                           // :575-588
             const float vxy = sqrtf(foot_v.x * foot_v.x + foot_v.y * foot_v.y);
-            const float d = foot_p.z - T->foot_clearance_target - T->foot_height_offset;
+            // go2_ee.py:136-150 measures the clearance above the mean terrain height around the foot
+            const float d = foot_p.z - (T->obs_layout == LG_OBS_GO2_EE ? foot_hmean : 0.f) - T->foot_clearance_target - T->foot_height_offset;
             const float err = quad_sum<LEGS>(vxy * (d * d));
             add(LG_R_FOOT_CLEARANCE, expf(-err / T->foot_clearance_sigma));
         }
@@ -895,11 +972,28 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
 
     // ---- reset_idx (legged_robot.py:94-148) + simulator.reset_idx (genesis_simulator.py:62-82) ----
     if (DO_RESET) {
+        V3 pos_origin_override = v3(0, 0, 0);
+        bool have_origin = false;
         if (lead && e == 0) {  // clear the per-step reset accumulator the NEXT launch will use
             float *nxt = B.episode_done_sums + ((p.counter + 1) % LG_DONE_RING) * (LG_R_COUNT + 2);
             for (int k = 0; k < LG_R_COUNT + 2; k++) nxt[k] = 0.f;
         }
         if (reset) {
+            if (T->terrain_curriculum && p.counter > 0) {
+                // legged_robot.py:254-272 + genesis_simulator.py:140-148 (skipped on the construction-time reset,
+                // where the reference returns early because init_done is False)
+                const V3 org = ld3(B.env_origins + 3 * e);
+                const float dx = pos.x - org.x, dy = pos.y - org.y;
+                const float dist = sqrtf(dx * dx + dy * dy);
+                const bool up = dist > T->terrain_env_length / 2.f;
+                const bool down = (dist < sqrtf(cmd0 * cmd0 + cmd1 * cmd1) * T->episode_length_s * 0.5f) && !up;
+                int lvl = B.terrain_levels[e] + (up ? 1 : 0) - (down ? 1 : 0);
+                if (lvl >= T->max_terrain_level) lvl = min((int)floorf(rs.draw(T->slots.terrain_level) * (float)T->max_terrain_level), T->max_terrain_level - 1);
+                else lvl = max(lvl, 0);
+                const V3 norg = ld3(B.terrain_origins + ((size_t)lvl * T->terrain_cols_n + B.terrain_types[e]) * 3);
+                if (lead) { B.terrain_levels[e] = lvl; st3(B.env_origins + 3 * e, norg); }
+                pos_origin_override = norg; have_origin = true;
+            }
             if (WTW) { resample_behavior(T->slots.task_reset); gait_time = 0.f; phi = 0.f; }   // go2_wtw.py:124-142
             resample_commands(T->slots.reset_cmd);
             // _reset_dofs (go2.py:17-37): default + U(range) per joint, zero velocity
@@ -911,7 +1005,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 act[j] = last_act[j] = llast_act[j] = 0.f;
             }
             // _reset_root_states (go2.py:119-134)
-            pos = ld3(O->base_init_pos) + ld3(B.env_origins + 3 * e);
+            pos = ld3(O->base_init_pos) + (have_origin ? pos_origin_override : ld3(B.env_origins + 3 * e));
             if (T->custom_origins) {
                 pos.x += T->reset_root_xy_span * rs.draw(T->slots.reset_root_xy) + T->reset_root_xy_lo;
                 pos.y += T->reset_root_xy_span * rs.draw(T->slots.reset_root_xy + 1) + T->reset_root_xy_lo;
@@ -976,64 +1070,27 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 atomicAdd(row + LG_R_COUNT, 1.f);
             }
         }
-        // ---- compute_observations (go2.py:40-64) + clip (legged_robot.py:48-49) ----
-        if (T->obs_layout == LG_OBS_GO2) {
-            float *o = B.obs_buf + (size_t)e * T->num_obs;
-            const float co = T->clip_obs;
-            const bool nz = T->add_noise != 0;
-            const int ns = T->slots.noise;
-            // uniforms for the noisy entries only (commands and actions carry zero noise scale,
-            // go2.py:104-113): q, qd per lane, gravity + ang vel on the lead lane
-            float uq[3] = {0.5f, 0.5f, 0.5f}, uqd[3] = {0.5f, 0.5f, 0.5f}, ub[6] = {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f};
-            if (nz) {
-                if (rs.in) {
-#pragma unroll
-                    for (int j = 0; j < 3; j++) { uq[j] = rs.in[ns + 9 + d0 + j]; uqd[j] = rs.in[ns + 9 + A + d0 + j]; }
-                    if (lead) {
-#pragma unroll
-                        for (int k = 0; k < 6; k++) ub[k] = rs.in[ns + 3 + k];
-                    }
-                } else {
-                    rs.block3(2 * leg, uq[0], uq[1], uq[2]);
-                    rs.block3(2 * leg + 1, uqd[0], uqd[1], uqd[2]);
-                    if (lead) { rs.block3(2 * LEGS, ub[0], ub[1], ub[2]); rs.block3(2 * LEGS + 1, ub[3], ub[4], ub[5]); }
-                }
-            }
-            auto put = [&](int idx, float v, float u) {
-                if (nz) v += (2.f * u - 1.f) * T->noise_vec[idx];
-                o[idx] = clampf(v, -co, co);
-            };
-            if (live) {
-#pragma unroll
-                for (int j = 0; j < 3; j++) {
-                    put(9 + d0 + j, (q[j] - O->default_dof_pos[d0 + j]) * T->obs_scale_dof_pos, uq[j]);
-                    put(9 + A + d0 + j, qd[j] * T->obs_scale_dof_vel, uqd[j]);
-                    put(9 + 2 * A + d0 + j, act[j], 0.5f);
-                }
-            }
-            if (lead) {
-                put(0, cmd0 * T->obs_scale_lin_vel, 0.5f); put(1, cmd1 * T->obs_scale_lin_vel, 0.5f); put(2, cmd2 * T->obs_scale_ang_vel, 0.5f);
-                put(3, pg.x, ub[0]); put(4, pg.y, ub[1]); put(5, pg.z, ub[2]);
-                put(6, bav.x * T->obs_scale_ang_vel, ub[3]); put(7, bav.y * T->obs_scale_ang_vel, ub[4]); put(8, bav.z * T->obs_scale_ang_vel, ub[5]);
-            }
-        }
     }
-    if (DO_RESET && T->obs_layout == LG_OBS_GO2_WTW) {
-        // ---- go2_wtw.py:53-111: 61-wide actor frame (+noise) and 99-wide critic frame pushed into
-        //      5-frame histories kept oldest -> newest inside obs_buf / priv_obs_buf themselves
+    if (DO_RESET) {
+        // ---- compute_observations + clip (legged_robot.py:48-49).  Layouts: go2.py:40-64 (45),
+        //      go2_wtw.py:53-111 (61x5 | 99x5), go2_ee.py:10-75 (45x20 | 174x5 | 24 labels).  Histories are
+        //      kept oldest -> newest inside obs_buf / priv_obs_buf themselves and shifted in place.
         const int FR = T->obs_frame, PF = T->priv_frame, ST = T->obs_stack, PST = T->priv_stack;
         float *o = B.obs_buf + (size_t)e * T->num_obs;
-        float *pv = B.priv_obs_buf + (size_t)e * T->num_priv_obs;
+        float *pv = T->num_priv_obs > 0 ? B.priv_obs_buf + (size_t)e * T->num_priv_obs : nullptr;
         const float co = T->clip_obs;
-        if (live) {   // shift this lane's columns one frame towards the past (zeros after a reset: go2_wtw.py:174-178)
+        if (live) {   // this lane's columns move one frame towards the past (zeros after a reset: go2_wtw.py:174-178)
             for (int f = 0; f + 1 < ST; f++)
                 for (int i = leg; i < FR; i += LEGS) o[f * FR + i] = reset ? 0.f : o[(f + 1) * FR + i];
-            for (int f = 0; f + 1 < PST; f++)
-                for (int i = leg; i < PF; i += LEGS) pv[f * PF + i] = reset ? 0.f : pv[(f + 1) * PF + i];
+            if (pv)
+                for (int f = 0; f + 1 < PST; f++)
+                    for (int i = leg; i < PF; i += LEGS) pv[f * PF + i] = reset ? 0.f : pv[(f + 1) * PF + i];
         }
-        float *on = o + (ST - 1) * FR, *pn = pv + (PST - 1) * PF;
+        float *on = o + (ST - 1) * FR, *pn = pv ? pv + (PST - 1) * PF : nullptr;
         const bool nz = T->add_noise != 0;
         const int ns = T->slots.noise;
+        // uniforms for the noisy entries only (commands and actions carry zero noise scale): q, qd per lane,
+        // gravity + ang vel on the lead lane
         float uq[3] = {0.5f, 0.5f, 0.5f}, uqd[3] = {0.5f, 0.5f, 0.5f}, ub[6] = {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f};
         if (nz) {
             if (rs.in) {
@@ -1049,39 +1106,84 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 if (lead) { rs.block3(2 * LEGS, ub[0], ub[1], ub[2]); rs.block3(2 * LEGS + 1, ub[3], ub[4], ub[5]); }
             }
         }
-        auto put = [&](int idx, float v, float u) {        // critic copy is noise-free (go2_wtw.py:78-80)
-            pn[idx] = clampf(v, -co, co);
+        auto put = [&](int idx, float v, float u) {        // critic copy of the frame is noise-free
+            if (pn) pn[idx] = clampf(v, -co, co);
             if (nz) v += (2.f * u - 1.f) * T->noise_vec[idx];
             on[idx] = clampf(v, -co, co);
         };
         auto putp = [&](int idx, float v) { pn[idx] = clampf(v, -co, co); };
-        // clock inputs (go2_wtw.py:251-256)
-        const float ang = 6.283185307179586f * (phi + theta);
         if (live) {
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 put(9 + d0 + j, (q[j] - O->default_dof_pos[d0 + j]) * T->obs_scale_dof_pos, uq[j]);
                 put(9 + A + d0 + j, qd[j] * T->obs_scale_dof_vel, uqd[j]);
                 put(9 + 2 * A + d0 + j, act[j], 0.5f);
-                putp(FR + 10 + d0 + j, B.kp_scale[e * A + d0 + j]);
-                putp(FR + 10 + A + d0 + j, B.kd_scale[e * A + d0 + j]);
             }
-            const float sn = sinf(ang), cs = cosf(ang);
-            put(45 + foot_slot, sn, 0.5f);
-            put(49 + foot_slot, cs, 0.5f);
-            put(57 + foot_slot, theta, 0.5f);
-            putp(FR + 10 + 2 * A + foot_slot, expC);
-            ts[6 + foot_slot] = theta; ts[10 + foot_slot] = sn; ts[14 + foot_slot] = cs; ts[18 + foot_slot] = expC;
         }
         if (lead) {
             put(0, cmd0 * T->obs_scale_lin_vel, 0.5f); put(1, cmd1 * T->obs_scale_lin_vel, 0.5f); put(2, cmd2 * T->obs_scale_ang_vel, 0.5f);
             put(3, pg.x, ub[0]); put(4, pg.y, ub[1]); put(5, pg.z, ub[2]);
             put(6, bav.x * T->obs_scale_ang_vel, ub[3]); put(7, bav.y * T->obs_scale_ang_vel, ub[4]); put(8, bav.z * T->obs_scale_ang_vel, ub[5]);
-            put(53, gait_period, 0.5f); put(54, bh_tgt, 0.5f); put(55, fc_tgt, 0.5f); put(56, pitch_tgt, 0.5f);
-            putp(FR + 0, blv.x * T->obs_scale_lin_vel); putp(FR + 1, blv.y * T->obs_scale_lin_vel); putp(FR + 2, blv.z * T->obs_scale_lin_vel);
-            putp(FR + 3, B.rand_push_vels[3 * e]); putp(FR + 4, B.rand_push_vels[3 * e + 1]);
-            putp(FR + 5, B.added_base_mass[e]); putp(FR + 6, B.friction_values[e]);
-            putp(FR + 7, B.base_com_bias[3 * e]); putp(FR + 8, B.base_com_bias[3 * e + 1]); putp(FR + 9, B.base_com_bias[3 * e + 2]);
+        }
+        if (T->obs_layout == LG_OBS_GO2_WTW) {
+            const float ang = 6.283185307179586f * (phi + theta);      // clock inputs (go2_wtw.py:251-256)
+            if (live) {
+                const float sn = sinf(ang), cs = cosf(ang);
+                put(45 + foot_slot, sn, 0.5f);
+                put(49 + foot_slot, cs, 0.5f);
+                put(57 + foot_slot, theta, 0.5f);
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    putp(FR + 10 + d0 + j, B.kp_scale[e * A + d0 + j]);
+                    putp(FR + 10 + A + d0 + j, B.kd_scale[e * A + d0 + j]);
+                }
+                putp(FR + 10 + 2 * A + foot_slot, expC);
+                ts[6 + foot_slot] = theta; ts[10 + foot_slot] = sn; ts[14 + foot_slot] = cs; ts[18 + foot_slot] = expC;
+            }
+            if (lead) {
+                put(53, gait_period, 0.5f); put(54, bh_tgt, 0.5f); put(55, fc_tgt, 0.5f); put(56, pitch_tgt, 0.5f);
+                putp(FR + 0, blv.x * T->obs_scale_lin_vel); putp(FR + 1, blv.y * T->obs_scale_lin_vel); putp(FR + 2, blv.z * T->obs_scale_lin_vel);
+                putp(FR + 3, B.rand_push_vels[3 * e]); putp(FR + 4, B.rand_push_vels[3 * e + 1]);
+                putp(FR + 5, B.added_base_mass[e]); putp(FR + 6, B.friction_values[e]);
+                putp(FR + 7, B.base_com_bias[3 * e]); putp(FR + 8, B.base_com_bias[3 * e + 1]); putp(FR + 9, B.base_com_bias[3 * e + 2]);
+            }
+        } else if (T->obs_layout == LG_OBS_GO2_EE) {
+            // critic frame (go2_ee.py:21-48): obs 45 | DR 31 | contact states K | heights P
+            const int K = __popc(M->state_link_mask);
+            const int l0 = foot_link - 3;
+            float *lab = B.labels_buf + (size_t)e * T->num_labels;
+            if (live) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    putp(FR + 7 + d0 + j, B.kp_scale[e * A + d0 + j] - T->kp_offset);
+                    putp(FR + 7 + A + d0 + j, B.kd_scale[e * A + d0 + j] - T->kd_offset);
+                }
+                // contact states are those of the physics read-back (stale for a just-reset env, as in the reference)
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int l = l0 + k;
+                    if ((M->state_link_mask >> l) & 1u) {
+                        const int idx = __popc(M->state_link_mask & ((1u << l) - 1u));
+                        const float cs = norm(f_link[k]) > 1.f ? 1.f : 0.f;
+                        putp(FR + 7 + 2 * A + idx, cs);
+                        lab[3 + idx] = cs;
+                    }
+                }
+                for (int k = leg; k < P; k += LEGS) {
+                    float hv = pos.z - T->heights_offset - B.measured_heights[(size_t)e * P + k];
+                    if (T->heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * T->obs_scale_height;
+                    putp(FR + 7 + 2 * A + K + k, hv);
+                }
+                // labels (go2_ee.py:69-75): v_b 3 | contact states K | foot height above the local terrain mean F
+                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmean - T->foot_height_offset, -1.f, 1.f);
+            }
+            if (lead) {
+                putp(FR + 0, B.friction_values[e] - T->friction_offset); putp(FR + 1, B.added_base_mass[e]);
+                putp(FR + 2, B.base_com_bias[3 * e]); putp(FR + 3, B.base_com_bias[3 * e + 1]); putp(FR + 4, B.base_com_bias[3 * e + 2]);
+                putp(FR + 5, B.rand_push_vels[3 * e]); putp(FR + 6, B.rand_push_vels[3 * e + 1]);
+                if (M->state_link_mask & 1u) { const float cs = norm(f_base) > 1.f ? 1.f : 0.f; putp(FR + 7 + 2 * A, cs); lab[3] = cs; }
+                lab[0] = blv.x * T->obs_scale_lin_vel; lab[1] = blv.y * T->obs_scale_lin_vel; lab[2] = blv.z * T->obs_scale_lin_vel;
+            }
         }
     }
     if (WTW && lead) {

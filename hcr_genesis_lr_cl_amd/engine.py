@@ -55,7 +55,7 @@ def buffer_specs(A, L, F, K, P, num_obs, num_priv, num_labels, n_slots, hist, pr
 
 
 class Engine:
-    def __init__(self, model, desc, opts, task, n_envs, device="cuda:0", num_labels=0, inject_rand=False):
+    def __init__(self, model, desc, opts, task, n_envs, device="cuda:0", inject_rand=False):
         if not torch.cuda.is_available():
             raise RuntimeError("hcr_genesis_lr_cl_amd needs a HIP device (no CPU fallback)")
         self.lib = abi.load_lib()
@@ -68,8 +68,8 @@ class Engine:
         P = int(opts.n_height_points)
         hist = (task.obs_stack, task.obs_frame) if task.obs_stack > 1 else None
         phist = (task.priv_stack, task.priv_frame) if task.priv_stack > 1 else None
-        specs = buffer_specs(A, L, F, K, P, task.num_obs, task.num_priv_obs, num_labels, task.slots.n_slots,
-                             hist, phist, int(task.task_state_width))
+        specs = buffer_specs(A, L, F, K, P, task.num_obs, task.num_priv_obs, int(task.num_labels), task.slots.n_slots,
+                             None, None, int(task.task_state_width))
         self.buf = {k: torch.zeros((self.n,) + tuple(shape), dtype=dt, device=self.device)
                     for k, (shape, dt) in specs.items()}
         self.buf["episode_sums"] = torch.zeros((abi.R_COUNT, self.n), device=self.device)
@@ -102,10 +102,16 @@ class Engine:
         self.task = task
         abi.check(self.lib.lg_set_task(self.handle, C.byref(task)), self.lib)
 
-    def set_terrain(self, height_samples: torch.Tensor):
-        hs = height_samples.to(self.device, torch.int16).contiguous()
-        self.buf["_height_samples"] = hs
+    def set_terrain(self, height_samples, terrain_origins=None, height_points=None):
+        """Upload the int16 heightfield (+ per-tile origins, + body-frame height sample offsets)."""
+        hs = torch.as_tensor(height_samples).to(self.device, torch.int16).contiguous()
+        self.height_samples = hs
         abi.check(self.lib.lg_set_terrain(self.handle, hs.data_ptr(), hs.shape[0], hs.shape[1]), self.lib)
+        if terrain_origins is not None:
+            self.buf["terrain_origins"] = torch.as_tensor(terrain_origins).to(self.device, torch.float32).contiguous()
+        if height_points is not None:
+            self.buf["height_points"] = torch.as_tensor(height_points).to(self.device, torch.float32).contiguous()
+        self.bind()
 
     def step(self, phases, actions, counter):
         a = 0

@@ -2,9 +2,11 @@
 from .legged_robot import LeggedRobot
 from .go2 import GO2
 from .go2_wtw import GO2WTW
-from ..config import GO2Cfg, GO2WTWCfg
+from .go2_ee import Go2EE
+from ..config import GO2Cfg, GO2WTWCfg, GO2EECfg
 
-TASKS = {"go2": (GO2, GO2Cfg), "go2_wtw": (GO2WTW, GO2WTWCfg)}
+# registry names of the reference (legged_gym/envs/__init__.py:80-91); go2_ee is the "go2_rough" experiment
+TASKS = {"go2": (GO2, GO2Cfg), "go2_wtw": (GO2WTW, GO2WTWCfg), "go2_ee": (Go2EE, GO2EECfg)}
 
 
 def make_env(name, num_envs=None, device="cuda:0", **kw):

@@ -179,6 +179,13 @@ class HipSimulator:
         self._task = builders.make_task_cfg(m, cfg, env_id_offset=self._env_id_offset)
         self._engine = Engine(m, self._desc, self._opts, self._task, self._num_envs, self._device,
                               inject_rand=self._inject_rand)
+        if self._terrain is not None:          # genesis_simulator.py:765-778 + height sample grid :496-507
+            self._height_samples = torch.tensor(self._terrain.heightsamples).view(self._terrain.tot_rows, self._terrain.tot_cols).to(self._device)
+            hx = torch.tensor(cfg.terrain.measured_points_x)
+            hy = torch.tensor(cfg.terrain.measured_points_y)
+            gx, gy = torch.meshgrid(hx, hy, indexing="ij")
+            hp = torch.stack([gx.flatten(), gy.flatten()], 1) if cfg.terrain.measure_heights else None
+            self._engine.set_terrain(self._height_samples, self._terrain.env_origins, hp)
         b = self._engine.buf
         dev = self._device
         self._dof_pos_limits = torch.tensor(cfgmod.soft_dof_limits(m, cfg), device=dev)

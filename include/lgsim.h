@@ -187,6 +187,9 @@ typedef struct LgTaskCfg {
     float friction_offset, kp_offset, kd_offset; /* privileged-obs centring (legged_robot.py:448-453) */
     /* terrain curriculum (legged_robot.py:254-272, genesis_simulator.py:140-148) */
     int32_t terrain_curriculum, max_terrain_level, terrain_cols_n;
+    int32_t num_labels;              /* estimator labels width (legged_robot_ee.py:20-27); 0 = none */
+    float heights_offset;            /* base_z - offset - h in the critic heights (0.5 go2_ee.py:45-46, 0.6 tron1) */
+    int32_t heights_clip_scale;      /* 1: clip to +-1 and scale by obs_scales.height_measurements */
     float terrain_env_length, episode_length_s;
     /* periodic-gait tasks (go2_wtw.py:29-36, 377-484; tron1_pf_ee.py:28-35, 347-433) */
     int32_t gait_mode;               /* 0 none, 1 quadruped wtw, 2 biped */

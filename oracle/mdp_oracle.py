@@ -52,6 +52,48 @@ def get_euler_xyz(q):
     return np.stack([roll, pitch, yaw], 1).astype(f32)
 
 
+def quat_apply_yaw(q, v):
+    """math_utils.py:43-47: zero x,y of the quaternion, renormalise, rotate."""
+    qy = q.copy().astype(f32)
+    qy[:, :2] = 0
+    n = np.clip(np.linalg.norm(qy, axis=1, keepdims=True), 1e-9, None)
+    qy = (qy / n).astype(f32)
+    P = v.shape[1]
+    qq = np.repeat(qy, P, axis=0)
+    return quat_apply(qq, v.reshape(-1, 3)).reshape(v.shape)
+
+
+def sample_heights(base_pos, base_quat, height_points, hf, border, hscale, vscale):
+    """genesis_simulator.py:552-577: grid around the base, truncation to cells, min of 3 neighbours."""
+    N, P = base_pos.shape[0], height_points.shape[0]
+    hp = np.zeros((N, P, 3), f32)
+    hp[:, :, :2] = height_points
+    pts = quat_apply_yaw(base_quat, hp) + base_pos[:, None, :]
+    pts = pts + f32(border)
+    idx = (pts / f32(hscale)).astype(np.int64)        # .long(): truncation towards zero
+    px = np.clip(idx[:, :, 0].reshape(-1), 0, hf.shape[0] - 2)
+    py = np.clip(idx[:, :, 1].reshape(-1), 0, hf.shape[1] - 2)
+    h = np.minimum(np.minimum(hf[px, py], hf[px + 1, py]), hf[px, py + 1])
+    return (h.reshape(N, P) * f32(vscale)).astype(f32)
+
+
+def feet_terrain_info(feet_pos, hf, border, hscale, vscale):
+    """genesis_simulator.py:579-610: 9 heights per foot; normal from RAW int16 differences."""
+    N, F = feet_pos.shape[:2]
+    idx = ((feet_pos + f32(border)) / f32(hscale)).astype(np.int64)
+    px = np.clip(idx[:, :, 0].reshape(-1), 0, hf.shape[0] - 2)
+    py = np.clip(idx[:, :, 1].reshape(-1), 0, hf.shape[1] - 2)
+    xm, ym = np.maximum(px - 1, 0), np.maximum(py - 1, 0)
+    hs = [hf[xm, py], hf[px + 1, py], hf[px, ym], hf[px, py + 1], hf[px, py], hf[xm, ym], hf[px + 1, py + 1],
+          hf[xm, py + 1], hf[px + 1, ym]]
+    dx = ((hs[1].astype(np.int16) - hs[0].astype(np.int16)) / (hscale * 2)).reshape(N, F).astype(f32)
+    dy = ((hs[3].astype(np.int16) - hs[2].astype(np.int16)) / (hscale * 2)).reshape(N, F).astype(f32)
+    nrm = np.stack([dx, dy, -np.ones_like(dx)], -1)
+    nrm = (nrm / np.linalg.norm(nrm, axis=-1, keepdims=True)).astype(f32)
+    har = np.stack([h.reshape(N, F) * f32(vscale) for h in hs], -1).astype(f32)
+    return har, nrm.reshape(N, F * 3)
+
+
 class MdpOracle:
     def __init__(self, model, cfg, task, n_envs, env_origins=None):
         self.model, self.cfg, self.task, self.N = model, cfg, task, n_envs
@@ -85,6 +127,14 @@ class MdpOracle:
         self.base_com_bias, self.rand_push_vels = z(N, 3), z(N, 3)
         self.kp_scale, self.kd_scale = np.ones((N, A), f32), np.ones((N, A), f32)
         self.priv_obs_buf = z(N, max(task.num_priv_obs, 1))
+        self.labels_buf = z(N, max(task.num_labels, 1))
+        self.state_links = model.find_link_indices(cfg.asset.contact_state_link_names) if cfg.asset.obtain_link_contact_states else []
+        self.terrain_levels = np.zeros(N, np.int64)
+        self.terrain_types = np.zeros(N, np.int64)
+        self.terrain_origins = None
+        if task.obs_layout == abi.OBS_GO2_EE:
+            self.obs_hist = z(N, task.obs_stack, task.obs_frame)
+            self.priv_hist = z(N, task.priv_stack, task.priv_frame)
         if task.gait_mode == 1:
             self._init_wtw()
 
@@ -247,7 +297,10 @@ class MdpOracle:
             add("foot_acc", np.sum(acc ** 2, axis=(1, 2)))
         if on("foot_clearance"):                                           # :575-588
             vxy = np.linalg.norm(feet_vel[:, :, :2], axis=-1)
-            err = np.sum(vxy * (feet_pos[:, :, 2] - f32(T.foot_clearance_target) - f32(T.foot_height_offset)) ** 2, axis=-1)
+            zf = feet_pos[:, :, 2]
+            if T.obs_layout == abi.OBS_GO2_EE:                                # go2_ee.py:136-150
+                zf = zf - np.mean(sim["height_around_feet"].reshape(N, F, 9), axis=-1)
+            err = np.sum(vxy * (zf - f32(T.foot_clearance_target) - f32(T.foot_height_offset)) ** 2, axis=-1)
             add("foot_clearance", np.exp(-err / f32(T.foot_clearance_sigma)))
         if on("foot_landing_vel"):
             zv = feet_vel[:, :, 2]
@@ -319,6 +372,15 @@ class MdpOracle:
         if len(ids):
             if self.cfg.commands.curriculum and counter % int(T.max_episode_length) == 0:   # :110-111
                 self.update_command_curriculum(ids)
+            if T.terrain_curriculum and counter > 0:                          # legged_robot.py:254-272, genesis_simulator.py:140-148
+                dist = np.linalg.norm(sim["base_pos"][ids, :2] - self.env_origins[ids, :2], axis=1)
+                up = dist > T.terrain_env_length / 2
+                down = (dist < np.linalg.norm(self.commands[ids, :2], axis=1) * f32(T.episode_length_s) * f32(0.5)) & ~up
+                lv = self.terrain_levels[ids] + up.astype(np.int64) - down.astype(np.int64)
+                rnd = np.minimum(np.floor(R[ids, S.terrain_level] * T.max_terrain_level).astype(np.int64), T.max_terrain_level - 1)
+                lv = np.where(lv >= T.max_terrain_level, rnd, np.clip(lv, 0, None))
+                self.terrain_levels[ids] = lv
+                self.env_origins[ids] = self.terrain_origins[lv, self.terrain_types[ids]]
             if T.gait_mode == 1:
                 self._resample_behavior(ids, R, S.task_reset)
             self._resample(ids, R, S.reset_cmd)
@@ -354,6 +416,7 @@ class MdpOracle:
             self.fail_buf[ids] = 0
             if T.gait_mode == 1:                                           # go2_wtw.py:139-142, 174-178
                 self.gait_time[ids] = 0; self.phi[ids] = 0; self.clock_input[ids] = 0
+            if T.obs_stack > 1:                                            # go2_wtw.py:174-178, legged_robot_ee.py:115-121
                 self.obs_hist[ids] = 0; self.priv_hist[ids] = 0
             self.done_sums = (self.episode_sums[:, ids].sum(1), len(ids))
             self.episode_sums[:, ids] = np.where((sc[:abi.R_COUNT] != 0)[:, None], 0, self.episode_sums[:, ids])
@@ -388,6 +451,27 @@ class MdpOracle:
             co = f32(T.clip_obs)
             self.obs_buf = np.clip(self.obs_hist.reshape(N, -1), -co, co).astype(f32)
             self.priv_obs_buf = np.clip(self.priv_hist.reshape(N, -1), -co, co).astype(f32)
+        elif T.obs_layout == abi.OBS_GO2_EE:                                 # go2_ee.py:10-75
+            cs = np.array([T.obs_scale_lin_vel, T.obs_scale_lin_vel, T.obs_scale_ang_vel], f32)
+            frame = np.concatenate([self.commands[:, :3] * cs, pg, bav * f32(T.obs_scale_ang_vel),
+                                    (sim["dof_pos"] - self.q0) * f32(T.obs_scale_dof_pos),
+                                    sim["dof_vel"] * f32(T.obs_scale_dof_vel), self.actions], axis=1).astype(f32)
+            states = (1.0 * (np.linalg.norm(F_l[:, self.state_links], axis=-1) > 1.0)).astype(f32)
+            dr = np.concatenate([self.friction_values - f32(T.friction_offset), self.added_base_mass, self.base_com_bias,
+                                 self.rand_push_vels[:, :2], self.kp_scale - f32(T.kp_offset), self.kd_scale - f32(T.kd_offset)], axis=1)
+            heights = np.clip(sim["base_pos"][:, 2:3] - f32(T.heights_offset) - sim["measured_heights"], -1, 1) * f32(T.obs_scale_height)
+            crit = np.concatenate([frame, dr, states, heights], axis=1).astype(f32)
+            now = frame
+            if T.add_noise:
+                now = frame + (f32(2) * R[:, S.noise:S.noise + frame.shape[1]] - f32(1)) * self.noise_vec
+            self.obs_hist = np.concatenate([self.obs_hist[:, 1:], now[:, None]], axis=1)
+            self.priv_hist = np.concatenate([self.priv_hist[:, 1:], crit[:, None]], axis=1)
+            co = f32(T.clip_obs)
+            self.obs_buf = np.clip(self.obs_hist.reshape(N, -1), -co, co).astype(f32)
+            self.priv_obs_buf = np.clip(self.priv_hist.reshape(N, -1), -co, co).astype(f32)
+            fh = np.clip(sim["feet_pos"].reshape(N, F, 3)[:, :, 2] - np.mean(sim["height_around_feet"].reshape(N, F, 9), axis=-1)
+                         - f32(T.foot_height_offset), -1, 1)
+            self.labels_buf = np.concatenate([blv * f32(T.obs_scale_lin_vel), states, fh], axis=1).astype(f32)
         else:
             raise NotImplementedError
         if T.double_shift:                                                   # go2_wtw.py:45-46

@@ -164,6 +164,56 @@ FakeSimulator.dr_base_com_bias = property(lambda s: s._base_com_bias)
 FakeSimulator.dr_rand_push_vels = property(lambda s: s._rand_push_vels)
 
 
+class RoughFakeSimulator(FakeSimulator):
+    """Adds the heightfield side: the terrain comes from the reference's own Terrain class, and the
+    height sampling / feet terrain info / contact states / terrain curriculum are the reference's own
+    GenesisSimulator methods executed on this object (genesis_simulator.py:53-60, 140-148, 496-610)."""
+    TERRAIN_SEED = 3
+
+    def __init__(self, cfg, sim_params, device, headless):
+        super().__init__(cfg, sim_params, device, headless)
+        from legged_gym.simulator.genesis_simulator import GenesisSimulator as GS
+        from legged_gym.utils.terrain import Terrain
+        self.GS = GS
+        np.random.seed(self.TERRAIN_SEED)
+        self._terrain = Terrain(cfg.terrain)
+        self._height_samples = torch.tensor(self._terrain.heightsamples).view(self._terrain.tot_rows, self._terrain.tot_cols)
+        N = self._num_envs
+        self._custom_origins = True
+        self._max_terrain_level = cfg.terrain.num_rows
+        rng = np.random.default_rng(17)
+        self._terrain_levels = torch.from_numpy(rng.integers(0, cfg.terrain.num_rows, N))
+        self._terrain_types = torch.div(torch.arange(N), (N / cfg.terrain.num_cols), rounding_mode='floor').to(torch.long)
+        self._terrain_origins = torch.from_numpy(self._terrain.env_origins).to(torch.float)
+        self._env_origins = self._terrain_origins[self._terrain_levels, self._terrain_types].clone()
+        GS._init_height_points(self)
+        self._measured_heights = torch.zeros(N, self._num_height_points)
+        F = self.model.n_legs
+        self._normal_vector_around_feet = torch.zeros(N, F * 3)
+        self._height_around_feet = torch.zeros(N, F, 9)
+        self._contact_state_link_indices = self.model.find_link_indices(cfg.asset.contact_state_link_names)
+        self._link_contact_states = torch.zeros(N, len(self._contact_state_link_indices))
+
+    def post_physics_step(self):
+        super().post_physics_step()
+        self._link_contact_states = 1. * (torch.norm(self._link_contact_forces[:, self._contact_state_link_indices, :], dim=-1) > 1.)
+        self.GS._update_surrounding_heights(self)
+        self.GS._calc_terrain_info_around_feet(self)
+
+    def update_terrain_curriculum(self, env_ids, move_up, move_down):
+        # the randint of genesis_simulator.py:144-145 goes through the recorder
+        orig = torch.randint_like
+        torch.randint_like = lambda t, high: self.rec.randint_like(t, high, env_ids)
+        try:
+            self.GS.update_terrain_curriculum(self, env_ids, move_up, move_down)
+        finally:
+            torch.randint_like = orig
+
+
+for _p in ("terrain_levels", "terrain_types", "link_contact_states", "normal_vector_around_feet", "height_around_feet"):
+    setattr(RoughFakeSimulator, _p, property(lambda s, _n="_" + _p: getattr(s, _n)))
+
+
 def make_script(rng, model, cfg, N, T):
     """Scripted read-backs: independent plausible states per step, biased to exercise branches."""
     A, L, F = model.n_dof, model.n_links, model.n_legs
@@ -217,7 +267,12 @@ def slots_from_calls(calls, slots, N, A, policy_dof_groups):
             for j, col in enumerate(cols):
                 R[ids, slots.reset_dof + col] = u[:, j]
         elif c["caller"] == "_reset_root_states":
-            base = [slots.reset_lin_vel, slots.reset_ang_vel][k] if u.shape[1] == 3 else slots.reset_root_xy
+            if u.shape[1] == 2:
+                base = slots.reset_root_xy
+            else:
+                k3 = seen.get("root3", 0)
+                seen["root3"] = k3 + 1
+                base = [slots.reset_lin_vel, slots.reset_ang_vel][k3]
             R[ids, base:base + u.shape[1]] = u
         elif c["caller"] == "reset_idx":     # FakeSimulator.reset_idx: friction, mass, com x/y/z, kp, kd
             order = [(slots.dr_friction, 1), (slots.dr_mass, 1), (slots.dr_com, 1), (slots.dr_com + 1, 1),
@@ -230,6 +285,8 @@ def slots_from_calls(calls, slots, N, A, policy_dof_groups):
         elif c["caller"] == "randint:_resample_behavior_params":
             base = slots.task_cb if c["parent"] == "_post_physics_step_callback" else slots.task_reset
             R[ids, base + 4] = float(u[0])
+        elif c["caller"] == "randint_like":
+            R[ids, slots.terrain_level] = u
         elif c["caller"] == "rand_like":
             R[:, slots.noise:slots.noise + u.shape[1]] = u
         else:
@@ -414,8 +471,93 @@ def gen_wtw(N=24, T=64, seed=11):
         torch.rand_like, torch.randint = orig_rand_like, orig_randint
 
 
+def gen_ee(N=24, T=48, seed=21):
+    """Go2EE (go2_ee.py, legged_robot_ee.py): heightfield terrain, terrain curriculum, estimator features /
+    labels / critic stacks.  Only the newest frame of each stack is stored per step (plus the full
+    stacks at the last step) to keep the fixture small; the stacking itself is checked on those."""
+    import legged_gym.envs.base.base_task as base_task
+    import legged_gym.envs.base.legged_robot as lr_mod
+    import legged_gym.envs.go2.go2_ee.go2_ee as ee_mod
+    from legged_gym.envs.go2.go2_ee.go2_ee_config import Go2EECfg
+    from legged_gym.utils.helpers import class_to_dict
+    from hcr_genesis_lr_cl_amd.config import GO2EECfg as MyCfg
+
+    rec = rh.DrawRecorder(seed)
+    base_task.GenesisSimulator = RoughFakeSimulator
+    lr_mod.torch_rand_float = rec.rand_float
+    ee_mod.torch_rand_float = rec.rand_float
+    orig_rand_like = torch.rand_like
+    torch.rand_like = rec.rand_like
+    try:
+        cfg = Go2EECfg()
+        cfg.env.num_envs = N
+        env = ee_mod.Go2EE(cfg, class_to_dict(cfg.sim), "cpu", True)
+        sim = env.simulator
+        sim.rec = rec
+        rng = np.random.default_rng(seed + 1)
+        model = sim.model
+        script = make_script(rng, model, cfg, N, T)
+        # place the robots on their tiles: around the env origin, some far enough to be promoted (> 4 m)
+        org = sim._env_origins.numpy()
+        off = rng.normal(size=(T, N, 2)) * 1.5 + np.where(rng.random((T, N, 1)) < 0.3, 4.5, 0.0)
+        script["base_pos"][:, :, :2] = (org[None, :, :2] + off).astype(np.float32)
+        script["base_pos"][:, :, 2] += org[None, :, 2]
+        script["feet_pos"][:, :, :, :2] += script["base_pos"][:, :, None, :2]
+        script["feet_pos"][:, :, :, 2] += org[None, :, None, 2]
+        sim.script = script
+        task = builders.make_task_cfg(model, MyCfg())
+        slots = task.slots
+        groups = [[0, 3, 6, 9], [1, 4, 7, 10], [2, 5, 8, 11]]
+        env.episode_length_buf[:] = torch.from_numpy(rng.choice([3, 120, 470, 495, 498, 499, 960, 985, 995, 998, 999, 1000], N).astype(np.int32))
+        env.commands[:] = torch.from_numpy((rng.normal(size=(N, 4)) * [0.4, 0.4, 0.5, 1.5]).astype(np.float32))
+        env.common_step_counter = 495                                   # push interval 10 s = 500 steps
+        env.reset_buf[:] = 0
+        rec.take()
+        init = dict(episode_length_buf=env.episode_length_buf.numpy().copy(), commands=env.commands.numpy().copy(),
+                    env_origins=sim._env_origins.numpy().copy(), terrain_levels=sim._terrain_levels.numpy().copy(),
+                    terrain_types=sim._terrain_types.numpy().copy(), height_points=sim._height_points[0, :, :2].numpy().copy())
+        keys = ("actions_in", "rand", "counter", "feat_new", "priv_new", "labels", "rew", "reset", "time_out", "commands", "ep_len",
+                "fail_buf", "feet_air_time", "episode_sums", "sim_dof_pos", "sim_base_pos", "terrain_levels", "env_origins",
+                "measured_heights", "height_around_feet", "normals", "contact_states", "last_dof_vel_in", "last_feet_vel_in", "esum_override")
+        out = {k: [] for k in keys}
+        names = env.reward_names
+        for t in range(T):
+            act = torch.from_numpy((rng.normal(size=(N, 12)) * (1.0 if t % 7 else 60.0)).astype(np.float32))
+            out["last_dof_vel_in"].append(sim._dof_vel.numpy().copy()); out["last_feet_vel_in"].append(sim._feet_vel.numpy().copy())
+            feat, labels, priv, rew, reset, extras = env.step(act)
+            calls = rec.take()
+            out["actions_in"].append(act.numpy().copy()); out["rand"].append(slots_from_calls(calls, slots, N, 12, groups))
+            out["counter"].append(env.common_step_counter); out["esum_override"].append(0.0)
+            out["feat_new"].append(feat.numpy()[:, -45:].copy()); out["priv_new"].append(priv.numpy()[:, -174:].copy())
+            out["labels"].append(labels.numpy().copy()); out["rew"].append(rew.numpy().copy())
+            out["reset"].append(reset.numpy().astype(np.uint8)); out["time_out"].append(env.time_out_buf.numpy().astype(np.uint8))
+            out["commands"].append(env.commands.numpy().copy()); out["ep_len"].append(env.episode_length_buf.numpy().copy())
+            out["fail_buf"].append(env.fail_buf.numpy().copy()); out["feet_air_time"].append(env.feet_air_time.numpy().copy())
+            out["episode_sums"].append(np.stack([env.episode_sums[n].numpy().copy() for n in names]))
+            out["sim_dof_pos"].append(sim._dof_pos.numpy().copy()); out["sim_base_pos"].append(sim._base_pos.numpy().copy())
+            out["terrain_levels"].append(sim._terrain_levels.numpy().copy()); out["env_origins"].append(sim._env_origins.numpy().copy())
+            out["measured_heights"].append(sim._measured_heights.numpy().copy())
+            out["height_around_feet"].append(sim._height_around_feet.numpy().copy())
+            out["normals"].append(sim._normal_vector_around_feet.numpy().copy())
+            out["contact_states"].append(sim._link_contact_states.numpy().copy())
+        arrays = {k: np.stack(v) for k, v in out.items()}
+        arrays["feat_last"], arrays["priv_last"] = feat.numpy().copy(), priv.numpy().copy()
+        arrays.update({"script_" + k: v for k, v in sim.script.items()})
+        arrays.update({"init_" + k: v for k, v in init.items()})
+        arrays["reward_names"] = np.array(names)
+        arrays["terrain_seed"] = RoughFakeSimulator.TERRAIN_SEED
+        path = os.path.join(HERE, "go2_ee_mdp.npz")
+        np.savez_compressed(path, **arrays)
+        print("wrote", path, os.path.getsize(path), "resets/step", arrays["reset"].sum(1), "levels moved",
+              int((arrays["terrain_levels"][-1] != init["terrain_levels"]).sum()))
+    finally:
+        torch.rand_like = orig_rand_like
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["go2", "wtw"]
+    which = sys.argv[1:] or ["go2", "wtw", "ee"]
+    if "ee" in which:
+        gen_ee()
     if "go2" in which:
         gen_go2()
     if "wtw" in which:

@@ -101,6 +101,14 @@ class DrawRecorder:
                                u=torch.tensor([(idx + 0.5) / high], dtype=torch.float32)))
         return torch.full(tuple(size), idx, dtype=torch.long)
 
+    def randint_like(self, t, high, env_ids):
+        import numpy as np
+        import torch
+        idx = self.rng.integers(0, high, size=tuple(t.shape))
+        self.calls.append(dict(caller="randint_like", parent="", env_ids=env_ids.clone(),
+                               u=torch.from_numpy(((idx + 0.5) / high).astype(np.float32))))
+        return torch.from_numpy(idx).to(t.dtype)
+
     def take(self):
         c, self.calls = self.calls, []
         return c

@@ -217,3 +217,105 @@ def test_wtw_env_runs_and_histories_shift():
         prev = (obs.clone(), priv.clone())
     assert torch.isfinite(obs).all() and torch.isfinite(priv).all() and torch.isfinite(rew).all()
     assert float(env.gait_period.min()) >= 0.3 and float(env.phi.max()) < 1.0
+
+
+# ------------------------------- go2_ee (rough terrain) ------------------------------------------
+class EEKernelStepper:
+    def __init__(self, fx, N):
+        import torch
+        from hcr_genesis_lr_cl_amd import builders
+        from hcr_genesis_lr_cl_amd.engine import Engine
+        from hcr_genesis_lr_cl_amd.model_compiler import load_model
+        from tests.test_mdp_oracle import ee_terrain
+        cfg, terrain = ee_terrain(fx)
+        self.cfg, self.terrain = cfg, terrain
+        model = load_model("go2")
+        desc, opts, task = builders.make_model_desc(model, cfg), builders.make_sim_options(model, cfg, terrain), builders.make_task_cfg(model, cfg)
+        eng = self.eng = Engine(model, desc, opts, task, N, "cuda:0", inject_rand=True)
+        eng.set_terrain(terrain.height_field_raw, terrain.env_origins, fx["init_height_points"])
+        cr = cfg.commands.ranges
+        eng.buf["command_ranges"][:8] = torch.tensor(list(cr.lin_vel_x) + list(cr.lin_vel_y) + list(cr.ang_vel_yaw) + list(cr.heading))
+        put(eng, "env_origins", fx["init_env_origins"]); put(eng, "episode_length_buf", fx["init_episode_length_buf"])
+        put(eng, "commands", fx["init_commands"])
+        put(eng, "terrain_levels", fx["init_terrain_levels"]); put(eng, "terrain_types", fx["init_terrain_types"])
+        eng.buf["friction_values"].fill_(0.0); eng.buf["added_base_mass"].fill_(1.0)
+        self.names = [str(n) for n in fx["reward_names"]]
+        self.fx = fx
+
+    def step(self, t, sim, actions, R, counter, override):
+        import torch
+        from hcr_genesis_lr_cl_amd import abi
+        eng, fx = self.eng, self.fx
+        load_sim(eng, sim)
+        # terrain read-backs of the SIM phase (checked separately against the numpy sampler): injected
+        put(eng, "measured_heights", fx["measured_heights"][t]); put(eng, "height_around_feet", fx["height_around_feet"][t])
+        put(eng, "rand_in", R)
+        eng.step(abi.PHASE_PRE | abi.PHASE_POST | abi.PHASE_RESET, torch.from_numpy(actions).cuda(), counter)
+        torch.cuda.synchronize()
+        es = get(eng, "episode_sums")
+        lab = get(eng, "labels_buf")
+        return dict(feat_new=get(eng, "obs_buf")[:, -45:], priv_new=get(eng, "priv_obs_buf")[:, -174:], labels=lab, rew=get(eng, "rew_buf"),
+                    reset=get(eng, "reset_buf"), time_out=get(eng, "time_out_buf"), commands=get(eng, "commands"),
+                    ep_len=get(eng, "episode_length_buf"), fail_buf=get(eng, "fail_buf"), feet_air_time=get(eng, "feet_air_time"),
+                    episode_sums=np.stack([es[abi.REWARD_ID[n]] for n in self.names]), sim_dof_pos=get(eng, "dof_pos"),
+                    sim_base_pos=get(eng, "base_pos"), terrain_levels=get(eng, "terrain_levels"), env_origins=get(eng, "env_origins"),
+                    measured_heights=fx["measured_heights"][t], height_around_feet=fx["height_around_feet"][t], normals=fx["normals"][t],
+                    contact_states=lab[:, 3:20], feat_full=get(eng, "obs_buf"), priv_full=get(eng, "priv_obs_buf"))
+
+
+def test_kernel_reproduces_reference_go2_ee_golden_vectors():
+    from tests.test_mdp_oracle import replay_ee, check_ee
+    replay_ee(EEKernelStepper, lambda t, fx, out: check_ee(t, fx, out, rtol=1e-5, atol=5e-5))
+
+
+def test_sim_phase_terrain_sampling_matches_numpy_sampler():
+    """a7/a8 on the GPU: after a physics step on the heightfield, measured_heights / height_around_feet /
+    normals / contact states written by the kernel equal the (reference-pinned) numpy sampler applied to
+    the kernel's own final base pose and feet positions."""
+    import torch
+    from hcr_genesis_lr_cl_amd import abi
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    np.random.seed(3)
+    env, cfg = make_env("go2_ee", 512)
+    env.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(2)
+    for _ in range(25):
+        env.step(torch.randn(512, 12, generator=g, device="cuda"))
+    # one bare physics step so that the read-backs are not modified by resets afterwards
+    env._engine.step(abi.PHASE_SIM, torch.randn(512, 12, generator=g, device="cuda"), 0)
+    torch.cuda.synchronize()
+    b = {k: v.detach().cpu().numpy() for k, v in env._engine.buf.items() if torch.is_tensor(v)}
+    t, c = env.simulator._terrain, cfg.terrain
+    hp = b["height_points"]
+    mh = mo.sample_heights(b["base_pos"], b["base_quat"], hp, t.height_field_raw, c.border_size, c.horizontal_scale, c.vertical_scale)
+    har, nrm = mo.feet_terrain_info(b["feet_pos"], t.height_field_raw, c.border_size, c.horizontal_scale, c.vertical_scale)
+    # a sample point within float round-off of a cell edge may fall in the neighbouring cell: allow a handful
+    bad = np.abs(b["measured_heights"] - mh) > 1e-6
+    assert bad.mean() < 2e-3, bad.mean()
+    assert (np.abs(b["height_around_feet"] - har) > 1e-6).mean() < 2e-3
+    assert (np.abs(b["normal_vector_around_feet"] - nrm) > 1e-5).mean() < 5e-3
+    st = (np.linalg.norm(b["link_contact_forces"], axis=-1) > 1.0).astype(np.float32)
+    np.testing.assert_array_equal(b["link_contact_states"], st)
+    assert np.ptp(mh) > 0.05          # the robots really are on uneven ground
+
+
+def test_go2_ee_env_surface_and_terrain_curriculum():
+    import torch
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    np.random.seed(3)
+    env, cfg = make_env("go2_ee", 1024)
+    f, l, p = env.reset()
+    assert f.shape == (1024, 900) and l.shape == (1024, 24) and p.shape == (1024, 870)
+    lv0 = env.simulator.terrain_levels.clone()
+    assert int(lv0.max()) <= 1                       # max_init_terrain_level (genesis_simulator.py:518-522)
+    env.episode_length_buf[:] = torch.randint(0, 1000, (1024,), device="cuda", dtype=torch.int32)
+    g = torch.Generator(device="cuda"); g.manual_seed(4)
+    for t in range(300):
+        f, l, p, rew, done, extras = env.step(torch.randn(1024, 12, generator=g, device="cuda") * 0.3)
+    assert torch.isfinite(f).all() and torch.isfinite(p).all() and torch.isfinite(rew).all()
+    lv = env.simulator.terrain_levels
+    assert int(lv.min()) >= 0 and int(lv.max()) < 10 and not torch.equal(lv, lv0)
+    org = env.simulator.env_origins
+    to = torch.from_numpy(env.simulator._terrain.env_origins).float().cuda()
+    assert torch.allclose(org, to[lv.long(), env.simulator.terrain_types.long()])
+    assert "terrain_level" in list(extras["episode"])
