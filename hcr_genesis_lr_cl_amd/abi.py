@@ -109,7 +109,9 @@ class LgTaskCfg(C.Structure):
         ("num_labels", i32), ("heights_offset", f32), ("heights_clip_scale", i32),
         ("terrain_env_length", f32), ("episode_length_s", f32),
         ("gait_mode", i32), ("double_shift", i32), ("behavior_resample_steps", i32), ("num_gait_max", i32),
-        ("b_swing", f32), ("gait_period_fixed", f32), ("theta_table", f32 * 4 * 4), ("task_state_width", i32),
+        ("b_swing", f32), ("gait_period_fixed", f32), ("theta_table", f32 * 4 * 4),
+        ("sit_percent", f32), ("sit_pos", f32 * 3), ("sit_quat", f32 * 4), ("sit_dof_pos", f32 * MAX_DOF),
+        ("task_state_width", i32),
         ("slots", LgRandSlots), ("seed", u64), ("env_id_offset", i64),
     ]
 

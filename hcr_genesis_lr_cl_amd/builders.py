@@ -116,6 +116,32 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
         abi.fill_array(t.noise_vec, go2_noise_vec(cfg))            # go2_ee.py:100-122
         t.slots = go2_slots(A, e.num_single_obs)
         t.heights_offset, t.heights_clip_scale = 0.5, 1             # go2_ee.py:45-46
+    elif layout == "tron1_ee":
+        e = cfg.env
+        t.obs_frame, t.obs_stack, t.num_obs = e.num_single_obs, e.frame_stack, e.num_estimator_features
+        t.priv_frame, t.priv_stack, t.num_priv_obs = e.single_critic_obs_len, e.c_frame_stack, e.num_privileged_obs
+        t.num_labels = e.num_estimator_labels
+        # tron1_pf_ee.py:322-342 writes the 12-DOF slices into a 31-wide vector: q AND qd get
+        # the dof_pos scale, actions and clock get the dof_vel scale
+        ns, lvl, sc = cfg.noise.noise_scales, cfg.noise.noise_level, cfg.normalization.obs_scales
+        nv = np.zeros(e.num_single_obs, np.float32)
+        nv[3:6] = ns.gravity * lvl
+        nv[6:9] = ns.ang_vel * lvl * sc.ang_vel
+        nv[9:21] = ns.dof_pos * lvl * sc.dof_pos
+        nv[21:33] = ns.dof_vel * lvl * sc.dof_vel
+        abi.fill_array(t.noise_vec, nv)
+        t.slots = go2_slots(A, e.num_single_obs)
+        t.heights_offset, t.heights_clip_scale = 0.6, 1           # tron1_pf_ee.py:96-98
+        prf, ini = cfg.rewards.periodic_reward_framework, cfg.init_state
+        t.gait_mode, t.double_shift = 2, 1
+        t.b_swing, t.gait_period_fixed = prf.b_swing, prf.gait_period
+        t.theta_table[0][0], t.theta_table[0][1] = prf.theta_left, prf.theta_right
+        t.task_state_width = abi.TASK_STATE_BIPED
+        t.sit_percent = ini.sit_init_percent
+        abi.fill_array(t.sit_pos, ini.sit_pos)
+        hp = 0.5 * ini.sit_pitch_angle                           # quat_from_euler_xyz(0, pitch, 0), math_utils.py:112-124
+        abi.fill_array(t.sit_quat, [0.0, np.float32(np.sin(np.float32(hp))), 0.0, np.float32(np.cos(np.float32(hp)))])
+        abi.fill_array(t.sit_dof_pos, [ini.sit_joint_angles[n] for n in cfg.asset.dof_names])
     else:
         raise NotImplementedError(layout)
     t.control_dt = dt

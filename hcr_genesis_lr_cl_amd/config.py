@@ -291,3 +291,58 @@ class GO2EECfg(LeggedRobotCfg):
     # go2_ee.py:77-98 (per-joint reset ranges), legged_robot.py:283-298 (base-class root reset), :124-134 (air time 0.25)
     reset = section(dof_ranges={"hip": 0.2, "thigh": 0.4, "calf": 0.4}, root_vel_range=0.5, robot="go2",
                     obs_layout="go2_ee", feet_air_time_threshold=0.25)
+
+
+# tron1_pf/tron1_pf_ee/tron1_pf_ee_config.py:4-174 (TRON1PF_EECfg, experiment "tron1_pf_rough"): 6-DOF point-foot biped
+class TRON1PFEECfg(LeggedRobotCfg):
+    env = section(LeggedRobotCfg.env, num_envs=4096, num_single_obs=31, frame_stack=10, num_estimator_features=310,
+                  num_estimator_labels=17, c_frame_stack=10, single_critic_obs_len=31 + 22 + 49 + 6 + 2 + 24,
+                  num_privileged_obs=10 * (31 + 22 + 49 + 6 + 2 + 24), num_observations=310, num_actions=6, env_spacing=3.0)
+    terrain = section(
+        LeggedRobotCfg.terrain, mesh_type="heightfield", border_size=15.0, curriculum=True,
+        obtain_terrain_info_around_feet=True, measure_heights=True,
+        measured_points_x=[-0.3, -0.2, -0.1, 0., 0.1, 0.2, 0.3], measured_points_y=[-0.3, -0.2, -0.1, 0., 0.1, 0.2, 0.3],
+        terrain_length=8.0, terrain_width=8.0, platform_size=4.0, num_rows=10, num_cols=10,
+        terrain_proportions=[0.2, 0.2, 0.2, 0.2, 0.2])
+    init_state = section(
+        LeggedRobotCfg.init_state, pos=[0.0, 0.0, 0.83],
+        default_joint_angles={f"{j}_{s}_Joint": 0.0 for s in ("L", "R") for j in ("abad", "hip", "knee", "foot")},
+        sit_pos=[0.0, 0.0, 0.55],
+        sit_joint_angles={"abad_L_Joint": 0.0, "hip_L_Joint": 0.6, "knee_L_Joint": 1.36, "foot_L_Joint": 0.0,
+                          "abad_R_Joint": 0.0, "hip_R_Joint": -0.6, "knee_R_Joint": -1.36, "foot_R_Joint": 0.0},
+        sit_pitch_angle=-0.2, sit_init_percent=0.7)
+    control = section(LeggedRobotCfg.control, stiffness={"Joint": 42.0}, damping={"Joint": 2.5}, action_scale=0.25,
+                      decimation=4, dt=0.02)
+    asset = section(
+        LeggedRobotCfg.asset, name="tron1_pf", file="{LEGGED_GYM_ROOT_DIR}/resources/robots/PF_TRON1A/urdf/robot.urdf",
+        obtain_link_contact_states=True, contact_state_link_names=["hip", "knee", "foot"], foot_name="foot",
+        penalize_contacts_on=["knee", "hip"], terminate_after_contacts_on=["base", "abad"], base_link_name="base_Link",
+        dof_names=[f"{j}_{s}_Joint" for s in ("L", "R") for j in ("abad", "hip", "knee")],
+        links_to_keep=["foot_L_Link", "foot_R_Link"], dof_vel_limits=[])
+    rewards = section(
+        LeggedRobotCfg.rewards, soft_dof_pos_limit=0.95, base_height_target=0.75, foot_clearance_target=0.06,
+        foot_height_offset=0.032, foot_clearance_tracking_sigma=0.01, base_height_tracking_sigma=0.01,
+        foot_distance_threshold=0.115, only_positive_rewards=False, max_projected_gravity=-0.2,
+        scales=section(
+            LeggedRobotCfg.rewards.scales, keep_balance=1.0, dof_pos_limits=-2.0, collision=-1.0, feet_distance=-100.0,
+            tracking_lin_vel=1.0, tracking_ang_vel=0.5, tracking_base_height=0.3, lin_vel_z=-0.5, ang_vel_xy=-0.05,
+            orientation=-4.0, dof_power=-2.0e-4, dof_acc=-2.0e-7, foot_acc=-1.0e-5, action_rate=-0.01,
+            action_smoothness=-0.01, biped_periodic_gait=1.0, foot_clearance=0.5),
+        periodic_reward_framework=section(gait_function_type="step", kappa=20, b_swing=0.5, theta_left=0.0,
+                                          theta_right=0.5, gait_period=0.5))
+    commands = section(
+        LeggedRobotCfg.commands, curriculum=True, max_curriculum=0.8, num_commands=4, resampling_time=10.0,
+        heading_command=True,
+        ranges=section(LeggedRobotCfg.commands.ranges, lin_vel_x=[-0.5, 0.5], lin_vel_y=[-0.6, 0.6],
+                       ang_vel_yaw=[-1, 1], heading=[-3.14, 3.14]))
+    domain_rand = section(
+        LeggedRobotCfg.domain_rand, randomize_friction=True, friction_range=[0.0, 1.7], randomize_base_mass=True,
+        added_mass_range=[-1.0, 2.0], push_robots=True, push_interval_s=10, max_push_vel_xy=1.0,
+        randomize_com_displacement=True, com_pos_x_range=[-0.03, 0.03], com_pos_y_range=[-0.03, 0.03],
+        com_pos_z_range=[-0.03, 0.03], randomize_pd_gain=True, kp_range=[0.8, 1.2], kd_range=[0.8, 1.2],
+        randomize_joint_armature=True, joint_armature_range=[0.11, 0.13], randomize_joint_friction=True,
+        joint_friction_range=[0.00, 0.01], randomize_joint_damping=True, joint_damping_range=[1.4, 1.45])
+    normalization = section(LeggedRobotCfg.normalization, clip_actions=20.0)
+    # tron1_pf_ee.py:258-275 (per-joint reset ranges), base-class root reset, sit-pose branch :204-210, 277-310
+    reset = section(dof_ranges={"abad": 0.2, "hip": 0.4, "knee": 0.4}, root_vel_range=0.5, robot="tron1_pf",
+                    obs_layout="tron1_ee", feet_air_time_threshold=0.3)

@@ -199,6 +199,9 @@ typedef struct LgTaskCfg {
     float b_swing;                   /* fraction of the cycle */
     float gait_period_fixed;         /* biped: constant gait period */
     float theta_table[4][4];         /* [gait][foot slot in feet_indices order] */
+    /* tron1_pf_ee sit-pose resets (tron1_pf_ee.py:204-210, 277-310): one batch-wide draw picks the branch */
+    float sit_percent;               /* 0 = feature off */
+    float sit_pos[3], sit_quat[4], sit_dof_pos[LG_MAX_DOF];
     int32_t task_state_width;
     LgRandSlots slots;
     uint64_t seed;

@@ -137,6 +137,16 @@ class MdpOracle:
             self.priv_hist = z(N, task.priv_stack, task.priv_frame)
         if task.gait_mode == 1:
             self._init_wtw()
+        self.joint_armature, self.joint_friction, self.joint_damping = z(N, 1), z(N, 1), z(N, 1)
+        if task.gait_mode == 2:                                       # tron1_pf_ee.py:150-184
+            self.theta = np.tile(np.ctypeslib.as_array(task.theta_table).reshape(4, 4)[0, :2], (N, 1)).astype(f32)
+            self.gait_time, self.phi = z(N, 1), z(N, 1)
+            self.gait_period = np.full((N, 1), task.gait_period_fixed, f32)
+            self.clock_input = z(N, 4)
+            self.exp_C_frc = z(N, 2)
+        if task.obs_layout == abi.OBS_TRON1_EE:
+            self.obs_hist = z(N, task.obs_stack, task.obs_frame)
+            self.priv_hist = z(N, task.priv_stack, task.priv_frame)
 
     def _init_wtw(self):
         """go2_wtw.py:295-376 (_init_buffers + _parse_cfg)."""
@@ -164,6 +174,28 @@ class MdpOracle:
     def behavior_ranges(self):
         return np.array(self.gait_period_range + self.base_height_target_range + self.foot_clearance_target_range
                         + self.pitch_target_range + [self.num_gaits], f32)
+
+    def _gait_indicator(self, feet_f, feet_vel, n_feet):
+        """"step" indicator of go2_wtw.py:377-470 / tron1_pf_ee.py:347-424, including the reference's index-flatten bug
+        that overwrites env 0 (see _resample_behavior docstring of the wtw notes)."""
+        T, N = self.task, self.N
+        acc = np.zeros(N, f32)
+        b_swing = f32(T.b_swing) * f32(2 * np.pi)
+        for i in range(n_feet):
+            q_frc = np.linalg.norm(feet_f[:, i], axis=-1)
+            q_spd = np.linalg.norm(feet_vel[:, i], axis=-1)
+            ph = np.remainder(self.phi[:, 0] + self.theta[:, i], f32(1.0)).astype(f32) * f32(2 * np.pi)
+            swing = (ph >= 0) & (ph < b_swing)
+            stance = (ph >= b_swing) & (ph < f32(2 * np.pi))
+            c_frc = np.where(swing, -1.0, 0.0).astype(f32)
+            c_spd = np.where(stance, -1.0, 0.0).astype(f32)
+            if swing.any():
+                c_frc[0], c_spd[0] = -1.0, 0.0
+            if stance.any():
+                c_frc[0], c_spd[0] = 0.0, -1.0
+            self.exp_C_frc[:, i] = c_frc
+            acc = acc + (c_spd * q_spd + c_frc * q_frc).astype(f32)
+        return acc
 
     def _resample_behavior(self, ids, R, slot):
         """go2_wtw.py:180-218.  One gait index per call for the whole batch (quirk 6); the pronk/bound
@@ -262,6 +294,8 @@ class MdpOracle:
             add("ang_vel_xy", np.sum(bav[:, :2] ** 2, axis=1))
         if on("base_height"):
             add("base_height", (sim["base_pos"][:, 2] - f32(T.base_height_target)) ** 2)
+        if on("biped_periodic_gait"):                                      # tron1_pf_ee.py:347-433
+            add("biped_periodic_gait", np.exp(self._gait_indicator(feet_f, feet_vel, 2)))
         if on("collision"):
             add("collision", np.sum(1.0 * (np.linalg.norm(F_l[:, self.pen], axis=-1) > 0.1), axis=1))
         if on("dof_acc"):
@@ -292,6 +326,9 @@ class MdpOracle:
         if on("feet_contact_stand_still"):
             full = np.sum(1.0 * (feet_f[:, :, 2] > 0.1), axis=1) == F
             add("feet_contact_stand_still", 1.0 * full * (cmd_xyz < 0.1))
+        if on("feet_distance"):                                            # tron1_pf_ee.py:458-463
+            d = np.linalg.norm(feet_pos[:, 0, :2] - feet_pos[:, 1, :2], axis=-1)
+            add("feet_distance", np.maximum(0, f32(T.foot_distance_threshold) - d))
         if on("foot_acc"):
             acc = (feet_vel - sim["last_feet_vel"].reshape(N, F, 3)) / self.dt
             add("foot_acc", np.sum(acc ** 2, axis=(1, 2)))
@@ -300,6 +337,8 @@ class MdpOracle:
             zf = feet_pos[:, :, 2]
             if T.obs_layout == abi.OBS_GO2_EE:                                # go2_ee.py:136-150
                 zf = zf - np.mean(sim["height_around_feet"].reshape(N, F, 9), axis=-1)
+            elif T.obs_layout == abi.OBS_TRON1_EE:                            # tron1_pf_ee.py:442-456
+                zf = zf - np.max(sim["height_around_feet"].reshape(N, F, 9), axis=-1)
             err = np.sum(vxy * (zf - f32(T.foot_clearance_target) - f32(T.foot_height_offset)) ** 2, axis=-1)
             add("foot_clearance", np.exp(-err / f32(T.foot_clearance_sigma)))
         if on("foot_landing_vel"):
@@ -340,7 +379,10 @@ class MdpOracle:
         if on("tracking_ang_vel"):
             add("tracking_ang_vel", np.exp(-((cmd[:, 2] - bav[:, 2]) ** 2) / f32(T.tracking_sigma)))
         if on("tracking_base_height"):                                     # go2_wtw.py:495-500 (plane: heights are 0)
-            d = sim["base_pos"][:, 2] - self.base_height_target[:, 0]
+            if T.gait_mode == 1:
+                d = sim["base_pos"][:, 2] - self.base_height_target[:, 0]
+            else:                                                              # tron1_pf_ee.py:435-440
+                d = np.mean(sim["base_pos"][:, 2:3] - sim["measured_heights"], axis=1) - f32(T.base_height_target)
             add("tracking_base_height", np.exp(-(d ** 2) / f32(T.base_height_sigma)))
         if on("tracking_foot_clearance"):                                  # go2_wtw.py:507-519
             vxy = np.linalg.norm(feet_vel[:, :, :2], axis=-1)
@@ -359,7 +401,7 @@ class MdpOracle:
             total = total + rew
             self.episode_sums[k] += rew
         self.rew_buf = total.astype(f32)
-        if T.gait_mode == 1:                                               # go2_wtw.py:29-36
+        if T.gait_mode in (1, 2):                                          # go2_wtw.py:29-36, tron1_pf_ee.py:28-35
             self.gait_time += self.dt
             over = self.gait_time >= (self.gait_period - self.dt / f32(2))
             self.gait_time[over] = 0
@@ -384,17 +426,23 @@ class MdpOracle:
             if T.gait_mode == 1:
                 self._resample_behavior(ids, R, S.task_reset)
             self._resample(ids, R, S.reset_cmd)
+            sit = T.sit_percent > 0 and R[ids[0], S.task_reset] < T.sit_percent      # one draw per call (quirk 11)
             lo = np.ctypeslib.as_array(T.reset_dof_lo)[:A]
             span = np.ctypeslib.as_array(T.reset_dof_span)[:A]
-            sim["dof_pos"][ids] = self.q0 + (span * R[ids, S.reset_dof:S.reset_dof + A] + lo)   # go2.py:30-35
+            if sit:                                                            # tron1_pf_ee.py:277-283
+                sim["dof_pos"][ids] = np.ctypeslib.as_array(T.sit_dof_pos)[:A]
+            else:
+                sim["dof_pos"][ids] = self.q0 + (span * R[ids, S.reset_dof:S.reset_dof + A] + lo)   # go2.py:30-35
             sim["dof_vel"][ids] = 0
-            pos = np.array(self.cfg.init_state.pos, f32) + self.env_origins[ids]
+            pos = (np.ctypeslib.as_array(T.sit_pos) if sit else np.array(self.cfg.init_state.pos, f32)) + self.env_origins[ids]
             if T.custom_origins:
                 pos[:, :2] += f32(T.reset_root_xy_span) * R[ids, S.reset_root_xy:S.reset_root_xy + 2] + f32(T.reset_root_xy_lo)
             sim["base_pos"][ids] = pos
-            sim["base_quat"][ids] = np.ctypeslib.as_array(T.base_init_quat)
+            sim["base_quat"][ids] = np.ctypeslib.as_array(T.sit_quat) if sit else np.ctypeslib.as_array(T.base_init_quat)
             lv = f32(T.reset_lin_vel_span) * R[ids, S.reset_lin_vel:S.reset_lin_vel + 3] + f32(T.reset_lin_vel_lo)
             av = f32(T.reset_ang_vel_span) * R[ids, S.reset_ang_vel:S.reset_ang_vel + 3] + f32(T.reset_ang_vel_lo)
+            if sit:
+                lv, av = np.zeros_like(lv), np.zeros_like(av)
             sim["base_lin_vel_w"][ids], sim["base_ang_vel_w"][ids] = lv, av
             blv[ids], bav[ids] = lv, av                                    # genesis_simulator.py:128-129
             pg = quat_rotate_inverse(sim["base_quat"], g)                  # :125
@@ -405,6 +453,10 @@ class MdpOracle:
             if T.dr_com_on:
                 for k in range(3):
                     self.base_com_bias[ids, k] = f32(T.dr_com_span[k]) * R[ids, S.dr_com + k] + f32(T.dr_com_lo[k])
+            if T.dr_joint_on:                                              # genesis_simulator.py:704-733
+                self.joint_armature[ids, 0] = f32(T.dr_joint_span[0]) * R[ids, S.dr_joint] + f32(T.dr_joint_lo[0])
+                self.joint_friction[ids, 0] = f32(T.dr_joint_span[1]) * R[ids, S.dr_joint + 1] + f32(T.dr_joint_lo[1])
+                self.joint_damping[ids, 0] = f32(T.dr_joint_span[2]) * R[ids, S.dr_joint + 2] + f32(T.dr_joint_lo[2])
             if T.dr_pd_on:
                 self.kp_scale[ids] = f32(T.dr_kp_span) * R[ids, S.dr_kp:S.dr_kp + A] + f32(T.dr_kp_lo)
                 self.kd_scale[ids] = f32(T.dr_kd_span) * R[ids, S.dr_kd:S.dr_kd + A] + f32(T.dr_kd_lo)
@@ -416,6 +468,13 @@ class MdpOracle:
             self.fail_buf[ids] = 0
             if T.gait_mode == 1:                                           # go2_wtw.py:139-142, 174-178
                 self.gait_time[ids] = 0; self.phi[ids] = 0; self.clock_input[ids] = 0
+            if T.gait_mode == 2:                                           # tron1_pf_ee.py:220-226
+                tt = np.ctypeslib.as_array(T.theta_table).reshape(4, 4)
+                self.theta[ids, 0] = f32(tt[0, 0]) + R[ids, S.task_reset + 1]
+                self.theta[ids, 1] = self.theta[ids, 0] + f32(tt[0, 1] - tt[0, 0])
+                self.gait_time[ids, 0] = R[ids, S.task_reset + 2] * self.gait_period[ids, 0]
+                self.phi[ids] = self.gait_time[ids] / self.gait_period[ids]
+                self.clock_input[ids] = 0
             if T.obs_stack > 1:                                            # go2_wtw.py:174-178, legged_robot_ee.py:115-121
                 self.obs_hist[ids] = 0; self.priv_hist[ids] = 0
             self.done_sums = (self.episode_sums[:, ids].sum(1), len(ids))
@@ -472,6 +531,34 @@ class MdpOracle:
             fh = np.clip(sim["feet_pos"].reshape(N, F, 3)[:, :, 2] - np.mean(sim["height_around_feet"].reshape(N, F, 9), axis=-1)
                          - f32(T.foot_height_offset), -1, 1)
             self.labels_buf = np.concatenate([blv * f32(T.obs_scale_lin_vel), states, fh], axis=1).astype(f32)
+        elif T.obs_layout == abi.OBS_TRON1_EE:                               # tron1_pf_ee.py:53-141, 251-256
+            for i in range(2):
+                ang = f32(2 * np.pi) * (self.phi[:, 0] + self.theta[:, i])
+                self.clock_input[:, i] = np.sin(ang)
+                self.clock_input[:, i + 2] = np.cos(ang)
+            cs = np.array([T.obs_scale_lin_vel, T.obs_scale_lin_vel, T.obs_scale_ang_vel], f32)
+            frame = np.concatenate([self.commands[:, :3] * cs, pg, bav * f32(T.obs_scale_ang_vel),
+                                    (sim["dof_pos"] - self.q0) * f32(T.obs_scale_dof_pos),
+                                    sim["dof_vel"] * f32(T.obs_scale_dof_vel), self.actions, self.clock_input], axis=1).astype(f32)
+            states = (1.0 * (np.linalg.norm(F_l[:, self.state_links], axis=-1) > 1.0)).astype(f32)
+            dr = np.concatenate([self.friction_values - f32(T.friction_offset), self.added_base_mass, self.base_com_bias,
+                                 self.rand_push_vels[:, :2], self.kp_scale - f32(T.kp_offset), self.kd_scale - f32(T.kd_offset),
+                                 self.joint_armature, self.joint_friction, self.joint_damping], axis=1)
+            heights = np.clip(sim["base_pos"][:, 2:3] - f32(T.heights_offset) - sim["measured_heights"], -1, 1) * f32(T.obs_scale_height)
+            har = sim["height_around_feet"].reshape(N, F, 9)
+            fpz = sim["feet_pos"].reshape(N, F, 3)[:, :, 2]
+            rel = np.clip((fpz[:, :, None] - har).reshape(N, -1), -1.0, 1.0)
+            crit = np.concatenate([frame, dr, self.exp_C_frc, states, heights, sim["normals"], rel], axis=1).astype(f32)
+            now = frame
+            if T.add_noise:
+                now = frame + (f32(2) * R[:, S.noise:S.noise + frame.shape[1]] - f32(1)) * self.noise_vec
+            self.obs_hist = np.concatenate([self.obs_hist[:, 1:], now[:, None]], axis=1)
+            self.priv_hist = np.concatenate([self.priv_hist[:, 1:], crit[:, None]], axis=1)
+            co = f32(T.clip_obs)
+            self.obs_buf = np.clip(self.obs_hist.reshape(N, -1), -co, co).astype(f32)
+            self.priv_obs_buf = np.clip(self.priv_hist.reshape(N, -1), -co, co).astype(f32)
+            fh = np.clip(fpz - np.max(har, axis=-1) - f32(T.foot_height_offset), -1, 1)
+            self.labels_buf = np.concatenate([blv * f32(T.obs_scale_lin_vel), states, fh, sim["normals"]], axis=1).astype(f32)
         else:
             raise NotImplementedError
         if T.double_shift:                                                   # go2_wtw.py:45-46

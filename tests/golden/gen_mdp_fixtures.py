@@ -82,6 +82,8 @@ class FakeSimulator:
         self._friction_values, self._added_base_mass = z(N, 1), torch.ones(N, 1)
         self._base_com_bias, self._rand_push_vels = z(N, 3), z(N, 3)
         self._kp_scale, self._kd_scale = torch.ones(N, A), torch.ones(N, A)
+        self._joint_armature, self._joint_friction, self._joint_damping = z(N, 1), z(N, 1), z(N, 1)
+        self.dof_names = list(cfg.asset.dof_names)   # tron1_pf_ee.py:171 reads simulator.dof_names (absent from the reference ABC)
         self._global_gravity = torch.tensor([0., 0., -1.]).repeat(N, 1)
         self.script, self.t, self.rec = None, -1, None
 
@@ -104,20 +106,29 @@ class FakeSimulator:
 
     # -- writes (semantics of genesis_simulator.py:62-158) ---------------------------------------
     def reset_idx(self, env_ids):
+        """Order and formulas of genesis_simulator.py:62-82, 665-739; draws go through the recorder."""
         d = self._cfg.domain_rand
         n = len(env_ids)
+        ids = torch.as_tensor(env_ids)
         if d.randomize_friction:
             lo, hi = d.friction_range
-            self._friction_values[env_ids] = self.rec.rand_float(0., 1., (n, 1), "cpu") * (hi - lo) + lo
+            self._friction_values[env_ids] = self.rec.tagged("dr_friction", (n, 1), ids) * (hi - lo) + lo
         if d.randomize_base_mass:
             lo, hi = d.added_mass_range
-            self._added_base_mass[env_ids] = self.rec.rand_float(0., 1., (n, 1), "cpu") * (hi - lo) + lo
+            self._added_base_mass[env_ids] = self.rec.tagged("dr_mass", (n, 1), ids) * (hi - lo) + lo
         if d.randomize_com_displacement:
             for k, (lo, hi) in enumerate((d.com_pos_x_range, d.com_pos_y_range, d.com_pos_z_range)):
-                self._base_com_bias[env_ids, k] = self.rec.rand_float(0., 1., (n, 1), "cpu").squeeze(1) * (hi - lo) + lo
+                self._base_com_bias[env_ids, k] = self.rec.tagged(f"dr_com+{k}", (n, 1), ids).squeeze(1) * (hi - lo) + lo
+        for k, (flag, rng_name, buf) in enumerate((("randomize_joint_armature", "joint_armature_range", "_joint_armature"),
+                                                   ("randomize_joint_friction", "joint_friction_range", "_joint_friction"),
+                                                   ("randomize_joint_damping", "joint_damping_range", "_joint_damping"))):
+            if getattr(d, flag):
+                lo, hi = getattr(d, rng_name)
+                getattr(self, buf)[env_ids, 0] = self.rec.tagged(f"dr_joint+{k}", (n,), ids) * (hi - lo) + lo
         if d.randomize_pd_gain:
-            self._kp_scale[env_ids] = self.rec.rand_float(d.kp_range[0], d.kp_range[1], (n, self._num_actions), "cpu")
-            self._kd_scale[env_ids] = self.rec.rand_float(d.kd_range[0], d.kd_range[1], (n, self._num_actions), "cpu")
+            A = self._num_actions
+            self._kp_scale[env_ids] = (d.kp_range[1] - d.kp_range[0]) * self.rec.tagged("dr_kp", (n, A), ids) + d.kp_range[0]
+            self._kd_scale[env_ids] = (d.kd_range[1] - d.kd_range[0]) * self.rec.tagged("dr_kd", (n, A), ids) + d.kd_range[0]
         self._last_dof_vel[env_ids] = 0.
         self._last_feet_vel[env_ids] = 0.
 
@@ -274,11 +285,18 @@ def slots_from_calls(calls, slots, N, A, policy_dof_groups):
                 seen["root3"] = k3 + 1
                 base = [slots.reset_lin_vel, slots.reset_ang_vel][k3]
             R[ids, base:base + u.shape[1]] = u
-        elif c["caller"] == "reset_idx":     # FakeSimulator.reset_idx: friction, mass, com x/y/z, kp, kd
-            order = [(slots.dr_friction, 1), (slots.dr_mass, 1), (slots.dr_com, 1), (slots.dr_com + 1, 1),
-                     (slots.dr_com + 2, 1), (slots.dr_kp, A), (slots.dr_kd, A)]
-            base, w = order[k]
-            R[ids, base:base + w] = u.reshape(len(ids), -1)
+        elif c["caller"].startswith("tag:"):
+            name, _, off = c["caller"][4:].partition("+")
+            base = getattr(slots, name) + (int(off) if off else 0)
+            uu = u.reshape(len(ids), -1)
+            R[ids, base:base + uu.shape[1]] = uu
+        elif c["caller"] == "torch_rand:reset_idx":          # tron1_pf_ee.py:220-225: theta offset, gait time
+            R[ids, slots.task_reset + 1 + k] = u[:, 0]
+        elif c["caller"] == "np_random:reset_idx":           # tron1_pf_ee.py:204 sit-pose coin, one per call
+            R[ids, slots.task_reset] = float(u[0])
+        elif c["caller"] == "_reset_root_states_sit_pose":
+            if u.shape[1] == 2:
+                R[ids, slots.reset_root_xy:slots.reset_root_xy + 2] = u
         elif c["caller"] == "_resample_behavior_params":
             base = slots.task_cb if c["parent"] == "_post_physics_step_callback" else slots.task_reset
             R[ids, base + k] = u[:, 0]
@@ -554,8 +572,103 @@ def gen_ee(N=24, T=48, seed=21):
         torch.rand_like = orig_rand_like
 
 
+def gen_tron1(N=24, T=48, seed=31):
+    """TRON1PF_EE (tron1_pf_ee.py): 6-DOF biped, heightfield + curriculum, biped periodic gait, sit-pose resets,
+    all domain randomisation incl. joint armature / friction / damping.  The command-curriculum gate step is not
+    crossed (the reference calls the non-existent `update_command_curriculum`, tron1_pf_ee.py:201)."""
+    import legged_gym.envs.base.base_task as base_task
+    import legged_gym.envs.base.legged_robot as lr_mod
+    import legged_gym.envs.tron1_pf.tron1_pf_ee.tron1_pf_ee as tr_mod
+    from legged_gym.envs.tron1_pf.tron1_pf_ee.tron1_pf_ee_config import TRON1PF_EECfg
+    from legged_gym.utils.helpers import class_to_dict
+    from hcr_genesis_lr_cl_amd.config import TRON1PFEECfg as MyCfg
+
+    rec = rh.DrawRecorder(seed)
+    base_task.GenesisSimulator = RoughFakeSimulator
+    lr_mod.torch_rand_float = rec.rand_float
+    tr_mod.torch_rand_float = rec.rand_float
+    orig = (torch.rand_like, torch.rand, np.random.random)
+    torch.rand_like, torch.rand, np.random.random = rec.rand_like, rec.torch_rand, rec.np_random
+    try:
+        cfg = TRON1PF_EECfg()
+        cfg.env.num_envs = N
+        torch.rand = orig[1]                      # construction uses torch.rand-free paths; keep the original until stepping
+        env = tr_mod.TRON1PF_EE(cfg, class_to_dict(cfg.sim), "cpu", True)
+        torch.rand = rec.torch_rand
+        sim = env.simulator
+        sim.rec = rec
+        rng = np.random.default_rng(seed + 1)
+        model = sim.model
+        script = make_script(rng, model, cfg, N, T)
+        org = sim._env_origins.numpy()
+        off = rng.normal(size=(T, N, 2)) * 1.5 + np.where(rng.random((T, N, 1)) < 0.3, 4.5, 0.0)
+        script["base_pos"][:, :, :2] = (org[None, :, :2] + off).astype(np.float32)
+        script["base_pos"][:, :, 2] += org[None, :, 2] + 0.4
+        script["feet_pos"][:, :, :, :2] = script["feet_pos"][:, :, :, :2] * 0.4 + script["base_pos"][:, :, None, :2]
+        script["feet_pos"][:, :, :, 2] += org[None, :, None, 2]
+        sim.script = script
+        task = builders.make_task_cfg(model, MyCfg())
+        slots = task.slots
+        groups = [[0, 3], [1, 4], [2, 5]]                                # tron1_pf_ee.py:268-273
+        env.episode_length_buf[:] = torch.from_numpy(rng.choice([3, 120, 470, 495, 498, 499, 960, 985, 995, 998, 999, 1000], N).astype(np.int32))
+        env.commands[:] = torch.from_numpy((rng.normal(size=(N, 4)) * [0.4, 0.4, 0.5, 1.5]).astype(np.float32))
+        env.common_step_counter = 495
+        env.reset_buf[:] = 0
+        env.theta[:, 0] = torch.from_numpy(rng.uniform(0, 1, N).astype(np.float32)); env.theta[:, 1] = env.theta[:, 0] + 0.5
+        env.gait_time[:] = torch.from_numpy(rng.uniform(0.0, 0.45, (N, 1)).astype(np.float32))
+        env.phi[:] = env.gait_time / env.gait_period
+        rec.take()
+        init = dict(episode_length_buf=env.episode_length_buf.numpy().copy(), commands=env.commands.numpy().copy(),
+                    env_origins=sim._env_origins.numpy().copy(), terrain_levels=sim._terrain_levels.numpy().copy(),
+                    terrain_types=sim._terrain_types.numpy().copy(), height_points=sim._height_points[0, :, :2].numpy().copy(),
+                    theta=env.theta.numpy().copy(), gait_time=env.gait_time.numpy().copy(), phi=env.phi.numpy().copy())
+        keys = ("actions_in", "rand", "counter", "feat_new", "priv_new", "labels", "rew", "reset", "time_out", "commands", "ep_len",
+                "fail_buf", "episode_sums", "act_hist", "sim_dof_pos", "sim_base_pos", "sim_base_quat", "terrain_levels", "env_origins",
+                "measured_heights", "height_around_feet", "normals", "dr_joint", "task_state", "last_dof_vel_in", "last_feet_vel_in", "esum_override")
+        out = {k: [] for k in keys}
+        names = env.reward_names
+        for t in range(T):
+            act = torch.from_numpy((rng.normal(size=(N, 6)) * (1.0 if t % 7 else 30.0)).astype(np.float32))
+            out["last_dof_vel_in"].append(sim._dof_vel.numpy().copy()); out["last_feet_vel_in"].append(sim._feet_vel.numpy().copy())
+            feat, labels, priv, rew, reset, extras = env.step(act)
+            calls = rec.take()
+            out["actions_in"].append(act.numpy().copy()); out["rand"].append(slots_from_calls(calls, slots, N, 6, groups))
+            out["counter"].append(env.common_step_counter); out["esum_override"].append(0.0)
+            out["feat_new"].append(feat.numpy()[:, -31:].copy()); out["priv_new"].append(priv.numpy()[:, -134:].copy())
+            out["labels"].append(labels.numpy().copy()); out["rew"].append(rew.numpy().copy())
+            out["reset"].append(reset.numpy().astype(np.uint8)); out["time_out"].append(env.time_out_buf.numpy().astype(np.uint8))
+            out["commands"].append(env.commands.numpy().copy()); out["ep_len"].append(env.episode_length_buf.numpy().copy())
+            out["fail_buf"].append(env.fail_buf.numpy().copy())
+            out["episode_sums"].append(np.stack([env.episode_sums[n].numpy().copy() for n in names]))
+            out["act_hist"].append(np.stack([env.actions.numpy(), env.last_actions.numpy(), env.llast_actions.numpy()]).copy())
+            out["sim_dof_pos"].append(sim._dof_pos.numpy().copy()); out["sim_base_pos"].append(sim._base_pos.numpy().copy())
+            out["sim_base_quat"].append(sim._base_quat.numpy().copy())
+            out["terrain_levels"].append(sim._terrain_levels.numpy().copy()); out["env_origins"].append(sim._env_origins.numpy().copy())
+            out["measured_heights"].append(sim._measured_heights.numpy().copy())
+            out["height_around_feet"].append(sim._height_around_feet.numpy().copy())
+            out["normals"].append(sim._normal_vector_around_feet.numpy().copy())
+            out["dr_joint"].append(np.concatenate([sim._joint_armature.numpy(), sim._joint_friction.numpy(), sim._joint_damping.numpy()], 1).copy())
+            out["task_state"].append(np.concatenate([env.gait_time.numpy(), env.phi.numpy(), env.theta.numpy(), env.clock_input.numpy(),
+                                                     env.exp_C_frc_left.numpy(), env.exp_C_frc_right.numpy()], 1).copy())
+        arrays = {k: np.stack(v) for k, v in out.items()}
+        arrays["feat_last"], arrays["priv_last"] = feat.numpy().copy(), priv.numpy().copy()
+        arrays.update({"script_" + k: v for k, v in sim.script.items()})
+        arrays.update({"init_" + k: v for k, v in init.items()})
+        arrays["reward_names"] = np.array(names)
+        arrays["terrain_seed"] = RoughFakeSimulator.TERRAIN_SEED
+        path = os.path.join(HERE, "tron1_pf_ee_mdp.npz")
+        np.savez_compressed(path, **arrays)
+        sit = (np.abs(arrays["sim_base_quat"][:, :, 1]) > 0.05) & arrays["reset"].astype(bool)
+        print("wrote", path, os.path.getsize(path), "resets/step", arrays["reset"].sum(1), "sit resets", int(sit.sum()),
+              "levels moved", int((arrays["terrain_levels"][-1] != init["terrain_levels"]).sum()))
+    finally:
+        torch.rand_like, torch.rand, np.random.random = orig
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["go2", "wtw", "ee"]
+    which = sys.argv[1:] or ["go2", "wtw", "ee", "tron1"]
+    if "tron1" in which:
+        gen_tron1()
     if "ee" in which:
         gen_ee()
     if "go2" in which:

@@ -101,6 +101,29 @@ class DrawRecorder:
                                u=torch.tensor([(idx + 0.5) / high], dtype=torch.float32)))
         return torch.full(tuple(size), idx, dtype=torch.long)
 
+    def tagged(self, tag, shape, env_ids):
+        """Uniform draw made by the fake simulator itself (domain randomisation), labelled with its slot name."""
+        u = self._u(shape)
+        self.calls.append(dict(caller="tag:" + tag, parent="", env_ids=env_ids.clone(), u=u.clone()))
+        return u
+
+    def torch_rand(self, *shape, **kw):
+        st = inspect.stack()
+        caller = st[1].function
+        env_ids = st[1].frame.f_locals.get("env_ids")
+        u = self._u(shape)
+        self.calls.append(dict(caller="torch_rand:" + caller, parent="", env_ids=None if env_ids is None else env_ids.clone(), u=u.clone()))
+        return u
+
+    def np_random(self):
+        st = inspect.stack()
+        env_ids = st[1].frame.f_locals.get("env_ids")
+        import torch
+        v = float(self.rng.random())
+        self.calls.append(dict(caller="np_random:" + st[1].function, parent="", env_ids=None if env_ids is None else env_ids.clone(),
+                               u=torch.tensor([v], dtype=torch.float32)))
+        return v
+
     def randint_like(self, t, high, env_ids):
         import numpy as np
         import torch

@@ -228,3 +228,100 @@ def test_ee_fixture_exercises_the_branches():
 
 def test_mdp_oracle_reproduces_reference_go2_ee():
     replay_ee(EEOracleStepper, check_ee)
+
+
+# ------------------------------- tron1_pf_ee (biped, rough terrain) -------------------------------
+GOLD_TRON1 = os.path.join(os.path.dirname(__file__), "golden", "tron1_pf_ee_mdp.npz")
+
+
+def tron1_terrain(fx):
+    from hcr_genesis_lr_cl_amd.config import TRON1PFEECfg
+    from hcr_genesis_lr_cl_amd.terrain import Terrain
+    cfg = TRON1PFEECfg()
+    np.random.seed(int(fx["terrain_seed"]))
+    return cfg, Terrain(cfg.terrain)
+
+
+class Tron1OracleStepper:
+    def __init__(self, fx, N):
+        import oracle.mdp_oracle as mo
+        self.mo = mo
+        model = load_model("tron1_pf")
+        self.cfg, self.terrain = tron1_terrain(fx)
+        task = builders.make_task_cfg(model, self.cfg)
+        o = self.o = MdpOracle(model, self.cfg, task, N, fx["init_env_origins"])
+        o.episode_length_buf[:] = fx["init_episode_length_buf"]
+        o.commands[:] = fx["init_commands"]
+        o.terrain_levels[:], o.terrain_types[:] = fx["init_terrain_levels"], fx["init_terrain_types"]
+        o.terrain_origins = self.terrain.env_origins.astype(np.float32)
+        o.theta[:], o.gait_time[:], o.phi[:] = fx["init_theta"], fx["init_gait_time"], fx["init_phi"]
+        o.friction_values[:] = 0; o.added_base_mass[:] = 1
+        self.hp = fx["init_height_points"]
+        self.names = [str(n) for n in fx["reward_names"]]
+
+    def step(self, t, sim, actions, R, counter, override):
+        o, c, mo = self.o, self.cfg.terrain, self.mo
+        hf = self.terrain.height_field_raw
+        N = len(actions)
+        sim["measured_heights"] = mo.sample_heights(sim["base_pos"], sim["base_quat"], self.hp, hf, c.border_size, c.horizontal_scale, c.vertical_scale)
+        sim["height_around_feet"], sim["normals"] = mo.feet_terrain_info(sim["feet_pos"].reshape(N, 2, 3), hf, c.border_size,
+                                                                          c.horizontal_scale, c.vertical_scale)
+        mh, har, nrm = sim["measured_heights"].copy(), sim["height_around_feet"].copy(), sim["normals"].copy()
+        o.step(sim, actions, R, counter)
+        ts = np.concatenate([o.gait_time, o.phi, o.theta, o.clock_input, o.exp_C_frc], 1)
+        return dict(feat_new=o.obs_buf[:, -31:], priv_new=o.priv_obs_buf[:, -134:], labels=o.labels_buf, rew=o.rew_buf,
+                    reset=o.reset_buf, time_out=o.time_out_buf, commands=o.commands, ep_len=o.episode_length_buf, fail_buf=o.fail_buf,
+                    episode_sums=np.stack([o.episode_sums[abi.REWARD_ID[n]] for n in self.names]),
+                    act_hist=np.stack([o.actions, o.last_actions, o.llast_actions]),
+                    sim_dof_pos=sim["dof_pos"], sim_base_pos=sim["base_pos"], sim_base_quat=sim["base_quat"],
+                    terrain_levels=o.terrain_levels, env_origins=o.env_origins, measured_heights=mh, height_around_feet=har,
+                    normals=nrm, dr_joint=np.concatenate([o.joint_armature, o.joint_friction, o.joint_damping], 1), task_state=ts,
+                    feat_full=o.obs_buf, priv_full=o.priv_obs_buf)
+
+
+T1_EXACT = ("reset", "time_out", "ep_len", "fail_buf", "terrain_levels")
+T1_FLOAT = ("measured_heights", "height_around_feet", "normals", "feat_new", "priv_new", "labels", "rew", "commands",
+            "episode_sums", "act_hist", "sim_dof_pos", "sim_base_pos", "sim_base_quat", "env_origins", "dr_joint", "task_state")
+
+
+def check_tron1(t, fx, out, rtol=2e-6, atol=2e-6, skip_env0=False):
+    sl = slice(1, None) if skip_env0 else slice(None)
+    for k in T1_EXACT:
+        np.testing.assert_array_equal(np.asarray(out[k]).astype(np.int64)[sl], fx[k][t].astype(np.int64)[sl], err_msg=f"{k} @ step {t}")
+    for k in T1_FLOAT:
+        got = np.asarray(out[k])
+        ref = fx[k][t].reshape(got.shape)
+        if k in ("episode_sums", "act_hist"):
+            got, ref = got[:, sl], ref[:, sl]
+        else:
+            got, ref = got[sl], ref[sl]
+        np.testing.assert_allclose(got, ref, rtol=rtol, atol=atol, err_msg=f"{k} @ step {t}")
+    if t == fx["rew"].shape[0] - 1:
+        np.testing.assert_allclose(out["feat_full"][sl], fx["feat_last"][sl], rtol=rtol, atol=atol, err_msg="stacked estimator features")
+        np.testing.assert_allclose(out["priv_full"][sl], fx["priv_last"][sl], rtol=rtol, atol=atol, err_msg="stacked critic obs")
+
+
+def replay_rough(gold, make_stepper, check):
+    fx = np.load(gold)
+    T, N = fx["rew"].shape
+    st = make_stepper(fx, N)
+    for t in range(T):
+        sim_in = {k[len("script_"):]: fx[k][t].copy() for k in fx.files if k.startswith("script_")}
+        sim_in["last_dof_vel"] = fx["last_dof_vel_in"][t].copy()
+        sim_in["last_feet_vel"] = fx["last_feet_vel_in"][t].copy()
+        out = st.step(t, sim_in, fx["actions_in"][t], fx["rand"][t], int(fx["counter"][t]), 0.0)
+        check(t, fx, out)
+
+
+def test_tron1_fixture_exercises_the_branches():
+    fx = np.load(GOLD_TRON1)
+    r = fx["reset"].astype(bool)
+    assert r.sum() >= 10
+    sit = (np.abs(fx["sim_base_quat"][:, :, 1]) > 0.05) & r
+    assert sit.sum() >= 2 and (r & ~sit).sum() >= 2                       # both reset branches (tron1_pf_ee.py:204-210)
+    assert (fx["reset"].astype(bool) & ~fx["time_out"].astype(bool)).sum() >= 1
+    assert fx["dr_joint"][-1][:, 0].max() > 0.11                           # armature randomised
+
+
+def test_mdp_oracle_reproduces_reference_tron1_pf_ee():
+    replay_rough(GOLD_TRON1, Tron1OracleStepper, check_tron1)
