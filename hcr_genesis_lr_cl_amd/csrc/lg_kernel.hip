@@ -225,7 +225,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     V3 f_link[4];                    // net contact force on this leg's hip, thigh, calf, foot (world)
     V3 f_base = v3(0, 0, 0);         // net contact force on the base (whole env)
     V3 foot_p, foot_v, last_foot_v = v3(0, 0, 0);
-    float foot_hmean = 0.f;          // mean of the 9 terrain heights around this lane's foot (a8)
+    float foot_hmean = 0.f, foot_hmax = 0.f;  // mean / max of the 9 terrain heights around this lane's foot (a8)
     float mean_height = 0.f;         // mean over the height-sample grid of (base_z - h) is formed from this (a7)
     const int P = O->n_height_points;
 
@@ -652,14 +652,14 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 // order of genesis_simulator.py:591-599
                 const int hh[9] = {hf[xm * C + py], hf[(px + 1) * C + py], hf[px * C + ym], hf[px * C + py + 1], hf[px * C + py],
                                    hf[xm * C + ym], hf[(px + 1) * C + py + 1], hf[xm * C + py + 1], hf[(px + 1) * C + ym]};
-                float sum = 0.f;
+                float sum = 0.f, mx = -1e30f;
 #pragma unroll
                 for (int k = 0; k < 9; k++) {
                     const float hv = (float)hh[k] * O->vscale;
-                    sum += hv;
+                    sum += hv; mx = fmaxf(mx, hv);
                     if (live) B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k] = hv;
                 }
-                foot_hmean = sum / 9.f;
+                foot_hmean = sum / 9.f; foot_hmax = mx;
                 // normal from RAW int16 differences over 2*hscale -- the reference does not apply the
                 // vertical scale here (genesis_simulator.py:601-606); reproduced
                 const float dx = (float)(hh[1] - hh[0]) / (O->hscale * 2.f), dy = (float)(hh[3] - hh[2]) / (O->hscale * 2.f);
@@ -697,10 +697,10 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             for (int k = leg; k < P; k += LEGS) acc += pos.z - B.measured_heights[(size_t)e * P + k];
             mean_height = quad_sum<LEGS>(acc) / (float)P;
             if (O->feet_terrain_info) {
-                float sum = 0.f;
+                float sum = 0.f, mx = -1e30f;
 #pragma unroll
-                for (int k = 0; k < 9; k++) sum += B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k];
-                foot_hmean = sum / 9.f;
+                for (int k = 0; k < 9; k++) { const float hv = B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k]; sum += hv; mx = fmaxf(mx, hv); }
+                foot_hmean = sum / 9.f; foot_hmax = mx;
             }
         }
     }
@@ -729,12 +729,16 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     float *esum = B.episode_sums;
 
     // ---- periodic-gait task state (go2_wtw.py:295-346): per-env scalars + this lane's foot entries
-    const bool WTW = T->gait_mode == 1;
+    const bool WTW = T->gait_mode == 1, BIPED = T->gait_mode == 2, GAIT = WTW || BIPED;
     float *ts = B.task_state ? B.task_state + (size_t)e * T->task_state_width : nullptr;
     float gait_time = 0.f, phi = 0.f, gait_period = 1.f, bh_tgt = 0.f, fc_tgt = 0.f, pitch_tgt = 0.f, theta = 0.f, expC = 0.f;
     if (WTW) {
         gait_time = ts[0]; phi = ts[1]; gait_period = ts[2]; bh_tgt = ts[3]; fc_tgt = ts[4]; pitch_tgt = ts[5];
         theta = ts[6 + foot_slot]; expC = ts[18 + foot_slot];
+    }
+    if (BIPED) {   // layout LG_TASK_STATE_BIPED (tron1_pf_ee.py:167-184)
+        gait_time = ts[0]; phi = ts[1]; gait_period = T->gait_period_fixed;
+        theta = ts[4 + foot_slot]; expC = ts[10 + foot_slot];
     }
     auto resample_behavior = [&](int slot) {   // go2_wtw.py:180-218
         gait_period = (cr[9] - cr[8]) * rs.draw(slot) + cr[8];
@@ -811,6 +815,16 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         float dq0[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) dq0[j] = q[j] - O->default_dof_pos[d0 + j];
+        auto gait_reward = [&]() {   // "step" indicator of go2_wtw.py:377-470 / tron1_pf_ee.py:347-424
+            const float two_pi = 6.283185307179586f;
+            float ph = phi + theta;
+            ph = (ph - floorf(ph)) * two_pi;                             // (phi + theta) % 1.0, operands >= 0
+            const float b_sw = T->b_swing * two_pi;
+            const float c_frc = (ph >= 0.f && ph < b_sw) ? -1.f : 0.f;
+            const float c_spd = (ph >= b_sw && ph < two_pi) ? -1.f : 0.f;
+            expC = c_frc;
+            return expf(quad_sum<LEGS>(c_spd * norm(foot_v) + c_frc * norm(f_link[3])));
+        };
         if (sc[LG_R_ACTION_RATE] != 0.f) {                              // :495-497
             float s = 0.f;
 #pragma unroll
@@ -829,6 +843,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             const float d = (P > 0 ? mean_height : pos.z) - T->base_height_target;
             add(LG_R_BASE_HEIGHT, d * d);
         }
+        if (sc[LG_R_BIPED_PERIODIC_GAIT] != 0.f) add(LG_R_BIPED_PERIODIC_GAIT, gait_reward());  // tron1_pf_ee.py:426-433
         if (sc[LG_R_COLLISION] != 0.f) {                                // :505-512
             float s = 0.f;
 #pragma unroll
@@ -898,6 +913,12 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             const float cnt = quad_sum<LEGS>(f_link[3].z > 0.1f ? 1.f : 0.f);
             add(LG_R_FEET_CONTACT_STAND_STILL, (cnt == (float)LEGS ? 1.f : 0.f) * (cmd_xyz < 0.1f ? 1.f : 0.f));
         }
+        if (sc[LG_R_FEET_DISTANCE] != 0.f) {                            // tron1_pf_ee.py:458-463 (two feet: lane pair)
+            const float ox = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(foot_p.x), 0xB1, 0xF, 0xF, false));
+            const float oy = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(foot_p.y), 0xB1, 0xF, 0xF, false));
+            const float dxy = sqrtf((foot_p.x - ox) * (foot_p.x - ox) + (foot_p.y - oy) * (foot_p.y - oy));
+            add(LG_R_FEET_DISTANCE, fmaxf(0.f, T->foot_distance_threshold - dxy));
+        }
         if (sc[LG_R_FOOT_ACC] != 0.f) {                                 // :605-608
             const V3 a = (foot_v - last_foot_v) * (1.f / cdt);
             add(LG_R_FOOT_ACC, quad_sum<LEGS>(dot(a, a)));
@@ -905,7 +926,8 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         if (sc[LG_R_FOOT_CLEARANCE] != 0.f) {                           // :575-588
             const float vxy = sqrtf(foot_v.x * foot_v.x + foot_v.y * foot_v.y);
             // go2_ee.py:136-150 measures the clearance above the mean terrain height around the foot
-            const float d = foot_p.z - (T->obs_layout == LG_OBS_GO2_EE ? foot_hmean : 0.f) - T->foot_clearance_target - T->foot_height_offset;
+            const float d = foot_p.z - (T->obs_layout == LG_OBS_GO2_EE ? foot_hmean : (T->obs_layout == LG_OBS_TRON1_EE ? foot_hmax : 0.f))
+                            - T->foot_clearance_target - T->foot_height_offset;   // tron1_pf_ee.py:442-456 uses the max
             const float err = quad_sum<LEGS>(vxy * (d * d));
             add(LG_R_FOOT_CLEARANCE, expf(-err / T->foot_clearance_sigma));
         }
@@ -919,16 +941,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         if (sc[LG_R_KEEP_BALANCE] != 0.f) add(LG_R_KEEP_BALANCE, 1.f);                      // :601-603
         if (sc[LG_R_LIN_VEL_Z] != 0.f) add(LG_R_LIN_VEL_Z, blv.z * blv.z);                  // :458-460
         if (sc[LG_R_ORIENTATION] != 0.f) add(LG_R_ORIENTATION, pg.x * pg.x + pg.y * pg.y);  // :466-468
-        if (sc[LG_R_QUAD_PERIODIC_GAIT] != 0.f) {                       // go2_wtw.py:377-484, "step" indicator
-            const float two_pi = 6.283185307179586f;
-            float ph = phi + theta;
-            ph = (ph - floorf(ph)) * two_pi;                             // (phi + theta) % 1.0, operands >= 0
-            const float b_sw = T->b_swing * two_pi;
-            const float c_frc = (ph >= 0.f && ph < b_sw) ? -1.f : 0.f;
-            const float c_spd = (ph >= b_sw && ph < two_pi) ? -1.f : 0.f;
-            expC = c_frc;
-            add(LG_R_QUAD_PERIODIC_GAIT, expf(quad_sum<LEGS>(c_spd * norm(foot_v) + c_frc * norm(f_link[3]))));
-        }
+        if (sc[LG_R_QUAD_PERIODIC_GAIT] != 0.f) add(LG_R_QUAD_PERIODIC_GAIT, gait_reward());   // go2_wtw.py:472-484
         if (sc[LG_R_TORQUES] != 0.f) {                                  // :478-480
             float s = 0.f;
 #pragma unroll
@@ -940,7 +953,8 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             add(LG_R_TRACKING_ANG_VEL, expf(-(d * d) / T->tracking_sigma));
         }
         if (sc[LG_R_TRACKING_BASE_HEIGHT] != 0.f) {                     // go2_wtw.py:495-500 (plane: heights are zero)
-            const float d = pos.z - bh_tgt;
+            // wtw: per-env target on the plane; tron1_pf_ee.py:435-440: fixed target, mean over the height samples
+            const float d = WTW ? pos.z - bh_tgt : (P > 0 ? mean_height : pos.z) - T->base_height_target;
             add(LG_R_TRACKING_BASE_HEIGHT, expf(-(d * d) / T->base_height_sigma));
         }
         if (sc[LG_R_TRACKING_FOOT_CLEARANCE] != 0.f) {                  // go2_wtw.py:507-519
@@ -958,7 +972,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         }
         if (T->only_positive_rewards) total = fmaxf(total, 0.f);        // :161-162
         if (sc[LG_R_TERMINATION] != 0.f) add(LG_R_TERMINATION, (reset && !time_out) ? 1.f : 0.f);  // :163-168
-        if (WTW) {   // gait clock (go2_wtw.py:29-36).  The reference additionally restarts env 0's clock whenever
+        if (GAIT) {  // gait clock (go2_wtw.py:29-36, tron1_pf_ee.py:28-35).  The reference additionally restarts env 0's clock whenever
                      // ANY env wraps (index-flatten bug); that grid-wide coupling is deliberately not reproduced.
             gait_time += cdt;
             if (gait_time >= gait_period - cdt / 2.f) gait_time = 0.f;
@@ -996,27 +1010,44 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             }
             if (WTW) { resample_behavior(T->slots.task_reset); gait_time = 0.f; phi = 0.f; }   // go2_wtw.py:124-142
             resample_commands(T->slots.reset_cmd);
+            // tron1_pf_ee.py:204-210: ONE coin per reset_idx call sends the whole batch to the sit pose (quirk 11)
+            bool sit = false;
+            if (T->sit_percent > 0.f) {
+                float us;
+                if (rs.in) us = rs.in[T->slots.task_reset];
+                else { RandSrc g = rs; g.e_lo = 0xFFFFFFFFu; g.e_hi = 0xFFFFFFFFu; us = g.draw(T->slots.task_reset); }
+                sit = us < T->sit_percent;
+            }
             // _reset_dofs (go2.py:17-37): default + U(range) per joint, zero velocity
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                q[j] = O->default_dof_pos[d0 + j] + (T->reset_dof_span[d0 + j] * rs.draw(T->slots.reset_dof + d0 + j) + T->reset_dof_lo[d0 + j]);
+                q[j] = sit ? T->sit_dof_pos[d0 + j]
+                           : O->default_dof_pos[d0 + j] + (T->reset_dof_span[d0 + j] * rs.draw(T->slots.reset_dof + d0 + j) + T->reset_dof_lo[d0 + j]);
                 qd[j] = 0.f;
                 last_qd[j] = 0.f;
                 act[j] = last_act[j] = llast_act[j] = 0.f;
             }
             // _reset_root_states (go2.py:119-134)
-            pos = ld3(O->base_init_pos) + (have_origin ? pos_origin_override : ld3(B.env_origins + 3 * e));
+            pos = (sit ? ld3(T->sit_pos) : ld3(O->base_init_pos)) + (have_origin ? pos_origin_override : ld3(B.env_origins + 3 * e));
             if (T->custom_origins) {
                 pos.x += T->reset_root_xy_span * rs.draw(T->slots.reset_root_xy) + T->reset_root_xy_lo;
                 pos.y += T->reset_root_xy_span * rs.draw(T->slots.reset_root_xy + 1) + T->reset_root_xy_lo;
             }
-            qx = T->base_init_quat[0]; qy = T->base_init_quat[1]; qz = T->base_init_quat[2]; qw = T->base_init_quat[3];
+            const float *iq = sit ? T->sit_quat : T->base_init_quat;
+            qx = iq[0]; qy = iq[1]; qz = iq[2]; qw = iq[3];
             vw = v3(T->reset_lin_vel_span * rs.draw(T->slots.reset_lin_vel) + T->reset_lin_vel_lo,
                     T->reset_lin_vel_span * rs.draw(T->slots.reset_lin_vel + 1) + T->reset_lin_vel_lo,
                     T->reset_lin_vel_span * rs.draw(T->slots.reset_lin_vel + 2) + T->reset_lin_vel_lo);
             ww = v3(T->reset_ang_vel_span * rs.draw(T->slots.reset_ang_vel) + T->reset_ang_vel_lo,
                     T->reset_ang_vel_span * rs.draw(T->slots.reset_ang_vel + 1) + T->reset_ang_vel_lo,
                     T->reset_ang_vel_span * rs.draw(T->slots.reset_ang_vel + 2) + T->reset_ang_vel_lo);
+            if (sit) { vw = v3(0, 0, 0); ww = v3(0, 0, 0); }        // tron1_pf_ee.py:304-309
+            if (BIPED) {                                             // tron1_pf_ee.py:220-226
+                const float th0 = T->theta_table[0][0] + rs.draw(T->slots.task_reset + 1);
+                theta = foot_slot == 0 ? th0 : th0 + (T->theta_table[0][1] - T->theta_table[0][0]);
+                gait_time = rs.draw(T->slots.task_reset + 2) * gait_period;
+                phi = gait_time / gait_period;
+            }
             // the reference stores the commanded reset twist verbatim in the body-frame properties
             // (genesis_simulator.py:128-129) and refreshes projected gravity (:125)
             blv = vw; bav = ww;
@@ -1106,6 +1137,18 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 if (lead) { rs.block3(2 * LEGS, ub[0], ub[1], ub[2]); rs.block3(2 * LEGS + 1, ub[3], ub[4], ub[5]); }
             }
         }
+        float uact[3] = {0.5f, 0.5f, 0.5f}, uclk[2] = {0.5f, 0.5f};
+        if (nz && T->noise_vec[9 + 2 * A] != 0.f) {   // tron1_pf_ee.py:338-342 (quirk 4): actions and clock are noisy too
+            if (rs.in) {
+#pragma unroll
+                for (int j = 0; j < 3; j++) uact[j] = rs.in[ns + 9 + 2 * A + d0 + j];
+                uclk[0] = rs.in[ns + 9 + 3 * A + foot_slot]; uclk[1] = rs.in[ns + 9 + 3 * A + LEGS + foot_slot];
+            } else {
+                float dummy;
+                rs.block3(2 * LEGS + 2 + leg, uact[0], uact[1], uact[2]);
+                rs.block3(3 * LEGS + 2 + leg, uclk[0], uclk[1], dummy);
+            }
+        }
         auto put = [&](int idx, float v, float u) {        // critic copy of the frame is noise-free
             if (pn) pn[idx] = clampf(v, -co, co);
             if (nz) v += (2.f * u - 1.f) * T->noise_vec[idx];
@@ -1117,7 +1160,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             for (int j = 0; j < 3; j++) {
                 put(9 + d0 + j, (q[j] - O->default_dof_pos[d0 + j]) * T->obs_scale_dof_pos, uq[j]);
                 put(9 + A + d0 + j, qd[j] * T->obs_scale_dof_vel, uqd[j]);
-                put(9 + 2 * A + d0 + j, act[j], 0.5f);
+                put(9 + 2 * A + d0 + j, act[j], uact[j]);
             }
         }
         if (lead) {
@@ -1184,11 +1227,65 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 if (M->state_link_mask & 1u) { const float cs = norm(f_base) > 1.f ? 1.f : 0.f; putp(FR + 7 + 2 * A, cs); lab[3] = cs; }
                 lab[0] = blv.x * T->obs_scale_lin_vel; lab[1] = blv.y * T->obs_scale_lin_vel; lab[2] = blv.z * T->obs_scale_lin_vel;
             }
+        } else if (T->obs_layout == LG_OBS_TRON1_EE) {
+            // tron1_pf_ee.py:53-141.  actor frame: 9 + 3A + clock 2F.  critic frame: frame | DR (7 + 2A + 3) |
+            // gait F | contact states K | heights P | normals 3F | clip(foot_z - h9) 9F.  labels: v_b 3 | K | F | 3F
+            const int K = __popc(M->state_link_mask);
+            const int l0 = foot_link - 3;
+            float *lab = B.labels_buf + (size_t)e * T->num_labels;
+            const float ang = 6.283185307179586f * (phi + theta);
+            const int oDR = FR, oG = FR + 7 + 2 * A + 3, oK = oG + F, oH = oK + K, oN = oH + P, oR = oN + 3 * F;
+            if (live) {
+                const float sn = sinf(ang), cs = cosf(ang);
+                put(9 + 3 * A + foot_slot, sn, uclk[0]);
+                put(9 + 3 * A + F + foot_slot, cs, uclk[1]);
+                ts[4 + foot_slot] = theta; ts[6 + foot_slot] = sn; ts[6 + F + foot_slot] = cs; ts[10 + foot_slot] = expC;
+#pragma unroll
+                for (int j = 0; j < 3; j++) {
+                    putp(oDR + 7 + d0 + j, B.kp_scale[e * A + d0 + j] - T->kp_offset);
+                    putp(oDR + 7 + A + d0 + j, B.kd_scale[e * A + d0 + j] - T->kd_offset);
+                }
+                putp(oG + foot_slot, expC);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int l = l0 + k;
+                    if ((M->state_link_mask >> l) & 1u) {
+                        const int idx = __popc(M->state_link_mask & ((1u << l) - 1u));
+                        const float cst = norm(f_link[k]) > 1.f ? 1.f : 0.f;
+                        putp(oK + idx, cst);
+                        lab[3 + idx] = cst;
+                    }
+                }
+                for (int k = leg; k < P; k += LEGS) {
+                    float hv = pos.z - T->heights_offset - B.measured_heights[(size_t)e * P + k];
+                    if (T->heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * T->obs_scale_height;
+                    putp(oH + k, hv);
+                }
+                const float *nv3 = B.normal_vector_around_feet + ((size_t)e * F + foot_slot) * 3;
+#pragma unroll
+                for (int k = 0; k < 3; k++) { putp(oN + 3 * foot_slot + k, nv3[k]); lab[3 + K + F + 3 * foot_slot + k] = nv3[k]; }
+#pragma unroll
+                for (int k = 0; k < 9; k++)
+                    putp(oR + 9 * foot_slot + k, clampf(foot_p.z - B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k], -1.f, 1.f));
+                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmax - T->foot_height_offset, -1.f, 1.f);
+            }
+            if (lead) {
+                putp(oDR + 0, B.friction_values[e] - T->friction_offset); putp(oDR + 1, B.added_base_mass[e]);
+                putp(oDR + 2, B.base_com_bias[3 * e]); putp(oDR + 3, B.base_com_bias[3 * e + 1]); putp(oDR + 4, B.base_com_bias[3 * e + 2]);
+                putp(oDR + 5, B.rand_push_vels[3 * e]); putp(oDR + 6, B.rand_push_vels[3 * e + 1]);
+                putp(oDR + 7 + 2 * A, B.joint_armature ? B.joint_armature[e] : 0.f);
+                putp(oDR + 8 + 2 * A, B.joint_friction ? B.joint_friction[e] : 0.f);
+                putp(oDR + 9 + 2 * A, B.joint_damping ? B.joint_damping[e] : 0.f);
+                if (M->state_link_mask & 1u) { const float cst = norm(f_base) > 1.f ? 1.f : 0.f; putp(oK, cst); lab[3] = cst; }
+                lab[0] = blv.x * T->obs_scale_lin_vel; lab[1] = blv.y * T->obs_scale_lin_vel; lab[2] = blv.z * T->obs_scale_lin_vel;
+            }
         }
     }
     if (WTW && lead) {
         ts[0] = gait_time; ts[1] = phi; ts[2] = gait_period; ts[3] = bh_tgt; ts[4] = fc_tgt; ts[5] = pitch_tgt;
     }
+    if (BIPED && lead) { ts[0] = gait_time; ts[1] = phi; ts[2] = gait_period; }
+    if (BIPED && live && !DO_RESET) { ts[4 + foot_slot] = theta; ts[10 + foot_slot] = expC; }
     if (WTW && live && !(DO_RESET && T->obs_layout == LG_OBS_GO2_WTW)) { ts[6 + foot_slot] = theta; ts[18 + foot_slot] = expC; }
     // second action-history shift of the wtw / tron1_ee tasks (go2_wtw.py:45-46): afterwards
     // last == llast == a_t, which makes action_smoothness == action_rate

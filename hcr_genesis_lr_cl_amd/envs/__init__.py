@@ -3,10 +3,12 @@ from .legged_robot import LeggedRobot
 from .go2 import GO2
 from .go2_wtw import GO2WTW
 from .go2_ee import Go2EE
-from ..config import GO2Cfg, GO2WTWCfg, GO2EECfg
+from .tron1_pf_ee import TRON1PF_EE
+from ..config import GO2Cfg, GO2WTWCfg, GO2EECfg, TRON1PFEECfg
 
 # registry names of the reference (legged_gym/envs/__init__.py:80-91); go2_ee is the "go2_rough" experiment
-TASKS = {"go2": (GO2, GO2Cfg), "go2_wtw": (GO2WTW, GO2WTWCfg), "go2_ee": (Go2EE, GO2EECfg)}
+TASKS = {"go2": (GO2, GO2Cfg), "go2_wtw": (GO2WTW, GO2WTWCfg), "go2_ee": (Go2EE, GO2EECfg),
+         "tron1_pf_ee": (TRON1PF_EE, TRON1PFEECfg)}
 
 
 def make_env(name, num_envs=None, device="cuda:0", **kw):

@@ -319,3 +319,77 @@ def test_go2_ee_env_surface_and_terrain_curriculum():
     to = torch.from_numpy(env.simulator._terrain.env_origins).float().cuda()
     assert torch.allclose(org, to[lv.long(), env.simulator.terrain_types.long()])
     assert "terrain_level" in list(extras["episode"])
+
+
+# ------------------------------- tron1_pf_ee (biped) ----------------------------------------------
+class Tron1KernelStepper:
+    def __init__(self, fx, N):
+        import torch
+        from hcr_genesis_lr_cl_amd import builders
+        from hcr_genesis_lr_cl_amd.engine import Engine
+        from hcr_genesis_lr_cl_amd.model_compiler import load_model
+        from tests.test_mdp_oracle import tron1_terrain
+        cfg, terrain = tron1_terrain(fx)
+        model = load_model("tron1_pf")
+        desc, opts, task = builders.make_model_desc(model, cfg), builders.make_sim_options(model, cfg, terrain), builders.make_task_cfg(model, cfg)
+        eng = self.eng = Engine(model, desc, opts, task, N, "cuda:0", inject_rand=True)
+        eng.set_terrain(terrain.height_field_raw, terrain.env_origins, fx["init_height_points"])
+        cr = cfg.commands.ranges
+        eng.buf["command_ranges"][:8] = torch.tensor(list(cr.lin_vel_x) + list(cr.lin_vel_y) + list(cr.ang_vel_yaw) + list(cr.heading))
+        for k in ("env_origins", "episode_length_buf", "commands", "terrain_levels", "terrain_types"):
+            put(eng, k, fx["init_" + k])
+        ts = np.zeros((N, 12), np.float32)
+        ts[:, 0:1], ts[:, 1:2], ts[:, 2], ts[:, 4:6] = fx["init_gait_time"], fx["init_phi"], 0.5, fx["init_theta"]
+        put(eng, "task_state", ts)
+        eng.buf["friction_values"].fill_(0.0); eng.buf["added_base_mass"].fill_(1.0)
+        self.names = [str(n) for n in fx["reward_names"]]
+        self.fx = fx
+
+    def step(self, t, sim, actions, R, counter, override):
+        import torch
+        from hcr_genesis_lr_cl_amd import abi
+        eng, fx = self.eng, self.fx
+        load_sim(eng, sim)
+        put(eng, "measured_heights", fx["measured_heights"][t]); put(eng, "height_around_feet", fx["height_around_feet"][t])
+        put(eng, "normal_vector_around_feet", fx["normals"][t])
+        put(eng, "rand_in", R)
+        eng.step(abi.PHASE_PRE | abi.PHASE_POST | abi.PHASE_RESET, torch.from_numpy(actions).cuda(), counter)
+        torch.cuda.synchronize()
+        es, tsb = get(eng, "episode_sums"), get(eng, "task_state")
+        return dict(feat_new=get(eng, "obs_buf")[:, -31:], priv_new=get(eng, "priv_obs_buf")[:, -134:], labels=get(eng, "labels_buf"),
+                    rew=get(eng, "rew_buf"), reset=get(eng, "reset_buf"), time_out=get(eng, "time_out_buf"), commands=get(eng, "commands"),
+                    ep_len=get(eng, "episode_length_buf"), fail_buf=get(eng, "fail_buf"),
+                    episode_sums=np.stack([es[abi.REWARD_ID[n]] for n in self.names]),
+                    act_hist=np.stack([get(eng, "actions"), get(eng, "last_actions"), get(eng, "llast_actions")]),
+                    sim_dof_pos=get(eng, "dof_pos"), sim_base_pos=get(eng, "base_pos"), sim_base_quat=get(eng, "base_quat"),
+                    terrain_levels=get(eng, "terrain_levels"), env_origins=get(eng, "env_origins"),
+                    measured_heights=fx["measured_heights"][t], height_around_feet=fx["height_around_feet"][t], normals=fx["normals"][t],
+                    dr_joint=np.concatenate([get(eng, "joint_armature"), get(eng, "joint_friction"), get(eng, "joint_damping")], 1),
+                    task_state=np.concatenate([tsb[:, 0:2], tsb[:, 4:12]], 1), feat_full=get(eng, "obs_buf"), priv_full=get(eng, "priv_obs_buf"))
+
+
+def test_kernel_reproduces_reference_tron1_pf_ee_golden_vectors():
+    """Env 0 excluded for the same reason as in the wtw test (reference index-flatten bugs on the gait clock / indicator)."""
+    from tests.test_mdp_oracle import GOLD_TRON1, replay_rough, check_tron1
+    replay_rough(GOLD_TRON1, Tron1KernelStepper, lambda t, fx, out: check_tron1(t, fx, out, rtol=1e-5, atol=5e-5, skip_env0=True))
+
+
+def test_tron1_env_runs_physics_and_mdp():
+    import torch
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    np.random.seed(3)
+    env, cfg = make_env("tron1_pf_ee", 512)
+    f, l, p = env.reset()
+    assert f.shape == (512, 310) and l.shape == (512, 17) and p.shape == (512, 1340)
+    g = torch.Generator(device="cuda"); g.manual_seed(6)
+    nres = 0
+    for t in range(200):
+        f, l, p, rew, done, extras = env.step(torch.randn(512, 6, generator=g, device="cuda") * 0.5)
+        nres += int(done.sum())
+    assert torch.isfinite(f).all() and torch.isfinite(p).all() and torch.isfinite(rew).all() and torch.isfinite(l).all()
+    s = env.simulator
+    assert s.link_contact_forces.shape == (512, 9, 3) and s.feet_pos.shape == (512, 2, 3) and s.dof_pos.shape == (512, 6)
+    assert float(s.dr_joint_armature.min()) >= 0.11 - 1e-6 and float(s.dr_joint_armature.max()) <= 0.13 + 1e-6
+    assert nres > 0 and float(s.base_pos[:, 2].max()) < 3.0
+    # sit-pose resets happen (pitched base, tron1_pf_ee.py:277-310)
+    assert float(env.theta.max()) <= 1.5 + 1e-6
