@@ -72,7 +72,7 @@ class HostState:
         b = abi.LgBuffers()
         b.n_envs = self.n
         for k, v in self.arr.items():
-            setattr(b, k, v.ctypes.data)
+            setattr(b, k, v.ctypes.data)    # optional per-env joint parameters ride along when present
         return b
 
     def copy(self):
