@@ -21,7 +21,6 @@ NUM_REWARDS = 40
 CMD_RANGE_FLOATS = 24
 TASK_STATE_WTW = 22
 TASK_STATE_BIPED = 12
-DONE_RING = 64
 
 PHASE_PRE, PHASE_SIM, PHASE_POST, PHASE_RESET, PHASE_ALL = 1, 2, 4, 8, 15
 
@@ -131,7 +130,7 @@ _BUF_FIELDS = [
         "feet_air_time", "last_contacts", "episode_length_buf", "fail_buf",
         "reset_buf", "time_out_buf",
         "rew_buf", "obs_buf", "priv_obs_buf", "labels_buf", "obs_hist", "priv_hist",
-        "episode_sums", "episode_done_sums", "command_ranges", "task_state", "rand_in")],
+        "episode_sums", "episode_done_sums", "episode_done_step", "command_ranges", "task_state", "rand_in")],
 ]
 
 
@@ -185,7 +184,8 @@ class HipExtensionMissing(RuntimeError):
 
 
 def lib_path():
-    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
+    # LG_LIB lets a developer point at an experimental build of the same ABI (still a HIP library, never a fallback)
+    return os.environ.get("LG_LIB") or os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc", LIB_NAME)
 
 
 def load_lib():

@@ -29,17 +29,250 @@
 #define LG_ABI_VERSION 1
 #define BLOCK 64
 
+// ---- hot constants: every scalar of LgTaskCfg / LgSimOptions the kernel reads, packed contiguously so that ONE burst of
+//      s_load_dwordx16 at kernel start fetches them (scattered `T->x` reads each cost an exposed scalar-cache round trip
+//      inside the dependency chain of a lone wave).  Internal to this file, filled on the host by fill_hot().
+struct LgHot {
+    int32_t obs_layout;
+    int32_t num_obs;
+    int32_t num_priv_obs;
+    int32_t obs_frame;
+    int32_t priv_frame;
+    int32_t obs_stack;
+    int32_t priv_stack;
+    float control_dt;
+    float clip_actions;
+    float clip_obs;
+    float max_episode_length;
+    float fail_threshold;
+    float max_projected_gravity;
+    int32_t resample_steps;
+    int32_t push_interval;
+    float max_push_vel_xy;
+    int32_t heading_command;
+    int32_t only_positive_rewards;
+    float tracking_sigma;
+    float base_height_target;
+    float foot_clearance_target;
+    float foot_height_offset;
+    float foot_clearance_sigma;
+    float about_landing_threshold;
+    float feet_air_time_threshold;
+    float base_height_sigma;
+    float euler_sigma;
+    float foot_distance_threshold;
+    float obs_scale_lin_vel;
+    float obs_scale_ang_vel;
+    float obs_scale_dof_pos;
+    float obs_scale_dof_vel;
+    float obs_scale_height;
+    int32_t add_noise;
+    float reset_root_xy_lo;
+    float reset_root_xy_span;
+    int32_t custom_origins;
+    float reset_lin_vel_lo;
+    float reset_lin_vel_span;
+    float reset_ang_vel_lo;
+    float reset_ang_vel_span;
+    int32_t dr_friction_on;
+    int32_t dr_mass_on;
+    int32_t dr_com_on;
+    int32_t dr_pd_on;
+    int32_t dr_joint_on;
+    float dr_friction_lo;
+    float dr_friction_span;
+    float dr_mass_lo;
+    float dr_mass_span;
+    float dr_kp_lo;
+    float dr_kp_span;
+    float dr_kd_lo;
+    float dr_kd_span;
+    float friction_offset;
+    float kp_offset;
+    float kd_offset;
+    int32_t terrain_curriculum;
+    int32_t max_terrain_level;
+    int32_t terrain_cols_n;
+    int32_t num_labels;
+    float heights_offset;
+    int32_t heights_clip_scale;
+    float terrain_env_length;
+    float episode_length_s;
+    int32_t gait_mode;
+    int32_t double_shift;
+    int32_t behavior_resample_steps;
+    int32_t num_gait_max;
+    float b_swing;
+    float gait_period_fixed;
+    float sit_percent;
+    int32_t task_state_width;
+    float yaw_clip[2];
+    float base_init_quat[4];
+    float dr_com_lo[3];
+    float dr_com_span[3];
+    float dr_joint_lo[3];
+    float dr_joint_span[3];
+    float noise_lead[6];   // noise_vec[3..8]: gravity + angular velocity entries written by the lead lane
+    float noise_act0;      // noise_vec[9 + 2A]: non-zero only for the tron1 layout
+    LgRandSlots slots;
+    unsigned long long seed; long long env_id_offset;
+    float o_dt;
+    int32_t o_decimation;
+    float o_gravity_z;
+    float o_contact_k;
+    float o_contact_b;
+    float o_terrain_friction;
+    float o_limit_k;
+    float o_limit_b;
+    int32_t o_contact_iters;
+    float o_contact_margin;
+    float o_limit_margin;
+    float o_max_base_lin_vel;
+    float o_max_base_ang_vel;
+    float o_joint_vel_clamp;
+    float o_action_scale;
+    int32_t o_terrain_rows;
+    int32_t o_terrain_cols;
+    float o_hscale;
+    float o_vscale;
+    float o_border;
+    int32_t o_n_height_points;
+    int32_t o_feet_terrain_info;
+    float o_base_init_pos[3];
+    float o_bound_x[2];
+    float o_bound_y[2];
+};
+static void fill_hot(LgHot &H, const LgTaskCfg &t, const LgSimOptions &o, int n_dof) {
+    memset(&H, 0, sizeof(H));
+    H.obs_layout = t.obs_layout;
+    H.num_obs = t.num_obs;
+    H.num_priv_obs = t.num_priv_obs;
+    H.obs_frame = t.obs_frame;
+    H.priv_frame = t.priv_frame;
+    H.obs_stack = t.obs_stack;
+    H.priv_stack = t.priv_stack;
+    H.control_dt = t.control_dt;
+    H.clip_actions = t.clip_actions;
+    H.clip_obs = t.clip_obs;
+    H.max_episode_length = t.max_episode_length;
+    H.fail_threshold = t.fail_threshold;
+    H.max_projected_gravity = t.max_projected_gravity;
+    H.resample_steps = t.resample_steps;
+    H.push_interval = t.push_interval;
+    H.max_push_vel_xy = t.max_push_vel_xy;
+    H.heading_command = t.heading_command;
+    H.only_positive_rewards = t.only_positive_rewards;
+    H.tracking_sigma = t.tracking_sigma;
+    H.base_height_target = t.base_height_target;
+    H.foot_clearance_target = t.foot_clearance_target;
+    H.foot_height_offset = t.foot_height_offset;
+    H.foot_clearance_sigma = t.foot_clearance_sigma;
+    H.about_landing_threshold = t.about_landing_threshold;
+    H.feet_air_time_threshold = t.feet_air_time_threshold;
+    H.base_height_sigma = t.base_height_sigma;
+    H.euler_sigma = t.euler_sigma;
+    H.foot_distance_threshold = t.foot_distance_threshold;
+    H.obs_scale_lin_vel = t.obs_scale_lin_vel;
+    H.obs_scale_ang_vel = t.obs_scale_ang_vel;
+    H.obs_scale_dof_pos = t.obs_scale_dof_pos;
+    H.obs_scale_dof_vel = t.obs_scale_dof_vel;
+    H.obs_scale_height = t.obs_scale_height;
+    H.add_noise = t.add_noise;
+    H.reset_root_xy_lo = t.reset_root_xy_lo;
+    H.reset_root_xy_span = t.reset_root_xy_span;
+    H.custom_origins = t.custom_origins;
+    H.reset_lin_vel_lo = t.reset_lin_vel_lo;
+    H.reset_lin_vel_span = t.reset_lin_vel_span;
+    H.reset_ang_vel_lo = t.reset_ang_vel_lo;
+    H.reset_ang_vel_span = t.reset_ang_vel_span;
+    H.dr_friction_on = t.dr_friction_on;
+    H.dr_mass_on = t.dr_mass_on;
+    H.dr_com_on = t.dr_com_on;
+    H.dr_pd_on = t.dr_pd_on;
+    H.dr_joint_on = t.dr_joint_on;
+    H.dr_friction_lo = t.dr_friction_lo;
+    H.dr_friction_span = t.dr_friction_span;
+    H.dr_mass_lo = t.dr_mass_lo;
+    H.dr_mass_span = t.dr_mass_span;
+    H.dr_kp_lo = t.dr_kp_lo;
+    H.dr_kp_span = t.dr_kp_span;
+    H.dr_kd_lo = t.dr_kd_lo;
+    H.dr_kd_span = t.dr_kd_span;
+    H.friction_offset = t.friction_offset;
+    H.kp_offset = t.kp_offset;
+    H.kd_offset = t.kd_offset;
+    H.terrain_curriculum = t.terrain_curriculum;
+    H.max_terrain_level = t.max_terrain_level;
+    H.terrain_cols_n = t.terrain_cols_n;
+    H.num_labels = t.num_labels;
+    H.heights_offset = t.heights_offset;
+    H.heights_clip_scale = t.heights_clip_scale;
+    H.terrain_env_length = t.terrain_env_length;
+    H.episode_length_s = t.episode_length_s;
+    H.gait_mode = t.gait_mode;
+    H.double_shift = t.double_shift;
+    H.behavior_resample_steps = t.behavior_resample_steps;
+    H.num_gait_max = t.num_gait_max;
+    H.b_swing = t.b_swing;
+    H.gait_period_fixed = t.gait_period_fixed;
+    H.sit_percent = t.sit_percent;
+    H.task_state_width = t.task_state_width;
+    for (int i = 0; i < 2; i++) H.yaw_clip[i] = t.yaw_clip[i];
+    for (int i = 0; i < 4; i++) H.base_init_quat[i] = t.base_init_quat[i];
+    for (int i = 0; i < 3; i++) H.dr_com_lo[i] = t.dr_com_lo[i];
+    for (int i = 0; i < 3; i++) H.dr_com_span[i] = t.dr_com_span[i];
+    for (int i = 0; i < 3; i++) H.dr_joint_lo[i] = t.dr_joint_lo[i];
+    for (int i = 0; i < 3; i++) H.dr_joint_span[i] = t.dr_joint_span[i];
+    for (int i = 0; i < 6; i++) H.noise_lead[i] = t.noise_vec[3 + i];
+    H.noise_act0 = t.noise_vec[9 + 2 * n_dof];
+    H.slots = t.slots; H.seed = t.seed; H.env_id_offset = t.env_id_offset;
+    H.o_dt = o.dt;
+    H.o_decimation = o.decimation;
+    H.o_gravity_z = o.gravity_z;
+    H.o_contact_k = o.contact_k;
+    H.o_contact_b = o.contact_b;
+    H.o_terrain_friction = o.terrain_friction;
+    H.o_limit_k = o.limit_k;
+    H.o_limit_b = o.limit_b;
+    H.o_contact_iters = o.contact_iters;
+    H.o_contact_margin = o.contact_margin;
+    H.o_limit_margin = o.limit_margin;
+    H.o_max_base_lin_vel = o.max_base_lin_vel;
+    H.o_max_base_ang_vel = o.max_base_ang_vel;
+    H.o_joint_vel_clamp = o.joint_vel_clamp;
+    H.o_action_scale = o.action_scale;
+    H.o_terrain_rows = o.terrain_rows;
+    H.o_terrain_cols = o.terrain_cols;
+    H.o_hscale = o.hscale;
+    H.o_vscale = o.vscale;
+    H.o_border = o.border;
+    H.o_n_height_points = o.n_height_points;
+    H.o_feet_terrain_info = o.feet_terrain_info;
+    for (int i = 0; i < 3; i++) H.o_base_init_pos[i] = o.base_init_pos[i];
+    for (int i = 0; i < 2; i++) H.o_bound_x[i] = o.bound_x[i];
+    for (int i = 0; i < 2; i++) H.o_bound_y[i] = o.bound_y[i];
+}
+
 struct KParams {
     const LgModelDesc *M;
     const LgSimOptions *O;
     const LgTaskCfg *T;
+    const LgHot *H;
     const int16_t *hf;
     LgBuffers B;
     const float *actions;
     long long counter;
+    int jrot_identity;   // every joint frame is axis-aligned with its parent at q = 0 (host-checked)
 };
 
-template <int LEGS> struct LegCtx;
+#ifdef LG_DBG_STAMPS
+// diagnostic build only: shader-clock stamps of workgroup 0 / lane 0 into episode_done_sums[0..15]
+#define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long _t; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); \
+    p.B.episode_done_sums[i] = (float)(_t - _stamp0); if (i == 0) _stamp0 = _t; } } while (0)
+#else
+#define STAMP(i) do { } while (0)
+#endif
 
 LG_DEV V3 ld3(const float *p) { return v3(p[0], p[1], p[2]); }
 LG_DEV void st3(float *p, V3 v) { p[0] = v.x; p[1] = v.y; p[2] = v.z; }
@@ -126,11 +359,25 @@ struct RandSrc {
     const float *in;  // injected row or nullptr
     unsigned k0, k1, e_lo, e_hi, step;
     LG_DEV float draw(int slot) const {
+#ifdef LG_DBG_NO_DRAWS
+        return 0.5f;
+#endif
         if (in) return in[slot];
         U4 c = {e_lo, e_hi, step, (unsigned)(slot >> 2)};
         U4 r = philox4x32_10(c, k0, k1);
         unsigned v = (slot & 3) == 0 ? r.x : ((slot & 3) == 1 ? r.y : ((slot & 3) == 2 ? r.z : r.w));
         return u01(v);
+    }
+    // three consecutive slots from ONE Philox call (integer multiplies are quarter-rate: a call is ~800 cycles);
+    // injected mode still reads the slots one by one
+    LG_DEV void draw3(int slot, float &a, float &b, float &c) const {
+#ifdef LG_DBG_NO_DRAWS
+        a = b = c = 0.5f; return;
+#endif
+        if (in) { a = in[slot]; b = in[slot + 1]; c = in[slot + 2]; return; }
+        U4 ctr = {e_lo, e_hi, step, 0x40000000u + (unsigned)slot};
+        U4 r = philox4x32_10(ctr, k0, k1);
+        a = u01(r.x); b = u01(r.y); c = u01(r.z);
     }
     // a whole Philox block (4 uniforms) from a counter space disjoint from the slot space; used
     // where a lane needs several draws per step (observation noise)
@@ -158,16 +405,25 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     constexpr int A = LEGS * 3;
     // model table -> LDS once per workgroup: per-lane (leg-indexed) reads then cost an LDS access
     // instead of an L2 round trip with a single wave per SIMD to hide it
-    __shared__ LgModelDesc sM;
+    unsigned long long _stamp0 = 0; (void)_stamp0;
+    STAMP(0);
+    constexpr int MODEL_V4 = (int)((sizeof(LgModelDesc) + 15) / 16);        // device copy is padded to 16 B
+    __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_V4];
     {
-        const uint32_t *src = reinterpret_cast<const uint32_t *>(p.M);
-        uint32_t *dst = reinterpret_cast<uint32_t *>(&sM);
-        for (int i = threadIdx.x; i < (int)(sizeof(LgModelDesc) / 4); i += BLOCK) dst[i] = src[i];
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.M);
+        constexpr int PER = (MODEL_V4 + BLOCK - 1) / BLOCK;
+        uint4 tmp[PER];
+#pragma unroll
+        for (int k = 0; k < PER; k++) { const int i = threadIdx.x + k * BLOCK; if (i < MODEL_V4) tmp[k] = src[i]; }   // all loads in flight
+#pragma unroll
+        for (int k = 0; k < PER; k++) { const int i = threadIdx.x + k * BLOCK; if (i < MODEL_V4) sMraw[i] = tmp[k]; }
     }
     __syncthreads();
-    const LgModelDesc *M = &sM;
+    STAMP(1);
+    const LgModelDesc *M = reinterpret_cast<const LgModelDesc *>(sMraw);
     const LgSimOptions *__restrict__ O = p.O;
     const LgTaskCfg *__restrict__ T = p.T;
+    const LgHot H = *p.H;   // by value: SGPRs / lane-spilled VGPRs for the whole launch
     const LgBuffers &B = p.B;
 
     const int tid = blockIdx.x * BLOCK + threadIdx.x;
@@ -187,19 +443,14 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     // ---------------- PRE: clip + action history (legged_robot.py:230-239) -----------------
     float act[3], last_act[3], llast_act[3];
     if (DO_PRE) {
-        const float ca = T->clip_actions;
+        const float ca = H.clip_actions;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             float prev = B.actions[e * A + d0 + j], prev2 = B.last_actions[e * A + d0 + j];
             act[j] = clampf(p.actions[e * A + d0 + j], -ca, ca);
             last_act[j] = prev;
             llast_act[j] = prev2;
-            if (live) {
-                B.llast_actions[e * A + d0 + j] = prev2;
-                B.last_actions[e * A + d0 + j] = prev;
-                B.actions[e * A + d0 + j] = act[j];
-            }
-        }
+        }   // the three history stores are issued after every start-of-kernel load (see "prologue stores" below)
     } else if (DO_SIM && !DO_POST) {  // Simulator.step(actions): actions come pre-clipped from the env
 #pragma unroll
         for (int j = 0; j < 3; j++) { act[j] = p.actions[e * A + d0 + j]; last_act[j] = llast_act[j] = 0.f; }
@@ -219,6 +470,66 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
 #pragma unroll
     for (int j = 0; j < 3; j++) { q[j] = B.dof_pos[e * A + d0 + j]; qd[j] = B.dof_vel[e * A + d0 + j]; }
 
+    // ---- MDP working set, fetched NOW so that the round trips overlap the physics below instead of being
+    //      exposed one by one behind it (a lone wave per SIMD has nothing else to switch to) -----------------
+    constexpr bool DO_MDP = DO_POST || DO_RESET;
+    const int N = B.n_envs;
+    float q0l[3], soft_lo[3] = {0.f, 0.f, 0.f}, soft_hi[3] = {0.f, 0.f, 0.f}, rdof_lo[3] = {0.f, 0.f, 0.f}, rdof_span[3] = {0.f, 0.f, 0.f};
+    float nv_q[3] = {0.f, 0.f, 0.f}, nv_qd[3] = {0.f, 0.f, 0.f}, nv_act[3] = {0.f, 0.f, 0.f}, nv_clk[2] = {0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < 3; j++) q0l[j] = O->default_dof_pos[d0 + j];
+    float cmd0 = 0.f, cmd1 = 0.f, cmd2 = 0.f, cmd3 = 0.f, air = 0.f;
+    int ep_len = 0, last_contact = 0;
+    long long fail_buf = 0;
+    float es[LG_R_COUNT];
+#pragma unroll
+    for (int k = 0; k < LG_R_COUNT; k++) es[k] = 0.f;
+    float cr[17];
+#pragma unroll
+    for (int k = 0; k < 17; k++) cr[k] = 0.f;
+    V3 origin_pre = v3(0, 0, 0);
+    // physics-side start-of-kernel loads: snapshot sources and per-env dynamics parameters
+    V3 snap_fv = v3(0, 0, 0), snap_blv = v3(0, 0, 0), snap_bav = v3(0, 0, 0), dr_com = v3(0, 0, 0), dr_joint = v3(0, 0, 0);
+    float dr_mass = 0.f, dr_fric = 1.f, dr_kp[3] = {1.f, 1.f, 1.f}, dr_kd[3] = {1.f, 1.f, 1.f}, gain_p[3] = {0.f, 0.f, 0.f}, gain_d[3] = {0.f, 0.f, 0.f};
+    if (DO_SIM) {
+        snap_fv = ld3(B.feet_vel + (e * F + foot_slot) * 3);
+        snap_blv = ld3(B.base_lin_vel + 3 * e); snap_bav = ld3(B.base_ang_vel + 3 * e);
+        if (B.added_base_mass) dr_mass = B.added_base_mass[e];
+        if (B.base_com_bias) dr_com = ld3(B.base_com_bias + 3 * e);
+        if (B.friction_values) dr_fric = B.friction_values[e];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            if (B.kp_scale) dr_kp[j] = B.kp_scale[e * A + d0 + j];
+            if (B.kd_scale) dr_kd[j] = B.kd_scale[e * A + d0 + j];
+            gain_p[j] = O->kp[d0 + j]; gain_d[j] = O->kd[d0 + j];
+        }
+        if (B.joint_armature) dr_joint = v3(B.joint_armature[e], B.joint_friction[e], B.joint_damping[e]);
+    }
+    float scl[LG_R_COUNT];          // reward scales: one batch of scalar loads instead of one exposed s_load per `if`
+#pragma unroll
+    for (int k = 0; k < LG_R_COUNT; k++) scl[k] = DO_MDP ? T->reward_scales[k] : 0.f;
+    if (DO_MDP) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            soft_lo[j] = T->soft_dof_lo[d0 + j]; soft_hi[j] = T->soft_dof_hi[d0 + j];
+            rdof_lo[j] = T->reset_dof_lo[d0 + j]; rdof_span[j] = T->reset_dof_span[d0 + j];
+            nv_q[j] = T->noise_vec[9 + d0 + j]; nv_qd[j] = T->noise_vec[9 + A + d0 + j]; nv_act[j] = T->noise_vec[9 + 2 * A + d0 + j];
+        }
+        if (H.obs_layout == LG_OBS_TRON1_EE) { nv_clk[0] = T->noise_vec[9 + 3 * A + foot_slot]; nv_clk[1] = T->noise_vec[9 + 3 * A + LEGS + foot_slot]; }
+        cmd0 = B.commands[4 * e]; cmd1 = B.commands[4 * e + 1]; cmd2 = B.commands[4 * e + 2]; cmd3 = B.commands[4 * e + 3];
+        ep_len = B.episode_length_buf[e];
+        fail_buf = B.fail_buf[e];
+        air = B.feet_air_time[e * F + foot_slot];
+        last_contact = B.last_contacts[e * F + foot_slot];
+        origin_pre = ld3(B.env_origins + 3 * e);
+#pragma unroll
+        for (int k = 0; k < 17; k++) cr[k] = B.command_ranges[k];
+        if (lead) {
+#pragma unroll
+            for (int k = 0; k < LG_R_COUNT; k++) es[k] = scl[k] != 0.f ? B.episode_sums[(size_t)k * N + e] : 0.f;
+        }
+    }
+
     // read-back quantities handed from SIM to POST/RESET (registers when fused, HBM otherwise)
     V3 blv, bav, pg, eul;            // body-frame lin/ang vel, projected gravity, euler
     float last_qd[3], torque[3];
@@ -227,52 +538,114 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     V3 foot_p, foot_v, last_foot_v = v3(0, 0, 0);
     float foot_hmean = 0.f, foot_hmax = 0.f;  // mean / max of the 9 terrain heights around this lane's foot (a8)
     float mean_height = 0.f;         // mean over the height-sample grid of (base_z - h) is formed from this (a7)
-    const int P = O->n_height_points;
+    const int P = H.o_n_height_points;
 
+    // compiler-level memory barrier: every load above is issued before anything below (LLVM otherwise sinks each one
+    // next to its consumer, where its full round trip is exposed); no hardware wait is emitted here
+    asm volatile("" ::: "memory");
+    STAMP(2);
+    // ---- prologue stores: only now, after every start-of-kernel load has been issued and awaited.  vmcnt counts
+    //      loads and stores together in issue order, so a load queued behind stores waits for the full HBM write
+    //      round trip of each; issued here the stores drain under the physics instead.
+    if (DO_PRE && live) {
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            B.llast_actions[e * A + d0 + j] = llast_act[j];
+            B.last_actions[e * A + d0 + j] = last_act[j];
+            B.actions[e * A + d0 + j] = act[j];
+        }
+    }
     if (DO_SIM) {
         // "last" snapshots (genesis_simulator.py:21-24)
 #pragma unroll
         for (int j = 0; j < 3; j++) last_qd[j] = qd[j];
+        last_foot_v = snap_fv;
         if (live) {
 #pragma unroll
             for (int j = 0; j < 3; j++) B.last_dof_vel[e * A + d0 + j] = qd[j];
-            last_foot_v = ld3(B.feet_vel + (e * F + foot_slot) * 3);
-            st3(B.last_feet_vel + (e * F + foot_slot) * 3, last_foot_v);
+            st3(B.last_feet_vel + (e * F + foot_slot) * 3, snap_fv);
             if (lead) {
-                st3(B.last_base_lin_vel + 3 * e, ld3(B.base_lin_vel + 3 * e));
-                st3(B.last_base_ang_vel + 3 * e, ld3(B.base_ang_vel + 3 * e));
+                st3(B.last_base_lin_vel + 3 * e, snap_blv);
+                st3(B.last_base_ang_vel + 3 * e, snap_bav);
             }
         }
-        // per-env dynamics parameters (genesis_simulator.py:665-739)
-        const float mass0 = M->mass[0] + (B.added_base_mass ? B.added_base_mass[e] : 0.f);
-        V3 com0 = ld3(M->com[0]);
-        if (B.base_com_bias) com0 += ld3(B.base_com_bias + 3 * e);
-        const float mu = O->terrain_friction * (B.friction_values ? B.friction_values[e] : 1.f);
+        // per-env dynamics parameters (genesis_simulator.py:665-739), fetched in the prologue batch
+        const float mass0 = M->mass[0] + dr_mass;
+        V3 com0 = ld3(M->com[0]) + dr_com;
+        const float mu = H.o_terrain_friction * dr_fric;
         float kps[3], kds[3], arm[3], jdamp[3], jfric[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            kps[j] = (B.kp_scale ? B.kp_scale[e * A + d0 + j] : 1.f) * O->kp[d0 + j];
-            kds[j] = (B.kd_scale ? B.kd_scale[e * A + d0 + j] : 1.f) * O->kd[d0 + j];
-            arm[j] = B.joint_armature ? B.joint_armature[e] : M->armature[d0 + j];
-            jdamp[j] = B.joint_damping ? B.joint_damping[e] : M->damping[d0 + j];
-            jfric[j] = B.joint_friction ? B.joint_friction[e] : M->frictionloss[d0 + j];
+            kps[j] = dr_kp[j] * gain_p[j];
+            kds[j] = dr_kd[j] * gain_d[j];
+            arm[j] = B.joint_armature ? dr_joint.x : M->armature[d0 + j];
+            jfric[j] = B.joint_friction ? dr_joint.y : M->frictionloss[d0 + j];
+            jdamp[j] = B.joint_damping ? dr_joint.z : M->damping[d0 + j];
         }
-        const float dt = O->dt, kc = O->contact_k, kappa = kc * dt + O->contact_b, margin = O->contact_margin;
-        const float kl = O->limit_k, kapl = kl * dt + O->limit_b;
-        const V3 grav = v3(0.f, 0.f, O->gravity_z);
+        const float dt = H.o_dt, kc = H.o_contact_k, kappa = kc * dt + H.o_contact_b, margin = H.o_contact_margin;
+        const float kl = H.o_limit_k, kapl = kl * dt + H.o_limit_b;
+        const V3 grav = v3(0.f, 0.f, H.o_gravity_z);
         const S3 I0 = {M->inertia[0][0], M->inertia[0][1], M->inertia[0][2], M->inertia[0][3], M->inertia[0][4], M->inertia[0][5]};
         const int fs = M->foot_sphere[leg];
         const V3 foot_c_loc = ld3(M->sph_pos[fs]);
         const float foot_r = M->sph_r[fs];
 
-        bool jrot_identity = true;
-        for (int b = 1; b < M->n_bodies; b++)
-            jrot_identity = jrot_identity && M->jrot[b][0] == 1.f && M->jrot[b][4] == 1.f && M->jrot[b][8] == 1.f;
+        // ---- this lane's model constants and collision spheres, read from the LDS table ONCE per launch and kept
+        //      in registers across the four sub-steps (a single wave per SIMD cannot hide ~100-cycle LDS round
+        //      trips issued from inside the dependency chain: they were 40 % of the wave's cycles)
+        float Lm[3], Lqlo[3], Lqhi[3], Leff[3], Lvlim[3];
+        V3 Lcom[3], Ljpos[3], Lax[3];
+        S3 LIc[3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const int b = b0 + j;
+            Lm[j] = M->mass[b]; Lcom[j] = ld3(M->com[b]); Ljpos[j] = ld3(M->jpos[b]); Lax[j] = ld3(M->axis[b]);
+            const S3 t = {M->inertia[b][0], M->inertia[b][1], M->inertia[b][2], M->inertia[b][3], M->inertia[b][4], M->inertia[b][5]};
+            LIc[j] = t;
+            Lqlo[j] = M->q_lo[d0 + j]; Lqhi[j] = M->q_hi[d0 + j]; Leff[j] = M->effort[d0 + j];
+            Lvlim[j] = H.o_joint_vel_clamp * M->vel_limit[d0 + j];
+        }
+        // spheres: up to SPH0/SPH1/SPH2 on the three chain bodies (foot sphere excluded) and SPHB of the base
+        // spheres dealt round-robin to the lanes of the env; counts are validated by lg_create
+        constexpr int SPH0 = 2, SPH1 = 2, SPH2 = 5, SPHB = 4;
+        struct Sph { V3 p; float r, w; };
+        Sph S0[SPH0], S1[SPH1], S2[SPH2], SB[SPHB];
+        int n0 = 0, n1 = 0, n2 = 0, nB = 0;
+        {
+            auto ld = [&](int s) { Sph t = {ld3(M->sph_pos[s]), M->sph_r[s], M->sph_w[s]}; return t; };
+            const int a0 = M->body_sph_start[b0], a1 = M->body_sph_start[b0 + 1], a2 = M->body_sph_start[b0 + 2], a3 = M->body_sph_start[b0 + 3];
+            n0 = a1 - a0; n1 = a2 - a1;
+#pragma unroll
+            for (int k = 0; k < SPH0; k++) S0[k] = ld(min(a0 + k, a1 - 1 >= a0 ? a1 - 1 : a0));
+#pragma unroll
+            for (int k = 0; k < SPH1; k++) S1[k] = ld(min(a1 + k, a2 - 1 >= a1 ? a2 - 1 : a1));
+            int cnt = 0;
+#pragma unroll
+            for (int k = 0; k < SPH2 + 1; k++) {       // skip the foot sphere (solved implicitly in stage 2)
+                const int s = a2 + k;
+                if (s < a3 && s != fs && cnt < SPH2) {
+                    const Sph t = ld(s);
+#pragma unroll
+                    for (int q2 = 0; q2 < SPH2; q2++) if (q2 == cnt) S2[q2] = t;
+                    cnt++;
+                }
+            }
+            n2 = cnt;
+            const int e0 = M->body_sph_start[0], e1 = M->body_sph_start[1];
+#pragma unroll
+            for (int k = 0; k < SPHB; k++) {
+                const int s = e0 + leg + LEGS * k;
+                SB[k] = ld(min(s, e1 - 1));
+                if (s < e1) nB = k + 1;
+            }
+        }
 
-        for (int sub = 0; sub < O->decimation; sub++) {
+        STAMP(3);
+        const bool jrot_identity = p.jrot_identity != 0;
+
+        for (int sub = 0; sub < H.o_decimation; sub++) {
             const M3 Rb = quat_to_mat(qx, qy, qz, qw);
             // ---- forward kinematics + velocities of the chain (root -> leaf) -----------------
-            asm volatile("" ::: "memory");  // keep model-table loads inside the sub-step (register pressure)
             BodyKin K[3];
             Joint J[3];
 #pragma unroll
@@ -287,7 +660,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     const int b = b0 + j;
-                    const V3 jp = ld3(M->jpos[b]), ax = ld3(M->axis[b]);
+                    const V3 jp = Ljpos[j], ax = Lax[j];
                     K[j].P = Pp + mul(Rp, jp);
                     M3 Rfix = Rp;
                     if (!jrot_identity) {
@@ -309,15 +682,15 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             }
             // ---- body (non-foot) collision spheres: penalty made implicit with the conservative
             //      point inverse mass sph_w; lane handles its chain + every LEGS-th base sphere
-            auto sphere_contact = [&](int s, const M3 &R, V3 P, const V6 &V, V3 &fsum, V6 &pacc) {
-                const V3 r = P + mul(R, ld3(M->sph_pos[s]));
-                const float rad = M->sph_r[s];
+            auto sphere_contact = [&](const Sph &sp, const M3 &R, V3 P, const V6 &V, V3 &fsum, V6 &pacc) {
+                const V3 r = P + mul(R, sp.p);
+                const float rad = sp.r;
                 float h; V3 n;
                 terrain_at(O, p.hf, pos.x + r.x, pos.y + r.y, h, n);
                 const float depth = rad - (pos.z + r.z - h) * n.z;
                 if (depth > -margin) {
                     const V3 v = V.l + cross(V.a, r);
-                    const float vn = dot(v, n), wi = M->sph_w[s];
+                    const float vn = dot(v, n), wi = sp.w;
                     const float fn = (kc * depth - kappa * vn) * rcp(1.f + kappa * dt * wi);
                     if (fn > 0.f) {
                         const V3 vt = v - n * vn;
@@ -333,16 +706,17 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 }
             };
             const V6 V0 = {ww, vw};
-            for (int s = M->body_sph_start[0] + leg; s < M->body_sph_start[1]; s += LEGS)
-                sphere_contact(s, Rb, v3(0, 0, 0), V0, fb_acc, pbase_ext);
+#pragma unroll
+            for (int k = 0; k < SPHB; k++)
+                if (k < nB) sphere_contact(SB[k], Rb, v3(0, 0, 0), V0, fb_acc, pbase_ext);
 
             // ---- actuation (genesis_simulator.py:630-642): PD, torque reported unclipped ----
             float tau[3];
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                const float t = kps[j] * (act[j] * O->action_scale + O->default_dof_pos[d0 + j] - q[j]) - kds[j] * qd[j];
+                const float t = kps[j] * (act[j] * H.o_action_scale + q0l[j] - q[j]) - kds[j] * qd[j];
                 torque[j] = t;
-                const float lim = M->effort[d0 + j];
+                const float lim = Leff[j];
                 tau[j] = clampf(t, -lim, lim) - jdamp[j] * qd[j] - jfric[j] * clampf(qd[j] * 20.f, -1.f, 1.f);
             }
             // ---- ABA pass 2 up the chain (leaf -> root): rigid inertia + bias force of each body
@@ -351,12 +725,10 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             V6 pacc;
 #pragma unroll
             for (int j = 2; j >= 0; j--) {
-                const int b = b0 + j;
                 {
-                    const float m = M->mass[b];
-                    const V3 cw = K[j].P + mul(K[j].R, ld3(M->com[b]));
-                    const S3 Ic = {M->inertia[b][0], M->inertia[b][1], M->inertia[b][2], M->inertia[b][3], M->inertia[b][4], M->inertia[b][5]};
-                    const S3 Icw = rot_sym(K[j].R, Ic);
+                    const float m = Lm[j];
+                    const V3 cw = K[j].P + mul(K[j].R, Lcom[j]);
+                    const S3 Icw = rot_sym(K[j].R, LIc[j]);
                     // bias force: V x* (I V) - gravity - contacts
                     const V3 vc = K[j].V.l + cross(K[j].V.a, cw);
                     const V3 Pm = vc * m;
@@ -366,9 +738,15 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                     pb.a = cross(K[j].V.a, Lm) + cross(K[j].V.l, Pm) - cross(cw, fg);
                     pb.l = cross(K[j].V.a, Pm) - fg;
                     V6 ext = {v3(0, 0, 0), v3(0, 0, 0)};
-                    for (int s = M->body_sph_start[b]; s < M->body_sph_start[b + 1]; s++) {
-                        if (s == fs) continue;   // the foot sphere is solved implicitly in stage 2
-                        sphere_contact(s, K[j].R, K[j].P, K[j].V, f_link[j], ext);
+                    if (j == 0) {
+#pragma unroll
+                        for (int k = 0; k < SPH0; k++) if (k < n0) sphere_contact(S0[k], K[j].R, K[j].P, K[j].V, f_link[j], ext);
+                    } else if (j == 1) {
+#pragma unroll
+                        for (int k = 0; k < SPH1; k++) if (k < n1) sphere_contact(S1[k], K[j].R, K[j].P, K[j].V, f_link[j], ext);
+                    } else {
+#pragma unroll
+                        for (int k = 0; k < SPH2; k++) if (k < n2) sphere_contact(S2[k], K[j].R, K[j].P, K[j].V, f_link[j], ext);
                     }
                     pb = pb - ext;
                     const S3 Ab = Icw + parallel_axis(m, cw);
@@ -441,10 +819,10 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             bool lact = false;
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                const float lo = M->q_lo[d0 + j], hi = M->q_hi[d0 + j];
+                const float lo = Lqlo[j], hi = Lqhi[j];
                 lim_s[j] = 0.f; lim_e[j] = 0.f;
-                if (q[j] < lo + O->limit_margin) { lim_s[j] = 1.f; lim_e[j] = lo - q[j]; lact = true; }
-                else if (q[j] > hi - O->limit_margin) { lim_s[j] = -1.f; lim_e[j] = q[j] - hi; lact = true; }
+                if (q[j] < lo + H.o_limit_margin) { lim_s[j] = 1.f; lim_e[j] = lo - q[j]; lact = true; }
+                else if (q[j] > hi - H.o_limit_margin) { lim_s[j] = -1.f; lim_e[j] = q[j] - hi; lact = true; }
             }
             const int any = quad_or<LEGS>((fact || lact) ? 1 : 0);
             float dqdd[3] = {0.f, 0.f, 0.f};
@@ -480,7 +858,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                     vfree = v3(dot(cn, vf), dot(ct1, vf), dot(ct2, vf));
                 }
                 V3 resp_c = v3(0, 0, 0);  // contact-frame acceleration response to the current force set
-                for (int it = 0; it < O->contact_iters; it++) {
+                for (int it = 0; it < H.o_contact_iters; it++) {
                     // foot: velocity it would have without its own force, then the local law
                     V3 fnew = v3(0, 0, 0);
                     if (fact) {
@@ -526,12 +904,12 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             {
                 const V3 alpha = a0.a + da0.a;
                 const V3 alin = a0.l + da0.l + cross(ww, vw);   // spatial -> classical at O
-                const float mv = O->max_base_lin_vel, mw = O->max_base_ang_vel;
+                const float mv = H.o_max_base_lin_vel, mw = H.o_max_base_ang_vel;
                 vw = v3(clampf(vw.x + dt * alin.x, -mv, mv), clampf(vw.y + dt * alin.y, -mv, mv), clampf(vw.z + dt * alin.z, -mv, mv));
                 ww = v3(clampf(ww.x + dt * alpha.x, -mw, mw), clampf(ww.y + dt * alpha.y, -mw, mw), clampf(ww.z + dt * alpha.z, -mw, mw));
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
-                    const float vl = O->joint_vel_clamp * M->vel_limit[d0 + j];
+                    const float vl = Lvlim[j];
                     qd[j] = clampf(qd[j] + dt * (qdd[j] + dqdd[j]), -vl, vl);
                     q[j] += dt * qd[j];
                 }
@@ -551,6 +929,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             f_base = quad_sum<LEGS>(fb_acc);
         }  // sub-steps
 
+        STAMP(4);
         // ---- read-back (genesis_simulator.py:35-60) ----------------------------------------------
         {   // non-finite guard: re-seat the robot (see oracle for the rationale)
             float chk = pos.x + pos.y + pos.z + qx + qy + qz + qw + vw.x + vw.y + vw.z + ww.x + ww.y + ww.z;
@@ -558,18 +937,18 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             for (int j = 0; j < 3; j++) chk += q[j] + qd[j];
             const int bad = quad_or<LEGS>(isfinite(chk) ? 0 : 1);
             if (bad) {
-                pos = ld3(O->base_init_pos);
+                pos = v3(H.o_base_init_pos[0], H.o_base_init_pos[1], H.o_base_init_pos[2]);
                 if (B.env_origins) pos += ld3(B.env_origins + 3 * e);
                 vw = ww = v3(0, 0, 0);
                 qx = qy = qz = 0.f; qw = 1.f;
 #pragma unroll
-                for (int j = 0; j < 3; j++) { q[j] = O->default_dof_pos[d0 + j]; qd[j] = 0.f; torque[j] = 0.f; f_link[j] = v3(0, 0, 0); }
+                for (int j = 0; j < 3; j++) { q[j] = q0l[j]; qd[j] = 0.f; torque[j] = 0.f; f_link[j] = v3(0, 0, 0); }
                 f_link[3] = v3(0, 0, 0); f_base = v3(0, 0, 0);
             }
         }
         // out-of-terrain teleport (genesis_simulator.py:612-628)
-        if (pos.x >= O->bound_x[1] || pos.x <= O->bound_x[0] || pos.y >= O->bound_y[1] || pos.y <= O->bound_y[0]) {
-            pos = ld3(O->base_init_pos);
+        if (pos.x >= H.o_bound_x[1] || pos.x <= H.o_bound_x[0] || pos.y >= H.o_bound_y[1] || pos.y <= H.o_bound_y[0]) {
+            pos = v3(H.o_base_init_pos[0], H.o_base_init_pos[1], H.o_base_init_pos[2]);
             if (B.env_origins) pos += ld3(B.env_origins + 3 * e);
         }
         eul.x = atan2f(2.f * (qw * qx + qy * qz), qw * qw - qx * qx - qy * qy + qz * qz);
@@ -643,11 +1022,11 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 if (live) B.measured_heights[(size_t)e * P + k] = h;
             }
             mean_height = quad_sum<LEGS>(acc) / (float)P;
-            if (O->feet_terrain_info) {
-                int px = (int)((foot_p.x + O->border) / O->hscale), py = (int)((foot_p.y + O->border) / O->hscale);
-                px = min(max(px, 0), O->terrain_rows - 2);
-                py = min(max(py, 0), O->terrain_cols - 2);
-                const int C = O->terrain_cols, xm = max(px - 1, 0), ym = max(py - 1, 0);
+            if (H.o_feet_terrain_info) {
+                int px = (int)((foot_p.x + H.o_border) / H.o_hscale), py = (int)((foot_p.y + H.o_border) / H.o_hscale);
+                px = min(max(px, 0), H.o_terrain_rows - 2);
+                py = min(max(py, 0), H.o_terrain_cols - 2);
+                const int C = H.o_terrain_cols, xm = max(px - 1, 0), ym = max(py - 1, 0);
                 const int16_t *hf = p.hf;
                 // order of genesis_simulator.py:591-599
                 const int hh[9] = {hf[xm * C + py], hf[(px + 1) * C + py], hf[px * C + ym], hf[px * C + py + 1], hf[px * C + py],
@@ -655,14 +1034,14 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 float sum = 0.f, mx = -1e30f;
 #pragma unroll
                 for (int k = 0; k < 9; k++) {
-                    const float hv = (float)hh[k] * O->vscale;
+                    const float hv = (float)hh[k] * H.o_vscale;
                     sum += hv; mx = fmaxf(mx, hv);
                     if (live) B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k] = hv;
                 }
                 foot_hmean = sum / 9.f; foot_hmax = mx;
                 // normal from RAW int16 differences over 2*hscale -- the reference does not apply the
                 // vertical scale here (genesis_simulator.py:601-606); reproduced
-                const float dx = (float)(hh[1] - hh[0]) / (O->hscale * 2.f), dy = (float)(hh[3] - hh[2]) / (O->hscale * 2.f);
+                const float dx = (float)(hh[1] - hh[0]) / (H.o_hscale * 2.f), dy = (float)(hh[3] - hh[2]) / (H.o_hscale * 2.f);
                 const float nn = sqrtf(dx * dx + dy * dy + 1.f);
                 if (live) st3(B.normal_vector_around_feet + ((size_t)e * F + foot_slot) * 3, v3(dx / nn, dy / nn, -1.f / nn));
             }
@@ -696,7 +1075,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             float acc = 0.f;
             for (int k = leg; k < P; k += LEGS) acc += pos.z - B.measured_heights[(size_t)e * P + k];
             mean_height = quad_sum<LEGS>(acc) / (float)P;
-            if (O->feet_terrain_info) {
+            if (H.o_feet_terrain_info) {
                 float sum = 0.f, mx = -1e30f;
 #pragma unroll
                 for (int k = 0; k < 9; k++) { const float hv = B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k]; sum += hv; mx = fmaxf(mx, hv); }
@@ -705,39 +1084,33 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         }
     }
 
+    STAMP(5);
     if (!DO_POST && !DO_RESET) return;
 
     // ======================= MDP: legged_robot.py:55-168, 300-334 ============================
     RandSrc rs;
-    rs.in = B.rand_in ? B.rand_in + (size_t)e * T->slots.n_slots : nullptr;
+    rs.in = B.rand_in ? B.rand_in + (size_t)e * H.slots.n_slots : nullptr;
     {
-        const unsigned long long gid = (unsigned long long)(T->env_id_offset + e);
-        rs.k0 = (unsigned)(T->seed & 0xFFFFFFFFu); rs.k1 = (unsigned)(T->seed >> 32);
+        const unsigned long long gid = (unsigned long long)(H.env_id_offset + e);
+        rs.k0 = (unsigned)(H.seed & 0xFFFFFFFFu); rs.k1 = (unsigned)(H.seed >> 32);
         rs.e_lo = (unsigned)(gid & 0xFFFFFFFFu); rs.e_hi = (unsigned)(gid >> 32);
         rs.step = (unsigned)p.counter;
     }
-    const int N = B.n_envs;
-    const float cdt = T->control_dt;
-    float cmd0 = B.commands[4 * e], cmd1 = B.commands[4 * e + 1], cmd2 = B.commands[4 * e + 2], cmd3 = B.commands[4 * e + 3];
-    int ep_len = B.episode_length_buf[e];
-    long long fail_buf = B.fail_buf[e];
+    const float cdt = H.control_dt;
     bool reset = false, time_out = false;
-    float air = B.feet_air_time[e * F + foot_slot];
-    int last_contact = B.last_contacts[e * F + foot_slot];
     float total = 0.f;
-    const float *cr = B.command_ranges;
     float *esum = B.episode_sums;
 
     // ---- periodic-gait task state (go2_wtw.py:295-346): per-env scalars + this lane's foot entries
-    const bool WTW = T->gait_mode == 1, BIPED = T->gait_mode == 2, GAIT = WTW || BIPED;
-    float *ts = B.task_state ? B.task_state + (size_t)e * T->task_state_width : nullptr;
+    const bool WTW = H.gait_mode == 1, BIPED = H.gait_mode == 2, GAIT = WTW || BIPED;
+    float *ts = B.task_state ? B.task_state + (size_t)e * H.task_state_width : nullptr;
     float gait_time = 0.f, phi = 0.f, gait_period = 1.f, bh_tgt = 0.f, fc_tgt = 0.f, pitch_tgt = 0.f, theta = 0.f, expC = 0.f;
     if (WTW) {
         gait_time = ts[0]; phi = ts[1]; gait_period = ts[2]; bh_tgt = ts[3]; fc_tgt = ts[4]; pitch_tgt = ts[5];
         theta = ts[6 + foot_slot]; expC = ts[18 + foot_slot];
     }
     if (BIPED) {   // layout LG_TASK_STATE_BIPED (tron1_pf_ee.py:167-184)
-        gait_time = ts[0]; phi = ts[1]; gait_period = T->gait_period_fixed;
+        gait_time = ts[0]; phi = ts[1]; gait_period = H.gait_period_fixed;
         theta = ts[4 + foot_slot]; expC = ts[10 + foot_slot];
     }
     auto resample_behavior = [&](int slot) {   // go2_wtw.py:180-218
@@ -759,10 +1132,12 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     };
 
     auto resample_commands = [&](int slot) {  // legged_robot.py:317-334
-        cmd0 = (cr[1] - cr[0]) * rs.draw(slot) + cr[0];
-        cmd1 = (cr[3] - cr[2]) * rs.draw(slot + 1) + cr[2];
-        if (T->heading_command) cmd3 = (cr[7] - cr[6]) * rs.draw(slot + 2) + cr[6];
-        else cmd2 = (cr[5] - cr[4]) * rs.draw(slot + 2) + cr[4];
+        float u0, u1, u2;
+        rs.draw3(slot, u0, u1, u2);
+        cmd0 = (cr[1] - cr[0]) * u0 + cr[0];
+        cmd1 = (cr[3] - cr[2]) * u1 + cr[2];
+        if (H.heading_command) cmd3 = (cr[7] - cr[6]) * u2 + cr[6];
+        else cmd2 = (cr[5] - cr[4]) * u2 + cr[4];
         const float keep = sqrtf(cmd0 * cmd0 + cmd1 * cmd1 + cmd2 * cmd2) > 0.2f ? 1.f : 0.f;
         cmd0 *= keep; cmd1 *= keep; cmd2 *= keep;
     };
@@ -770,26 +1145,30 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     if (DO_POST) {
         ep_len += 1;                                                   // legged_robot.py:60
         // ---- _post_physics_step_callback (legged_robot.py:300-315) ----
-        if (ep_len % T->resample_steps == 0) resample_commands(T->slots.cb_cmd);
-        if (T->heading_command) {
+        if (ep_len % H.resample_steps == 0) resample_commands(H.slots.cb_cmd);
+        if (H.heading_command) {
             // forward = quat_apply(base_quat, [1,0,0]) (math_utils.py:34-40)
             const V3 xyz = v3(qx, qy, qz), bvec = v3(1.f, 0.f, 0.f);
             const V3 t = cross(xyz, bvec) * 2.f;
             const V3 fwd = bvec + t * qw + cross(xyz, t);
             const float heading = atan2f(fwd.y, fwd.x);
-            cmd2 = clampf(0.5f * wrap_to_pi(cmd3 - heading), T->yaw_clip[0], T->yaw_clip[1]);
+            cmd2 = clampf(0.5f * wrap_to_pi(cmd3 - heading), H.yaw_clip[0], H.yaw_clip[1]);
         }
-        if (T->push_interval > 0 && (p.counter % T->push_interval) == 0) {   // genesis_simulator.py:150-158
-            const float m = T->max_push_vel_xy;
-            const float px = (m + m) * rs.draw(T->slots.push) - m, py = (m + m) * rs.draw(T->slots.push + 1) - m;
+        if (H.push_interval > 0 && (p.counter % H.push_interval) == 0) {   // genesis_simulator.py:150-158
+            const float m = H.max_push_vel_xy;
+            const float px = (m + m) * rs.draw(H.slots.push) - m, py = (m + m) * rs.draw(H.slots.push + 1) - m;
             vw.x += px; vw.y += py;
             if (lead) {
                 B.rand_push_vels[3 * e] = px; B.rand_push_vels[3 * e + 1] = py;
                 B.base_lin_vel_w[3 * e] = vw.x; B.base_lin_vel_w[3 * e + 1] = vw.y;
             }
         }
-        if (WTW && T->behavior_resample_steps > 0 && ep_len % T->behavior_resample_steps == 0)   // go2_wtw.py:258-263
-            resample_behavior(T->slots.task_cb);
+        if (WTW && H.behavior_resample_steps > 0 && ep_len % H.behavior_resample_steps == 0)   // go2_wtw.py:258-263
+            resample_behavior(H.slots.task_cb);
+#ifdef LG_DBG_RET_CALLBACK
+        if (p.counter >= 0) { if (lead) B.rew_buf[e] = cmd2 + (float)ep_len; return; }
+#endif
+        STAMP(6);
         // ---- check_termination (legged_robot.py:78-92) ----
         const int l0 = foot_link - 3;
         int fail = 0;
@@ -798,28 +1177,31 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             if ((M->term_link_mask >> (l0 + k)) & 1u) fail |= norm(f_link[k]) > 10.0f ? 1 : 0;
         fail = quad_or<LEGS>(fail);
         if (M->term_link_mask & 1u) fail |= norm(f_base) > 10.0f ? 1 : 0;
-        fail |= pg.z > T->max_projected_gravity ? 1 : 0;
+        fail |= pg.z > H.max_projected_gravity ? 1 : 0;
         fail_buf += fail;
-        time_out = (float)ep_len > T->max_episode_length;
-        reset = ((float)fail_buf > T->fail_threshold) || time_out;
+        time_out = (float)ep_len > H.max_episode_length;
+        reset = ((float)fail_buf > H.fail_threshold) || time_out;
 
+#ifdef LG_DBG_RET_TERM
+        if (p.counter >= 0) { if (lead) B.rew_buf[e] = cmd2 + (float)fail_buf + (reset ? 1.f : 0.f); return; }
+#endif
         // ---- compute_reward (legged_robot.py:150-168), alphabetical order ----
-        const float *sc = T->reward_scales;
+        const float (&sc)[LG_R_COUNT] = scl;
         auto add = [&](int id, float r) {
             const float rew = r * sc[id];
             total += rew;
-            if (lead) esum[(size_t)id * N + e] += rew;
+            es[id] += rew;
         };
         const float cmd_xy = sqrtf(cmd0 * cmd0 + cmd1 * cmd1);
         const float cmd_xyz = sqrtf(cmd0 * cmd0 + cmd1 * cmd1 + cmd2 * cmd2);
         float dq0[3];
 #pragma unroll
-        for (int j = 0; j < 3; j++) dq0[j] = q[j] - O->default_dof_pos[d0 + j];
+        for (int j = 0; j < 3; j++) dq0[j] = q[j] - q0l[j];
         auto gait_reward = [&]() {   // "step" indicator of go2_wtw.py:377-470 / tron1_pf_ee.py:347-424
             const float two_pi = 6.283185307179586f;
             float ph = phi + theta;
             ph = (ph - floorf(ph)) * two_pi;                             // (phi + theta) % 1.0, operands >= 0
-            const float b_sw = T->b_swing * two_pi;
+            const float b_sw = H.b_swing * two_pi;
             const float c_frc = (ph >= 0.f && ph < b_sw) ? -1.f : 0.f;
             const float c_spd = (ph >= b_sw && ph < two_pi) ? -1.f : 0.f;
             expC = c_frc;
@@ -840,7 +1222,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         if (sc[LG_R_ANG_VEL_XY] != 0.f) add(LG_R_ANG_VEL_XY, bav.x * bav.x + bav.y * bav.y);   // :462-464
         if (sc[LG_R_BASE_HEIGHT] != 0.f) {                              // :470-476
             // plane: measured_heights is the all-zero buffer of genesis_simulator.py:494 -> base z
-            const float d = (P > 0 ? mean_height : pos.z) - T->base_height_target;
+            const float d = (P > 0 ? mean_height : pos.z) - H.base_height_target;
             add(LG_R_BASE_HEIGHT, d * d);
         }
         if (sc[LG_R_BIPED_PERIODIC_GAIT] != 0.f) add(LG_R_BIPED_PERIODIC_GAIT, gait_reward());  // tron1_pf_ee.py:426-433
@@ -869,8 +1251,8 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                s += -fminf(q[j] - T->soft_dof_lo[d0 + j], 0.f);
-                s += fmaxf(q[j] - T->soft_dof_hi[d0 + j], 0.f);
+                s += -fminf(q[j] - soft_lo[j], 0.f);
+                s += fmaxf(q[j] - soft_hi[j], 0.f);
             }
             add(LG_R_DOF_POS_LIMITS, quad_sum<LEGS>(s));
         }
@@ -904,7 +1286,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             last_contact = contact;
             const float first = (air > 0.f ? 1.f : 0.f) * (float)filt;
             air += cdt;
-            float r = quad_sum<LEGS>((air - T->feet_air_time_threshold) * first);
+            float r = quad_sum<LEGS>((air - H.feet_air_time_threshold) * first);
             r *= cmd_xy > 0.1f ? 1.f : 0.f;
             air *= filt ? 0.f : 1.f;
             add(LG_R_FEET_AIR_TIME, r);
@@ -917,7 +1299,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             const float ox = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(foot_p.x), 0xB1, 0xF, 0xF, false));
             const float oy = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(foot_p.y), 0xB1, 0xF, 0xF, false));
             const float dxy = sqrtf((foot_p.x - ox) * (foot_p.x - ox) + (foot_p.y - oy) * (foot_p.y - oy));
-            add(LG_R_FEET_DISTANCE, fmaxf(0.f, T->foot_distance_threshold - dxy));
+            add(LG_R_FEET_DISTANCE, fmaxf(0.f, H.foot_distance_threshold - dxy));
         }
         if (sc[LG_R_FOOT_ACC] != 0.f) {                                 // :605-608
             const V3 a = (foot_v - last_foot_v) * (1.f / cdt);
@@ -926,14 +1308,14 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         if (sc[LG_R_FOOT_CLEARANCE] != 0.f) {                           // :575-588
             const float vxy = sqrtf(foot_v.x * foot_v.x + foot_v.y * foot_v.y);
             // go2_ee.py:136-150 measures the clearance above the mean terrain height around the foot
-            const float d = foot_p.z - (T->obs_layout == LG_OBS_GO2_EE ? foot_hmean : (T->obs_layout == LG_OBS_TRON1_EE ? foot_hmax : 0.f))
-                            - T->foot_clearance_target - T->foot_height_offset;   // tron1_pf_ee.py:442-456 uses the max
+            const float d = foot_p.z - (H.obs_layout == LG_OBS_GO2_EE ? foot_hmean : (H.obs_layout == LG_OBS_TRON1_EE ? foot_hmax : 0.f))
+                            - H.foot_clearance_target - H.foot_height_offset;   // tron1_pf_ee.py:442-456 uses the max
             const float err = quad_sum<LEGS>(vxy * (d * d));
-            add(LG_R_FOOT_CLEARANCE, expf(-err / T->foot_clearance_sigma));
+            add(LG_R_FOOT_CLEARANCE, expf(-err / H.foot_clearance_sigma));
         }
         if (sc[LG_R_FOOT_LANDING_VEL] != 0.f) {                         // :590-599
             const bool c01 = f_link[3].z > 0.1f;
-            const bool land = ((foot_p.z - T->foot_height_offset) < T->about_landing_threshold) && !c01 && (foot_v.z < 0.f);
+            const bool land = ((foot_p.z - H.foot_height_offset) < H.about_landing_threshold) && !c01 && (foot_v.z < 0.f);
             const float vz = land ? foot_v.z : 0.f;
             add(LG_R_FOOT_LANDING_VEL, quad_sum<LEGS>(vz * vz));
         }
@@ -950,27 +1332,31 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         }
         if (sc[LG_R_TRACKING_ANG_VEL] != 0.f) {                         // :539-543
             const float d = cmd2 - bav.z;
-            add(LG_R_TRACKING_ANG_VEL, expf(-(d * d) / T->tracking_sigma));
+            add(LG_R_TRACKING_ANG_VEL, expf(-(d * d) / H.tracking_sigma));
         }
         if (sc[LG_R_TRACKING_BASE_HEIGHT] != 0.f) {                     // go2_wtw.py:495-500 (plane: heights are zero)
             // wtw: per-env target on the plane; tron1_pf_ee.py:435-440: fixed target, mean over the height samples
-            const float d = WTW ? pos.z - bh_tgt : (P > 0 ? mean_height : pos.z) - T->base_height_target;
-            add(LG_R_TRACKING_BASE_HEIGHT, expf(-(d * d) / T->base_height_sigma));
+            const float d = WTW ? pos.z - bh_tgt : (P > 0 ? mean_height : pos.z) - H.base_height_target;
+            add(LG_R_TRACKING_BASE_HEIGHT, expf(-(d * d) / H.base_height_sigma));
         }
         if (sc[LG_R_TRACKING_FOOT_CLEARANCE] != 0.f) {                  // go2_wtw.py:507-519
             const float vxy = sqrtf(foot_v.x * foot_v.x + foot_v.y * foot_v.y);
-            const float d = foot_p.z - fc_tgt - T->foot_height_offset;
-            add(LG_R_TRACKING_FOOT_CLEARANCE, expf(-quad_sum<LEGS>(vxy * (d * d)) / T->foot_clearance_sigma));
+            const float d = foot_p.z - fc_tgt - H.foot_height_offset;
+            add(LG_R_TRACKING_FOOT_CLEARANCE, expf(-quad_sum<LEGS>(vxy * (d * d)) / H.foot_clearance_sigma));
         }
         if (sc[LG_R_TRACKING_LIN_VEL] != 0.f) {                         // :533-537
             const float dx = cmd0 - blv.x, dy = cmd1 - blv.y;
-            add(LG_R_TRACKING_LIN_VEL, expf(-(dx * dx + dy * dy) / T->tracking_sigma));
+            add(LG_R_TRACKING_LIN_VEL, expf(-(dx * dx + dy * dy) / H.tracking_sigma));
         }
         if (sc[LG_R_TRACKING_ORIENTATION] != 0.f) {                     // go2_wtw.py:502-505
             const float dp = eul.y - pitch_tgt;
-            add(LG_R_TRACKING_ORIENTATION, expf(-(eul.x * eul.x + dp * dp) / T->euler_sigma));
+            add(LG_R_TRACKING_ORIENTATION, expf(-(eul.x * eul.x + dp * dp) / H.euler_sigma));
         }
-        if (T->only_positive_rewards) total = fmaxf(total, 0.f);        // :161-162
+#ifdef LG_DBG_RET_REW
+        if (p.counter >= 0) { if (lead) B.rew_buf[e] = total + es[0] + es[5] + es[28]; return; }
+#endif
+        STAMP(7);
+        if (H.only_positive_rewards) total = fmaxf(total, 0.f);        // :161-162
         if (sc[LG_R_TERMINATION] != 0.f) add(LG_R_TERMINATION, (reset && !time_out) ? 1.f : 0.f);  // :163-168
         if (GAIT) {  // gait clock (go2_wtw.py:29-36, tron1_pf_ee.py:28-35).  The reference additionally restarts env 0's clock whenever
                      // ANY env wraps (index-flatten bug); that grid-wide coupling is deliberately not reproduced.
@@ -984,68 +1370,73 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         total = B.rew_buf[e];
     }
 
+    STAMP(8);
     // ---- reset_idx (legged_robot.py:94-148) + simulator.reset_idx (genesis_simulator.py:62-82) ----
     if (DO_RESET) {
         V3 pos_origin_override = v3(0, 0, 0);
         bool have_origin = false;
-        if (lead && e == 0) {  // clear the per-step reset accumulator the NEXT launch will use
-            float *nxt = B.episode_done_sums + ((p.counter + 1) % LG_DONE_RING) * (LG_R_COUNT + 2);
-            for (int k = 0; k < LG_R_COUNT + 2; k++) nxt[k] = 0.f;
-        }
         if (reset) {
-            if (T->terrain_curriculum && p.counter > 0) {
+            if (H.terrain_curriculum && p.counter > 0) {
                 // legged_robot.py:254-272 + genesis_simulator.py:140-148 (skipped on the construction-time reset,
                 // where the reference returns early because init_done is False)
-                const V3 org = ld3(B.env_origins + 3 * e);
+                const V3 org = origin_pre;
                 const float dx = pos.x - org.x, dy = pos.y - org.y;
                 const float dist = sqrtf(dx * dx + dy * dy);
-                const bool up = dist > T->terrain_env_length / 2.f;
-                const bool down = (dist < sqrtf(cmd0 * cmd0 + cmd1 * cmd1) * T->episode_length_s * 0.5f) && !up;
+                const bool up = dist > H.terrain_env_length / 2.f;
+                const bool down = (dist < sqrtf(cmd0 * cmd0 + cmd1 * cmd1) * H.episode_length_s * 0.5f) && !up;
                 int lvl = B.terrain_levels[e] + (up ? 1 : 0) - (down ? 1 : 0);
-                if (lvl >= T->max_terrain_level) lvl = min((int)floorf(rs.draw(T->slots.terrain_level) * (float)T->max_terrain_level), T->max_terrain_level - 1);
+                if (lvl >= H.max_terrain_level) lvl = min((int)floorf(rs.draw(H.slots.terrain_level) * (float)H.max_terrain_level), H.max_terrain_level - 1);
                 else lvl = max(lvl, 0);
-                const V3 norg = ld3(B.terrain_origins + ((size_t)lvl * T->terrain_cols_n + B.terrain_types[e]) * 3);
+                const V3 norg = ld3(B.terrain_origins + ((size_t)lvl * H.terrain_cols_n + B.terrain_types[e]) * 3);
                 if (lead) { B.terrain_levels[e] = lvl; st3(B.env_origins + 3 * e, norg); }
                 pos_origin_override = norg; have_origin = true;
             }
-            if (WTW) { resample_behavior(T->slots.task_reset); gait_time = 0.f; phi = 0.f; }   // go2_wtw.py:124-142
-            resample_commands(T->slots.reset_cmd);
+            if (WTW) { resample_behavior(H.slots.task_reset); gait_time = 0.f; phi = 0.f; }   // go2_wtw.py:124-142
+            resample_commands(H.slots.reset_cmd);
             // tron1_pf_ee.py:204-210: ONE coin per reset_idx call sends the whole batch to the sit pose (quirk 11)
             bool sit = false;
-            if (T->sit_percent > 0.f) {
+            if (H.sit_percent > 0.f) {
                 float us;
-                if (rs.in) us = rs.in[T->slots.task_reset];
-                else { RandSrc g = rs; g.e_lo = 0xFFFFFFFFu; g.e_hi = 0xFFFFFFFFu; us = g.draw(T->slots.task_reset); }
-                sit = us < T->sit_percent;
+                if (rs.in) us = rs.in[H.slots.task_reset];
+                else { RandSrc g = rs; g.e_lo = 0xFFFFFFFFu; g.e_hi = 0xFFFFFFFFu; us = g.draw(H.slots.task_reset); }
+                sit = us < H.sit_percent;
             }
             // _reset_dofs (go2.py:17-37): default + U(range) per joint, zero velocity
+            float ud[3];
+            rs.draw3(H.slots.reset_dof + d0, ud[0], ud[1], ud[2]);
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 q[j] = sit ? T->sit_dof_pos[d0 + j]
-                           : O->default_dof_pos[d0 + j] + (T->reset_dof_span[d0 + j] * rs.draw(T->slots.reset_dof + d0 + j) + T->reset_dof_lo[d0 + j]);
+                           : q0l[j] + (rdof_span[j] * ud[j] + rdof_lo[j]);
                 qd[j] = 0.f;
                 last_qd[j] = 0.f;
                 act[j] = last_act[j] = llast_act[j] = 0.f;
             }
             // _reset_root_states (go2.py:119-134)
-            pos = (sit ? ld3(T->sit_pos) : ld3(O->base_init_pos)) + (have_origin ? pos_origin_override : ld3(B.env_origins + 3 * e));
-            if (T->custom_origins) {
-                pos.x += T->reset_root_xy_span * rs.draw(T->slots.reset_root_xy) + T->reset_root_xy_lo;
-                pos.y += T->reset_root_xy_span * rs.draw(T->slots.reset_root_xy + 1) + T->reset_root_xy_lo;
+            pos = (sit ? ld3(T->sit_pos) : v3(H.o_base_init_pos[0], H.o_base_init_pos[1], H.o_base_init_pos[2])) + (have_origin ? pos_origin_override : origin_pre);
+            if (H.custom_origins) {
+                pos.x += H.reset_root_xy_span * rs.draw(H.slots.reset_root_xy) + H.reset_root_xy_lo;
+                pos.y += H.reset_root_xy_span * rs.draw(H.slots.reset_root_xy + 1) + H.reset_root_xy_lo;
             }
-            const float *iq = sit ? T->sit_quat : T->base_init_quat;
-            qx = iq[0]; qy = iq[1]; qz = iq[2]; qw = iq[3];
-            vw = v3(T->reset_lin_vel_span * rs.draw(T->slots.reset_lin_vel) + T->reset_lin_vel_lo,
-                    T->reset_lin_vel_span * rs.draw(T->slots.reset_lin_vel + 1) + T->reset_lin_vel_lo,
-                    T->reset_lin_vel_span * rs.draw(T->slots.reset_lin_vel + 2) + T->reset_lin_vel_lo);
-            ww = v3(T->reset_ang_vel_span * rs.draw(T->slots.reset_ang_vel) + T->reset_ang_vel_lo,
-                    T->reset_ang_vel_span * rs.draw(T->slots.reset_ang_vel + 1) + T->reset_ang_vel_lo,
-                    T->reset_ang_vel_span * rs.draw(T->slots.reset_ang_vel + 2) + T->reset_ang_vel_lo);
+            qx = sit ? T->sit_quat[0] : H.base_init_quat[0]; qy = sit ? T->sit_quat[1] : H.base_init_quat[1];
+            qz = sit ? T->sit_quat[2] : H.base_init_quat[2]; qw = sit ? T->sit_quat[3] : H.base_init_quat[3];
+            if (H.reset_lin_vel_span != 0.f || H.reset_ang_vel_span != 0.f || rs.in) {   // go2.py:131-133 draws U(0,0): skip
+                float a0, a1, a2, b0_, b1_, b2_;
+                rs.draw3(H.slots.reset_lin_vel, a0, a1, a2);
+                rs.draw3(H.slots.reset_ang_vel, b0_, b1_, b2_);
+                vw = v3(H.reset_lin_vel_span * a0 + H.reset_lin_vel_lo, H.reset_lin_vel_span * a1 + H.reset_lin_vel_lo,
+                        H.reset_lin_vel_span * a2 + H.reset_lin_vel_lo);
+                ww = v3(H.reset_ang_vel_span * b0_ + H.reset_ang_vel_lo, H.reset_ang_vel_span * b1_ + H.reset_ang_vel_lo,
+                        H.reset_ang_vel_span * b2_ + H.reset_ang_vel_lo);
+            } else {
+                vw = v3(H.reset_lin_vel_lo, H.reset_lin_vel_lo, H.reset_lin_vel_lo);
+                ww = v3(H.reset_ang_vel_lo, H.reset_ang_vel_lo, H.reset_ang_vel_lo);
+            }
             if (sit) { vw = v3(0, 0, 0); ww = v3(0, 0, 0); }        // tron1_pf_ee.py:304-309
             if (BIPED) {                                             // tron1_pf_ee.py:220-226
-                const float th0 = T->theta_table[0][0] + rs.draw(T->slots.task_reset + 1);
+                const float th0 = T->theta_table[0][0] + rs.draw(H.slots.task_reset + 1);
                 theta = foot_slot == 0 ? th0 : th0 + (T->theta_table[0][1] - T->theta_table[0][0]);
-                gait_time = rs.draw(T->slots.task_reset + 2) * gait_period;
+                gait_time = rs.draw(H.slots.task_reset + 2) * gait_period;
                 phi = gait_time / gait_period;
             }
             // the reference stores the commanded reset twist verbatim in the body-frame properties
@@ -1062,11 +1453,14 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                     B.actions[e * A + d0 + j] = 0.f; B.last_actions[e * A + d0 + j] = 0.f; B.llast_actions[e * A + d0 + j] = 0.f;
                 }
                 st3(B.last_feet_vel + (e * F + foot_slot) * 3, v3(0, 0, 0));
-                if (T->dr_pd_on) {   // genesis_simulator.py:735-739
+                if (H.dr_pd_on) {   // genesis_simulator.py:735-739
+                    float up[3], ud2[3];
+                    rs.draw3(H.slots.dr_kp + d0, up[0], up[1], up[2]);
+                    rs.draw3(H.slots.dr_kd + d0, ud2[0], ud2[1], ud2[2]);
 #pragma unroll
                     for (int j = 0; j < 3; j++) {
-                        B.kp_scale[e * A + d0 + j] = T->dr_kp_span * rs.draw(T->slots.dr_kp + d0 + j) + T->dr_kp_lo;
-                        B.kd_scale[e * A + d0 + j] = T->dr_kd_span * rs.draw(T->slots.dr_kd + d0 + j) + T->dr_kd_lo;
+                        B.kp_scale[e * A + d0 + j] = H.dr_kp_span * up[j] + H.dr_kp_lo;
+                        B.kd_scale[e * A + d0 + j] = H.dr_kd_span * ud2[j] + H.dr_kd_lo;
                     }
                 }
             }
@@ -1078,38 +1472,41 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 st3(B.projected_gravity + 3 * e, pg);
                 st3(B.last_base_lin_vel + 3 * e, v3(0, 0, 0)); st3(B.last_base_ang_vel + 3 * e, v3(0, 0, 0));
                 // domain randomisation (genesis_simulator.py:62-77, 665-739)
-                if (T->dr_friction_on) B.friction_values[e] = T->dr_friction_span * rs.draw(T->slots.dr_friction) + T->dr_friction_lo;
-                if (T->dr_mass_on) B.added_base_mass[e] = T->dr_mass_span * rs.draw(T->slots.dr_mass) + T->dr_mass_lo;
-                if (T->dr_com_on) {
+                if (H.dr_friction_on) B.friction_values[e] = H.dr_friction_span * rs.draw(H.slots.dr_friction) + H.dr_friction_lo;
+                if (H.dr_mass_on) B.added_base_mass[e] = H.dr_mass_span * rs.draw(H.slots.dr_mass) + H.dr_mass_lo;
+                if (H.dr_com_on) {
+                    float uc[3];
+                    rs.draw3(H.slots.dr_com, uc[0], uc[1], uc[2]);
 #pragma unroll
-                    for (int k = 0; k < 3; k++)
-                        B.base_com_bias[3 * e + k] = T->dr_com_span[k] * rs.draw(T->slots.dr_com + k) + T->dr_com_lo[k];
+                    for (int k = 0; k < 3; k++) B.base_com_bias[3 * e + k] = H.dr_com_span[k] * uc[k] + H.dr_com_lo[k];
                 }
-                if (T->dr_joint_on && B.joint_armature) {
-                    B.joint_armature[e] = T->dr_joint_span[0] * rs.draw(T->slots.dr_joint) + T->dr_joint_lo[0];
-                    B.joint_friction[e] = T->dr_joint_span[1] * rs.draw(T->slots.dr_joint + 1) + T->dr_joint_lo[1];
-                    B.joint_damping[e] = T->dr_joint_span[2] * rs.draw(T->slots.dr_joint + 2) + T->dr_joint_lo[2];
+                if (H.dr_joint_on && B.joint_armature) {
+                    float uj[3];
+                    rs.draw3(H.slots.dr_joint, uj[0], uj[1], uj[2]);
+                    B.joint_armature[e] = H.dr_joint_span[0] * uj[0] + H.dr_joint_lo[0];
+                    B.joint_friction[e] = H.dr_joint_span[1] * uj[1] + H.dr_joint_lo[1];
+                    B.joint_damping[e] = H.dr_joint_span[2] * uj[2] + H.dr_joint_lo[2];
                 }
-                // extras["episode"] sums (legged_robot.py:128-132): one atomic per active term per reset
-                float *row = B.episode_done_sums + (p.counter % LG_DONE_RING) * (LG_R_COUNT + 2);
+                // extras["episode"] (legged_robot.py:128-132): snapshot this env's sums + the step it reset at; the
+                // host forms the per-step means lazily from these.  (A first version used one float atomic per term
+                // per reset on a shared accumulator: ~10 us per launch of same-line atomic latency.)
+#pragma unroll
                 for (int k = 0; k < LG_R_COUNT; k++) {
-                    if (T->reward_scales[k] != 0.f) {
-                        atomicAdd(row + k, esum[(size_t)k * N + e]);
-                        esum[(size_t)k * N + e] = 0.f;
-                    }
+                    if (scl[k] != 0.f) { B.episode_done_sums[(size_t)k * N + e] = es[k]; es[k] = 0.f; }
                 }
-                atomicAdd(row + LG_R_COUNT, 1.f);
+                B.episode_done_step[e] = (int)p.counter;
             }
         }
     }
     if (DO_RESET) {
+        STAMP(9);
         // ---- compute_observations + clip (legged_robot.py:48-49).  Layouts: go2.py:40-64 (45),
         //      go2_wtw.py:53-111 (61x5 | 99x5), go2_ee.py:10-75 (45x20 | 174x5 | 24 labels).  Histories are
         //      kept oldest -> newest inside obs_buf / priv_obs_buf themselves and shifted in place.
-        const int FR = T->obs_frame, PF = T->priv_frame, ST = T->obs_stack, PST = T->priv_stack;
-        float *o = B.obs_buf + (size_t)e * T->num_obs;
-        float *pv = T->num_priv_obs > 0 ? B.priv_obs_buf + (size_t)e * T->num_priv_obs : nullptr;
-        const float co = T->clip_obs;
+        const int FR = H.obs_frame, PF = H.priv_frame, ST = H.obs_stack, PST = H.priv_stack;
+        float *o = B.obs_buf + (size_t)e * H.num_obs;
+        float *pv = H.num_priv_obs > 0 ? B.priv_obs_buf + (size_t)e * H.num_priv_obs : nullptr;
+        const float co = H.clip_obs;
         if (live) {   // this lane's columns move one frame towards the past (zeros after a reset: go2_wtw.py:174-178)
             for (int f = 0; f + 1 < ST; f++)
                 for (int i = leg; i < FR; i += LEGS) o[f * FR + i] = reset ? 0.f : o[(f + 1) * FR + i];
@@ -1118,8 +1515,8 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                     for (int i = leg; i < PF; i += LEGS) pv[f * PF + i] = reset ? 0.f : pv[(f + 1) * PF + i];
         }
         float *on = o + (ST - 1) * FR, *pn = pv ? pv + (PST - 1) * PF : nullptr;
-        const bool nz = T->add_noise != 0;
-        const int ns = T->slots.noise;
+        const bool nz = H.add_noise != 0;
+        const int ns = H.slots.noise;
         // uniforms for the noisy entries only (commands and actions carry zero noise scale): q, qd per lane,
         // gravity + ang vel on the lead lane
         float uq[3] = {0.5f, 0.5f, 0.5f}, uqd[3] = {0.5f, 0.5f, 0.5f}, ub[6] = {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f};
@@ -1138,7 +1535,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             }
         }
         float uact[3] = {0.5f, 0.5f, 0.5f}, uclk[2] = {0.5f, 0.5f};
-        if (nz && T->noise_vec[9 + 2 * A] != 0.f) {   // tron1_pf_ee.py:338-342 (quirk 4): actions and clock are noisy too
+        if (nz && H.noise_act0 != 0.f) {  // uniform index: scalar load   // tron1_pf_ee.py:338-342 (quirk 4): actions and clock are noisy too
             if (rs.in) {
 #pragma unroll
                 for (int j = 0; j < 3; j++) uact[j] = rs.in[ns + 9 + 2 * A + d0 + j];
@@ -1149,32 +1546,32 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 rs.block3(3 * LEGS + 2 + leg, uclk[0], uclk[1], dummy);
             }
         }
-        auto put = [&](int idx, float v, float u) {        // critic copy of the frame is noise-free
+        auto put = [&](int idx, float v, float u, float nscale) {   // critic copy of the frame is noise-free
             if (pn) pn[idx] = clampf(v, -co, co);
-            if (nz) v += (2.f * u - 1.f) * T->noise_vec[idx];
+            if (nz) v += (2.f * u - 1.f) * nscale;
             on[idx] = clampf(v, -co, co);
         };
         auto putp = [&](int idx, float v) { pn[idx] = clampf(v, -co, co); };
         if (live) {
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                put(9 + d0 + j, (q[j] - O->default_dof_pos[d0 + j]) * T->obs_scale_dof_pos, uq[j]);
-                put(9 + A + d0 + j, qd[j] * T->obs_scale_dof_vel, uqd[j]);
-                put(9 + 2 * A + d0 + j, act[j], uact[j]);
+                put(9 + d0 + j, (q[j] - q0l[j]) * H.obs_scale_dof_pos, uq[j], nv_q[j]);
+                put(9 + A + d0 + j, qd[j] * H.obs_scale_dof_vel, uqd[j], nv_qd[j]);
+                put(9 + 2 * A + d0 + j, act[j], uact[j], nv_act[j]);
             }
         }
         if (lead) {
-            put(0, cmd0 * T->obs_scale_lin_vel, 0.5f); put(1, cmd1 * T->obs_scale_lin_vel, 0.5f); put(2, cmd2 * T->obs_scale_ang_vel, 0.5f);
-            put(3, pg.x, ub[0]); put(4, pg.y, ub[1]); put(5, pg.z, ub[2]);
-            put(6, bav.x * T->obs_scale_ang_vel, ub[3]); put(7, bav.y * T->obs_scale_ang_vel, ub[4]); put(8, bav.z * T->obs_scale_ang_vel, ub[5]);
+            put(0, cmd0 * H.obs_scale_lin_vel, 0.5f, 0.f); put(1, cmd1 * H.obs_scale_lin_vel, 0.5f, 0.f); put(2, cmd2 * H.obs_scale_ang_vel, 0.5f, 0.f);
+            put(3, pg.x, ub[0], H.noise_lead[0]); put(4, pg.y, ub[1], H.noise_lead[1]); put(5, pg.z, ub[2], H.noise_lead[2]);
+            put(6, bav.x * H.obs_scale_ang_vel, ub[3], H.noise_lead[3]); put(7, bav.y * H.obs_scale_ang_vel, ub[4], H.noise_lead[4]); put(8, bav.z * H.obs_scale_ang_vel, ub[5], H.noise_lead[5]);
         }
-        if (T->obs_layout == LG_OBS_GO2_WTW) {
+        if (H.obs_layout == LG_OBS_GO2_WTW) {
             const float ang = 6.283185307179586f * (phi + theta);      // clock inputs (go2_wtw.py:251-256)
             if (live) {
                 const float sn = sinf(ang), cs = cosf(ang);
-                put(45 + foot_slot, sn, 0.5f);
-                put(49 + foot_slot, cs, 0.5f);
-                put(57 + foot_slot, theta, 0.5f);
+                put(45 + foot_slot, sn, 0.5f, 0.f);
+                put(49 + foot_slot, cs, 0.5f, 0.f);
+                put(57 + foot_slot, theta, 0.5f, 0.f);
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
                     putp(FR + 10 + d0 + j, B.kp_scale[e * A + d0 + j]);
@@ -1184,22 +1581,22 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 ts[6 + foot_slot] = theta; ts[10 + foot_slot] = sn; ts[14 + foot_slot] = cs; ts[18 + foot_slot] = expC;
             }
             if (lead) {
-                put(53, gait_period, 0.5f); put(54, bh_tgt, 0.5f); put(55, fc_tgt, 0.5f); put(56, pitch_tgt, 0.5f);
-                putp(FR + 0, blv.x * T->obs_scale_lin_vel); putp(FR + 1, blv.y * T->obs_scale_lin_vel); putp(FR + 2, blv.z * T->obs_scale_lin_vel);
+                put(53, gait_period, 0.5f, 0.f); put(54, bh_tgt, 0.5f, 0.f); put(55, fc_tgt, 0.5f, 0.f); put(56, pitch_tgt, 0.5f, 0.f);
+                putp(FR + 0, blv.x * H.obs_scale_lin_vel); putp(FR + 1, blv.y * H.obs_scale_lin_vel); putp(FR + 2, blv.z * H.obs_scale_lin_vel);
                 putp(FR + 3, B.rand_push_vels[3 * e]); putp(FR + 4, B.rand_push_vels[3 * e + 1]);
                 putp(FR + 5, B.added_base_mass[e]); putp(FR + 6, B.friction_values[e]);
                 putp(FR + 7, B.base_com_bias[3 * e]); putp(FR + 8, B.base_com_bias[3 * e + 1]); putp(FR + 9, B.base_com_bias[3 * e + 2]);
             }
-        } else if (T->obs_layout == LG_OBS_GO2_EE) {
+        } else if (H.obs_layout == LG_OBS_GO2_EE) {
             // critic frame (go2_ee.py:21-48): obs 45 | DR 31 | contact states K | heights P
             const int K = __popc(M->state_link_mask);
             const int l0 = foot_link - 3;
-            float *lab = B.labels_buf + (size_t)e * T->num_labels;
+            float *lab = B.labels_buf + (size_t)e * H.num_labels;
             if (live) {
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
-                    putp(FR + 7 + d0 + j, B.kp_scale[e * A + d0 + j] - T->kp_offset);
-                    putp(FR + 7 + A + d0 + j, B.kd_scale[e * A + d0 + j] - T->kd_offset);
+                    putp(FR + 7 + d0 + j, B.kp_scale[e * A + d0 + j] - H.kp_offset);
+                    putp(FR + 7 + A + d0 + j, B.kd_scale[e * A + d0 + j] - H.kd_offset);
                 }
                 // contact states are those of the physics read-back (stale for a just-reset env, as in the reference)
 #pragma unroll
@@ -1213,37 +1610,37 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                     }
                 }
                 for (int k = leg; k < P; k += LEGS) {
-                    float hv = pos.z - T->heights_offset - B.measured_heights[(size_t)e * P + k];
-                    if (T->heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * T->obs_scale_height;
+                    float hv = pos.z - H.heights_offset - B.measured_heights[(size_t)e * P + k];
+                    if (H.heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * H.obs_scale_height;
                     putp(FR + 7 + 2 * A + K + k, hv);
                 }
                 // labels (go2_ee.py:69-75): v_b 3 | contact states K | foot height above the local terrain mean F
-                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmean - T->foot_height_offset, -1.f, 1.f);
+                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmean - H.foot_height_offset, -1.f, 1.f);
             }
             if (lead) {
-                putp(FR + 0, B.friction_values[e] - T->friction_offset); putp(FR + 1, B.added_base_mass[e]);
+                putp(FR + 0, B.friction_values[e] - H.friction_offset); putp(FR + 1, B.added_base_mass[e]);
                 putp(FR + 2, B.base_com_bias[3 * e]); putp(FR + 3, B.base_com_bias[3 * e + 1]); putp(FR + 4, B.base_com_bias[3 * e + 2]);
                 putp(FR + 5, B.rand_push_vels[3 * e]); putp(FR + 6, B.rand_push_vels[3 * e + 1]);
                 if (M->state_link_mask & 1u) { const float cs = norm(f_base) > 1.f ? 1.f : 0.f; putp(FR + 7 + 2 * A, cs); lab[3] = cs; }
-                lab[0] = blv.x * T->obs_scale_lin_vel; lab[1] = blv.y * T->obs_scale_lin_vel; lab[2] = blv.z * T->obs_scale_lin_vel;
+                lab[0] = blv.x * H.obs_scale_lin_vel; lab[1] = blv.y * H.obs_scale_lin_vel; lab[2] = blv.z * H.obs_scale_lin_vel;
             }
-        } else if (T->obs_layout == LG_OBS_TRON1_EE) {
+        } else if (H.obs_layout == LG_OBS_TRON1_EE) {
             // tron1_pf_ee.py:53-141.  actor frame: 9 + 3A + clock 2F.  critic frame: frame | DR (7 + 2A + 3) |
             // gait F | contact states K | heights P | normals 3F | clip(foot_z - h9) 9F.  labels: v_b 3 | K | F | 3F
             const int K = __popc(M->state_link_mask);
             const int l0 = foot_link - 3;
-            float *lab = B.labels_buf + (size_t)e * T->num_labels;
+            float *lab = B.labels_buf + (size_t)e * H.num_labels;
             const float ang = 6.283185307179586f * (phi + theta);
             const int oDR = FR, oG = FR + 7 + 2 * A + 3, oK = oG + F, oH = oK + K, oN = oH + P, oR = oN + 3 * F;
             if (live) {
                 const float sn = sinf(ang), cs = cosf(ang);
-                put(9 + 3 * A + foot_slot, sn, uclk[0]);
-                put(9 + 3 * A + F + foot_slot, cs, uclk[1]);
+                put(9 + 3 * A + foot_slot, sn, uclk[0], nv_clk[0]);
+                put(9 + 3 * A + F + foot_slot, cs, uclk[1], nv_clk[1]);
                 ts[4 + foot_slot] = theta; ts[6 + foot_slot] = sn; ts[6 + F + foot_slot] = cs; ts[10 + foot_slot] = expC;
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
-                    putp(oDR + 7 + d0 + j, B.kp_scale[e * A + d0 + j] - T->kp_offset);
-                    putp(oDR + 7 + A + d0 + j, B.kd_scale[e * A + d0 + j] - T->kd_offset);
+                    putp(oDR + 7 + d0 + j, B.kp_scale[e * A + d0 + j] - H.kp_offset);
+                    putp(oDR + 7 + A + d0 + j, B.kd_scale[e * A + d0 + j] - H.kd_offset);
                 }
                 putp(oG + foot_slot, expC);
 #pragma unroll
@@ -1257,8 +1654,8 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                     }
                 }
                 for (int k = leg; k < P; k += LEGS) {
-                    float hv = pos.z - T->heights_offset - B.measured_heights[(size_t)e * P + k];
-                    if (T->heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * T->obs_scale_height;
+                    float hv = pos.z - H.heights_offset - B.measured_heights[(size_t)e * P + k];
+                    if (H.heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * H.obs_scale_height;
                     putp(oH + k, hv);
                 }
                 const float *nv3 = B.normal_vector_around_feet + ((size_t)e * F + foot_slot) * 3;
@@ -1267,17 +1664,17 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
 #pragma unroll
                 for (int k = 0; k < 9; k++)
                     putp(oR + 9 * foot_slot + k, clampf(foot_p.z - B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k], -1.f, 1.f));
-                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmax - T->foot_height_offset, -1.f, 1.f);
+                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmax - H.foot_height_offset, -1.f, 1.f);
             }
             if (lead) {
-                putp(oDR + 0, B.friction_values[e] - T->friction_offset); putp(oDR + 1, B.added_base_mass[e]);
+                putp(oDR + 0, B.friction_values[e] - H.friction_offset); putp(oDR + 1, B.added_base_mass[e]);
                 putp(oDR + 2, B.base_com_bias[3 * e]); putp(oDR + 3, B.base_com_bias[3 * e + 1]); putp(oDR + 4, B.base_com_bias[3 * e + 2]);
                 putp(oDR + 5, B.rand_push_vels[3 * e]); putp(oDR + 6, B.rand_push_vels[3 * e + 1]);
                 putp(oDR + 7 + 2 * A, B.joint_armature ? B.joint_armature[e] : 0.f);
                 putp(oDR + 8 + 2 * A, B.joint_friction ? B.joint_friction[e] : 0.f);
                 putp(oDR + 9 + 2 * A, B.joint_damping ? B.joint_damping[e] : 0.f);
                 if (M->state_link_mask & 1u) { const float cst = norm(f_base) > 1.f ? 1.f : 0.f; putp(oK, cst); lab[3] = cst; }
-                lab[0] = blv.x * T->obs_scale_lin_vel; lab[1] = blv.y * T->obs_scale_lin_vel; lab[2] = blv.z * T->obs_scale_lin_vel;
+                lab[0] = blv.x * H.obs_scale_lin_vel; lab[1] = blv.y * H.obs_scale_lin_vel; lab[2] = blv.z * H.obs_scale_lin_vel;
             }
         }
     }
@@ -1286,16 +1683,17 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     }
     if (BIPED && lead) { ts[0] = gait_time; ts[1] = phi; ts[2] = gait_period; }
     if (BIPED && live && !DO_RESET) { ts[4 + foot_slot] = theta; ts[10 + foot_slot] = expC; }
-    if (WTW && live && !(DO_RESET && T->obs_layout == LG_OBS_GO2_WTW)) { ts[6 + foot_slot] = theta; ts[18 + foot_slot] = expC; }
+    if (WTW && live && !(DO_RESET && H.obs_layout == LG_OBS_GO2_WTW)) { ts[6 + foot_slot] = theta; ts[18 + foot_slot] = expC; }
     // second action-history shift of the wtw / tron1_ee tasks (go2_wtw.py:45-46): afterwards
     // last == llast == a_t, which makes action_smoothness == action_rate
-    if (DO_RESET && T->double_shift && live) {
+    if (DO_RESET && H.double_shift && live) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             B.llast_actions[e * A + d0 + j] = reset ? 0.f : last_act[j];
             B.last_actions[e * A + d0 + j] = act[j];
         }
     }
+    STAMP(10);
     // ---- persistent MDP state ----
     if (live) {
         B.feet_air_time[e * F + foot_slot] = air;
@@ -1308,7 +1706,13 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         B.reset_buf[e] = reset ? 1 : 0;
         B.time_out_buf[e] = time_out ? 1 : 0;
         B.rew_buf[e] = total;
+        if (DO_POST || (DO_RESET && reset)) {
+#pragma unroll
+            for (int k = 0; k < LG_R_COUNT; k++)
+                if (scl[k] != 0.f) esum[(size_t)k * N + e] = es[k];
+        }
     }
+    STAMP(11);
 }
 
 // =============================== host side: the C ABI ==========================================
@@ -1318,7 +1722,7 @@ static int fail(const std::string &m) { g_err = m; return 1; }
 
 struct LgEngine {
     LgModelDesc model; LgSimOptions opts; LgTaskCfg task;
-    LgModelDesc *d_model = nullptr; LgSimOptions *d_opts = nullptr; LgTaskCfg *d_task = nullptr;
+    LgModelDesc *d_model = nullptr; LgSimOptions *d_opts = nullptr; LgTaskCfg *d_task = nullptr; LgHot *d_hot = nullptr;
     const int16_t *hf = nullptr;
     LgBuffers bufs; bool bound = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -1326,6 +1730,14 @@ struct LgEngine {
 
 extern "C" const char *lg_last_error(void) { return g_err.c_str(); }
 extern "C" int lg_abi_version(void) { return LG_ABI_VERSION; }
+
+static int upload_hot(LgEngine *h) {
+    LgHot hot;
+    fill_hot(hot, h->task, h->opts, 3 * h->model.n_legs);
+    if (!h->d_hot) { hipError_t e = hipMalloc(&h->d_hot, sizeof(LgHot)); if (e != hipSuccess) return fail(std::string("hipMalloc(hot): ") + hipGetErrorString(e)); }
+    HIPCHK(hipMemcpy(h->d_hot, &hot, sizeof(LgHot), hipMemcpyHostToDevice));
+    return 0;
+}
 
 static int validate_model(const LgModelDesc *m) {
     if (m->n_legs != 2 && m->n_legs != 4) return fail("lg_create: engine supports 2 or 4 legs of 3 revolute joints");
@@ -1342,6 +1754,11 @@ static int validate_model(const LgModelDesc *m) {
         if (m->link_body[fl] != 3 + 3 * l) return fail("lg_create: foot link must move with the last body of its leg");
     }
     if (m->link_body[0] != 0) return fail("lg_create: link 0 must be the base");
+    for (int l = 0; l < m->n_legs; l++) {   // register-resident sphere tables of the kernel: 2 / 2 / 5 (+foot) per chain body
+        const int *st = m->body_sph_start + 1 + 3 * l;
+        if (st[1] - st[0] > 2 || st[2] - st[1] > 2 || st[3] - st[2] > 6) return fail("lg_create: too many collision spheres on a leg body (max 2/2/5+foot)");
+    }
+    if ((m->body_sph_start[1] - m->body_sph_start[0] + m->n_legs - 1) / m->n_legs > 4) return fail("lg_create: too many base collision spheres (max 4 per leg lane)");
     for (int b = 0; b <= m->n_bodies; b++)
         if (m->body_sph_start[b] < 0 || m->body_sph_start[b] > m->n_spheres || (b && m->body_sph_start[b] < m->body_sph_start[b - 1]))
             return fail("lg_create: body_sph_start not monotone");
@@ -1359,11 +1776,12 @@ extern "C" int lg_create(const LgModelDesc *model, const LgSimOptions *opts, con
     h->model = *model; h->opts = *opts; h->task = *task;
     memset(&h->bufs, 0, sizeof(h->bufs));
     hipError_t e;
-    if ((e = hipMalloc(&h->d_model, sizeof(LgModelDesc))) != hipSuccess || (e = hipMalloc(&h->d_opts, sizeof(LgSimOptions))) != hipSuccess ||
+    if ((e = hipMalloc(&h->d_model, (sizeof(LgModelDesc) + 15) / 16 * 16)) != hipSuccess || (e = hipMalloc(&h->d_opts, sizeof(LgSimOptions))) != hipSuccess ||
         (e = hipMalloc(&h->d_task, sizeof(LgTaskCfg))) != hipSuccess) { delete h; return fail(std::string("lg_create: hipMalloc: ") + hipGetErrorString(e)); }
     HIPCHK(hipMemcpy(h->d_model, model, sizeof(LgModelDesc), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_opts, opts, sizeof(LgSimOptions), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_task, task, sizeof(LgTaskCfg), hipMemcpyHostToDevice));
+    if (upload_hot(h)) return 1;
     HIPCHK(hipEventCreate(&h->ev0));
     HIPCHK(hipEventCreate(&h->ev1));
     *out = h;
@@ -1372,7 +1790,7 @@ extern "C" int lg_create(const LgModelDesc *model, const LgSimOptions *opts, con
 
 extern "C" int lg_destroy(LgHandle h) {
     if (!h) return 0;
-    (void)hipFree(h->d_model); (void)hipFree(h->d_opts); (void)hipFree(h->d_task);
+    (void)hipFree(h->d_model); (void)hipFree(h->d_opts); (void)hipFree(h->d_task); (void)hipFree(h->d_hot);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     delete h;
@@ -1383,7 +1801,7 @@ extern "C" int lg_set_task(LgHandle h, const LgTaskCfg *task) {
     if (!h || !task) return fail("lg_set_task: null argument");
     h->task = *task;
     HIPCHK(hipMemcpy(h->d_task, task, sizeof(LgTaskCfg), hipMemcpyHostToDevice));
-    return 0;
+    return upload_hot(h);
 }
 
 extern "C" int lg_set_terrain(LgHandle h, const int16_t *hf, int32_t rows, int32_t cols) {
@@ -1393,7 +1811,7 @@ extern "C" int lg_set_terrain(LgHandle h, const int16_t *hf, int32_t rows, int32
     h->opts.terrain_rows = hf ? rows : 0;
     h->opts.terrain_cols = hf ? cols : 0;
     HIPCHK(hipMemcpy(h->d_opts, &h->opts, sizeof(LgSimOptions), hipMemcpyHostToDevice));
-    return 0;
+    return upload_hot(h);
 }
 
 extern "C" int lg_bind(LgHandle h, const LgBuffers *b) {
@@ -1412,7 +1830,11 @@ extern "C" int lg_bind(LgHandle h, const LgBuffers *b) {
 
 template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *actions, int64_t counter, hipStream_t st) {
     KParams p;
-    p.M = h->d_model; p.O = h->d_opts; p.T = h->d_task; p.hf = h->hf; p.B = h->bufs; p.actions = actions; p.counter = counter;
+    p.M = h->d_model; p.O = h->d_opts; p.T = h->d_task; p.H = h->d_hot; p.hf = h->hf; p.B = h->bufs; p.actions = actions; p.counter = counter;
+    p.jrot_identity = 1;
+    for (int b = 1; b < h->model.n_bodies; b++)
+        for (int k = 0; k < 9; k++)
+            if (h->model.jrot[b][k] != ((k % 4 == 0) ? 1.f : 0.f)) p.jrot_identity = 0;
     const int threads = h->bufs.n_envs * LEGS;
     dim3 grid((threads + BLOCK - 1) / BLOCK), block(BLOCK);
     switch (ph) {
@@ -1437,7 +1859,7 @@ static int check_mdp_bufs(const LgEngine *h, uint32_t ph) {
 #define REQ(f) if (!b.f) return fail("lg_step: MDP phases need buffer " #f)
         REQ(actions); REQ(last_actions); REQ(llast_actions); REQ(commands); REQ(feet_air_time); REQ(last_contacts);
         REQ(episode_length_buf); REQ(fail_buf); REQ(reset_buf); REQ(time_out_buf); REQ(rew_buf); REQ(obs_buf);
-        REQ(episode_sums); REQ(episode_done_sums); REQ(command_ranges); REQ(rand_push_vels);
+        REQ(episode_sums); REQ(episode_done_sums); REQ(episode_done_step); REQ(command_ranges); REQ(rand_push_vels);
         REQ(friction_values); REQ(added_base_mass); REQ(base_com_bias); REQ(kp_scale); REQ(kd_scale);
 #undef REQ
     }

@@ -73,7 +73,8 @@ class Engine:
         self.buf = {k: torch.zeros((self.n,) + tuple(shape), dtype=dt, device=self.device)
                     for k, (shape, dt) in specs.items()}
         self.buf["episode_sums"] = torch.zeros((abi.R_COUNT, self.n), device=self.device)
-        self.buf["episode_done_sums"] = torch.zeros((abi.DONE_RING, abi.R_COUNT + 2), device=self.device)
+        self.buf["episode_done_sums"] = torch.zeros((abi.R_COUNT, self.n), device=self.device)
+        self.buf["episode_done_step"] = torch.full((self.n,), -1, dtype=torch.int32, device=self.device)
         self.buf["command_ranges"] = torch.zeros(abi.CMD_RANGE_FLOATS, device=self.device)
         if inject_rand:
             self.buf["rand_in"] = torch.zeros((self.n, task.slots.n_slots), device=self.device)

@@ -27,26 +27,26 @@ from ..simulator import HipSimulator
 
 
 class _EpisodeExtras(Mapping):
-    """Lazy ``extras["episode"]`` (legged_robot.py:128-138): per-term mean of the episode sums over
-    the envs reset at one step, divided by episode_length_s.  Values are computed on access from
-    the kernel's per-step accumulator ring, so the hot loop issues no extra launches.  When a step
-    had no reset the reference leaves the previous dict in place; the same is done here by
-    walking back through the ring."""
+    """Lazy ``extras["episode"]`` (legged_robot.py:128-138): per-term mean of the episode sums over the envs
+    reset at one step, divided by episode_length_s.  The kernel snapshots every resetting env's sums and the
+    step index; the means are formed on access, so the hot loop issues no extra launches and no atomics.
+    When a step had no reset the reference leaves the previous dict in place: the same happens here by
+    falling back to the most recent step (<= this one) that had resets.  (An env that resets twice before
+    the dict is read contributes only its latest episode -- logging only.)"""
 
     def __init__(self, env, step):
         self._env, self._step = env, step
+        self._mask = None
 
-    def _row(self):
-        ring = self._env._engine.buf["episode_done_sums"]
-        R = abi.R_COUNT
-        for back in range(abi.DONE_RING - 2):
-            s = self._step - back
-            if s < 1:
-                break
-            row = ring[s % abi.DONE_RING]
-            if float(row[R]) > 0:
-                return row
-        return None
+    def _ids(self):
+        if self._mask is None:
+            ds = self._env._engine.buf["episode_done_step"]
+            ok = (ds <= self._step) & (ds >= 0)
+            if bool(ok.any()):
+                self._mask = ds == ds[ok].max()
+            else:
+                self._mask = torch.zeros_like(ds, dtype=torch.bool)
+        return self._mask
 
     def __getitem__(self, key):
         env = self._env
@@ -57,10 +57,10 @@ class _EpisodeExtras(Mapping):
         name = key[4:]
         if not key.startswith("rew_") or name not in env.episode_sums:
             raise KeyError(key)
-        row = self._row()
-        if row is None:
+        m = self._ids()
+        if not bool(m.any()):
             return torch.zeros((), device=env.device)
-        return row[abi.REWARD_ID[name]] / row[abi.R_COUNT] / env.max_episode_length_s
+        return torch.mean(env._engine.buf["episode_done_sums"][abi.REWARD_ID[name]][m]) / env.max_episode_length_s
 
     def __iter__(self):
         env = self._env

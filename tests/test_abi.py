@@ -46,7 +46,6 @@ def test_constants_match_header():
     assert int(d["LG_MAX_DOF"]) == abi.MAX_DOF and int(d["LG_MAX_BODIES"]) == abi.MAX_BODIES
     assert int(d["LG_MAX_LINKS"]) == abi.MAX_LINKS and int(d["LG_MAX_SPHERES"]) == abi.MAX_SPHERES
     assert int(d["LG_MAX_OBS"]) == abi.MAX_OBS and int(d["LG_NUM_REWARDS"]) == abi.NUM_REWARDS
-    assert int(d["LG_DONE_RING"]) == abi.DONE_RING
     enum = re.search(r"enum LgReward \{(.*?)\};", h, re.S).group(1)
     names = [n.strip().split("=")[0].strip() for n in re.sub(r"/\*.*?\*/", "", enum, flags=re.S).split(",") if n.strip()]
     assert names[-1] == "LG_R_COUNT"

@@ -1,0 +1,44 @@
+"""Developer timing: fused launch vs physics-only vs MDP-only launches on the same steady state."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from hcr_genesis_lr_cl_amd import abi
+from hcr_genesis_lr_cl_amd.envs import make_env
+
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 4096
+env, cfg = make_env(sys.argv[2] if len(sys.argv) > 2 else "go2", n)
+env.reset()
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+env.episode_length_buf[:] = torch.randint(0, 1000, (n,), generator=g, device="cuda", dtype=torch.int32)
+A = env.num_actions
+bank = [torch.randn(n, A, generator=g, device="cuda") for _ in range(8)]
+for i in range(600):
+    env.step(bank[i % 8])
+torch.cuda.synchronize()
+eng = env._engine
+
+
+def timeit(ph, reps=200):
+    ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    torch.cuda.synchronize()
+    ev0.record()
+    for i in range(reps):
+        eng.step(ph, bank[i % 8], 1000 + i)
+    ev1.record(); torch.cuda.synchronize()
+    return ev0.elapsed_time(ev1) / reps * 1e3
+
+
+snap = {k: v.clone() for k, v in eng.buf.items() if torch.is_tensor(v)}
+for name, ph in (("ALL", abi.PHASE_ALL), ("SIM", abi.PHASE_SIM), ("PRE|POST|RESET", abi.PHASE_PRE | abi.PHASE_POST | abi.PHASE_RESET),
+                 ("PRE|SIM|POST", abi.PHASE_PRE | abi.PHASE_SIM | abi.PHASE_POST), ("RESET", abi.PHASE_RESET)):
+    for k, v in snap.items():
+        eng.buf[k].copy_(v)
+    print(f"{name:16s} {timeit(ph):8.1f} us", flush=True)
+for k, v in snap.items():
+    eng.buf[k].copy_(v)
+eng.buf["reset_buf"].zero_()
+print(f"{'RESET (no resets)':16s} {timeit(abi.PHASE_RESET):8.1f} us", flush=True)
+eng.buf["reset_buf"].zero_(); eng.buf["reset_buf"][::64] = 1
+print(f"{'RESET (64 resets)':16s} {timeit(abi.PHASE_RESET):8.1f} us", flush=True)
+eng.buf["reset_buf"].fill_(1)
+print(f"{'RESET (all reset)':16s} {timeit(abi.PHASE_RESET):8.1f} us", flush=True)
