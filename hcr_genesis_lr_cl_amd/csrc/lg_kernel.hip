@@ -23,11 +23,14 @@
 #include <stdio.h>
 #include <string.h>
 #include <string>
+#include <type_traits>
 #include "../../include/lgsim.h"
 #include "lg_math.h"
 
 #define LG_ABI_VERSION 1
 #define BLOCK 64
+#define MODEL_STG 4   /* uint4 per thread to stage the model table: 4 * 64 * 16 B = 4 KiB >= sizeof(LgModelDesc) */
+static_assert(sizeof(LgModelDesc) <= MODEL_STG * BLOCK * 16, "model table does not fit the staging image");
 
 // ---- hot constants: every scalar of LgTaskCfg / LgSimOptions the kernel reads, packed contiguously so that ONE burst of
 //      s_load_dwordx16 at kernel start fetches them (scattered `T->x` reads each cost an exposed scalar-cache round trip
@@ -112,10 +115,12 @@ struct LgHot {
     float dr_com_span[3];
     float dr_joint_lo[3];
     float dr_joint_span[3];
+    float reward_scales[LG_NUM_REWARDS];
     float noise_lead[6];   // noise_vec[3..8]: gravity + angular velocity entries written by the lead lane
     float noise_act0;      // noise_vec[9 + 2A]: non-zero only for the tron1 layout
     LgRandSlots slots;
     unsigned long long seed; long long env_id_offset;
+    int32_t m_n_links, m_foot_link[LG_MAX_LEGS], m_foot_sphere[LG_MAX_LEGS];   // model uniforms needed before the LDS table is up
     float o_dt;
     int32_t o_decimation;
     float o_gravity_z;
@@ -142,8 +147,11 @@ struct LgHot {
     float o_bound_x[2];
     float o_bound_y[2];
 };
-static void fill_hot(LgHot &H, const LgTaskCfg &t, const LgSimOptions &o, int n_dof) {
+static void fill_hot(LgHot &H, const LgTaskCfg &t, const LgSimOptions &o, const LgModelDesc &m) {
+    const int n_dof = 3 * m.n_legs;
     memset(&H, 0, sizeof(H));
+    H.m_n_links = m.n_links;
+    for (int i = 0; i < LG_MAX_LEGS; i++) { H.m_foot_link[i] = m.foot_link[i]; H.m_foot_sphere[i] = m.foot_sphere[i]; }
     H.obs_layout = t.obs_layout;
     H.num_obs = t.num_obs;
     H.num_priv_obs = t.num_priv_obs;
@@ -223,6 +231,7 @@ static void fill_hot(LgHot &H, const LgTaskCfg &t, const LgSimOptions &o, int n_
     for (int i = 0; i < 3; i++) H.dr_com_span[i] = t.dr_com_span[i];
     for (int i = 0; i < 3; i++) H.dr_joint_lo[i] = t.dr_joint_lo[i];
     for (int i = 0; i < 3; i++) H.dr_joint_span[i] = t.dr_joint_span[i];
+    for (int i = 0; i < LG_NUM_REWARDS; i++) H.reward_scales[i] = t.reward_scales[i];
     for (int i = 0; i < 6; i++) H.noise_lead[i] = t.noise_vec[3 + i];
     H.noise_act0 = t.noise_vec[9 + 2 * n_dof];
     H.slots = t.slots; H.seed = t.seed; H.env_id_offset = t.env_id_offset;
@@ -252,6 +261,31 @@ static void fill_hot(LgHot &H, const LgTaskCfg &t, const LgSimOptions &o, int n_
     for (int i = 0; i < 2; i++) H.o_bound_x[i] = o.bound_x[i];
     for (int i = 0; i < 2; i++) H.o_bound_y[i] = o.bound_y[i];
 }
+
+static_assert(sizeof(LgHot) <= 256 * 4, "hot block must fit four dwords per lane");
+template <typename T> struct HotGet;
+template <> struct HotGet<float> { static LG_DEV float get(int v0, int v1, int v2, int v3, int i) {
+    const int v = i < 64 ? v0 : (i < 128 ? v1 : (i < 192 ? v2 : v3)); return __int_as_float(__builtin_amdgcn_readlane(v, i & 63)); } };
+template <> struct HotGet<int32_t> { static LG_DEV int get(int v0, int v1, int v2, int v3, int i) {
+    const int v = i < 64 ? v0 : (i < 128 ? v1 : (i < 192 ? v2 : v3)); return __builtin_amdgcn_readlane(v, i & 63); } };
+template <> struct HotGet<unsigned long long> { static LG_DEV unsigned long long get(int v0, int v1, int v2, int v3, int i) {
+    return (unsigned long long)(unsigned)HotGet<int32_t>::get(v0, v1, v2, v3, i) | ((unsigned long long)(unsigned)HotGet<int32_t>::get(v0, v1, v2, v3, i + 1) << 32); } };
+template <> struct HotGet<long long> { static LG_DEV long long get(int v0, int v1, int v2, int v3, int i) {
+    return (long long)HotGet<unsigned long long>::get(v0, v1, v2, v3, i); } };
+#define HOT_OFF(f) ((int)(((size_t) & reinterpret_cast<char const volatile &>(((LgHot *)0)->f)) / 4))
+// After the prologue the block lives in LDS (sHot): a field is one broadcast ds_read.  (Holding it in VGPR lanes for the
+// whole kernel is NOT safe: register copies made under a partial exec mask drop the inactive lanes' entries.)  Integers
+// steer control flow, so they are made scalar.
+template <typename T> struct HotLds;
+template <> struct HotLds<float> { static LG_DEV float get(const int *s, int i) { return __int_as_float(s[i]); } };
+template <> struct HotLds<int32_t> { static LG_DEV int get(const int *s, int i) { return __builtin_amdgcn_readfirstlane(s[i]); } };
+template <> struct HotLds<unsigned long long> { static LG_DEV unsigned long long get(const int *s, int i) {
+    return (unsigned long long)(unsigned)HotLds<int32_t>::get(s, i) | ((unsigned long long)(unsigned)HotLds<int32_t>::get(s, i + 1) << 32); } };
+template <> struct HotLds<long long> { static LG_DEV long long get(const int *s, int i) { return (long long)HotLds<unsigned long long>::get(s, i); } };
+#define HOT_T(f) typename std::remove_cv<typename std::remove_reference<decltype(((LgHot *)0)->f)>::type>::type
+#define CR(k) (__int_as_float(sHot[256 + (k)]))
+#define HOT0(f) (HotGet<HOT_T(f)>::get(hv0, hv1, hv2, hv3, HOT_OFF(f)))   // prologue only (full exec, fresh registers)
+#define HOT(f) (HotLds<HOT_T(f)>::get(sHot, HOT_OFF(f)))
 
 struct KParams {
     const LgModelDesc *M;
@@ -407,23 +441,24 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     // instead of an L2 round trip with a single wave per SIMD to hide it
     unsigned long long _stamp0 = 0; (void)_stamp0;
     STAMP(0);
-    constexpr int MODEL_V4 = (int)((sizeof(LgModelDesc) + 15) / 16);        // device copy is padded to 16 B
-    __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_V4];
-    {
-        const uint4 *src = reinterpret_cast<const uint4 *>(p.M);
-        constexpr int PER = (MODEL_V4 + BLOCK - 1) / BLOCK;
-        uint4 tmp[PER];
-#pragma unroll
-        for (int k = 0; k < PER; k++) { const int i = threadIdx.x + k * BLOCK; if (i < MODEL_V4) tmp[k] = src[i]; }   // all loads in flight
-#pragma unroll
-        for (int k = 0; k < PER; k++) { const int i = threadIdx.x + k * BLOCK; if (i < MODEL_V4) sMraw[i] = tmp[k]; }
+    // model table: device copy and LDS image are padded to MODEL_STG * BLOCK uint4 so the staging needs no predicate
+    __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_STG * BLOCK];
+    uint4 stg0, stg1, stg2, stg3;
+    {   // global -> registers now (same batch as every other start-of-kernel load); registers -> LDS after the barrier
+        const uint4 *src = reinterpret_cast<const uint4 *>(p.M) + threadIdx.x;
+        stg0 = src[0]; stg1 = src[BLOCK]; stg2 = src[2 * BLOCK]; stg3 = src[3 * BLOCK];
     }
-    __syncthreads();
-    STAMP(1);
     const LgModelDesc *M = reinterpret_cast<const LgModelDesc *>(sMraw);
     const LgSimOptions *__restrict__ O = p.O;
     const LgTaskCfg *__restrict__ T = p.T;
-    const LgHot H = *p.H;   // by value: SGPRs / lane-spilled VGPRs for the whole launch
+    // hot constants: lane i of hv[k] holds dword 64*k + i of the LgHot block (three coalesced loads, one wait);
+    // a field is then one v_readlane with a constant lane -- no scalar-cache round trips, no SGPR pressure
+    __shared__ int sHot[256 + BLOCK];
+    int hv0, hv1, hv2, hv3;
+    {
+        const int *hp = reinterpret_cast<const int *>(p.H) + (threadIdx.x & 63);
+        hv0 = hp[0]; hv1 = hp[64]; hv2 = hp[128]; hv3 = hp[192];
+    }
     const LgBuffers &B = p.B;
 
     const int tid = blockIdx.x * BLOCK + threadIdx.x;
@@ -432,18 +467,18 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     const bool live = e < B.n_envs;
     if (!live) e = B.n_envs - 1;  // dead lanes shadow the last env (keeps DPP quads uniform), never store
     const bool lead = live && leg == 0;
-    const int L = M->n_links, F = LEGS;
+    const int L = HOT0(m_n_links), F = LEGS;
     const int b0 = 1 + 3 * leg;            // first body of this lane's chain
     const int d0 = 3 * leg;                // first dof
-    const int foot_link = M->foot_link[leg];
+    const int foot_link = leg == 0 ? HOT0(m_foot_link[0]) : (leg == 1 ? HOT0(m_foot_link[1]) : (leg == 2 ? HOT0(m_foot_link[2]) : HOT0(m_foot_link[3])));
     int foot_slot = 0;                     // rank of this foot among feet in link order (feet_indices)
 #pragma unroll
-    for (int k = 0; k < LEGS; k++) foot_slot += (M->foot_link[k] < foot_link) ? 1 : 0;
+    for (int k = 0; k < LEGS; k++) foot_slot += (HOT0(m_foot_link[k]) < foot_link) ? 1 : 0;
 
     // ---------------- PRE: clip + action history (legged_robot.py:230-239) -----------------
     float act[3], last_act[3], llast_act[3];
     if (DO_PRE) {
-        const float ca = H.clip_actions;
+        const float ca = HOT0(clip_actions);
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             float prev = B.actions[e * A + d0 + j], prev2 = B.last_actions[e * A + d0 + j];
@@ -484,9 +519,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     float es[LG_R_COUNT];
 #pragma unroll
     for (int k = 0; k < LG_R_COUNT; k++) es[k] = 0.f;
-    float cr[17];
-#pragma unroll
-    for (int k = 0; k < 17; k++) cr[k] = 0.f;
+    int crv = 0;   // command / behaviour ranges (runtime buffer): lane k holds entry k, read with v_readlane
     V3 origin_pre = v3(0, 0, 0);
     // physics-side start-of-kernel loads: snapshot sources and per-env dynamics parameters
     V3 snap_fv = v3(0, 0, 0), snap_blv = v3(0, 0, 0), snap_bav = v3(0, 0, 0), dr_com = v3(0, 0, 0), dr_joint = v3(0, 0, 0);
@@ -505,9 +538,6 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         }
         if (B.joint_armature) dr_joint = v3(B.joint_armature[e], B.joint_friction[e], B.joint_damping[e]);
     }
-    float scl[LG_R_COUNT];          // reward scales: one batch of scalar loads instead of one exposed s_load per `if`
-#pragma unroll
-    for (int k = 0; k < LG_R_COUNT; k++) scl[k] = DO_MDP ? T->reward_scales[k] : 0.f;
     if (DO_MDP) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -515,18 +545,17 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             rdof_lo[j] = T->reset_dof_lo[d0 + j]; rdof_span[j] = T->reset_dof_span[d0 + j];
             nv_q[j] = T->noise_vec[9 + d0 + j]; nv_qd[j] = T->noise_vec[9 + A + d0 + j]; nv_act[j] = T->noise_vec[9 + 2 * A + d0 + j];
         }
-        if (H.obs_layout == LG_OBS_TRON1_EE) { nv_clk[0] = T->noise_vec[9 + 3 * A + foot_slot]; nv_clk[1] = T->noise_vec[9 + 3 * A + LEGS + foot_slot]; }
+        if (HOT0(obs_layout) == LG_OBS_TRON1_EE) { nv_clk[0] = T->noise_vec[9 + 3 * A + foot_slot]; nv_clk[1] = T->noise_vec[9 + 3 * A + LEGS + foot_slot]; }
         cmd0 = B.commands[4 * e]; cmd1 = B.commands[4 * e + 1]; cmd2 = B.commands[4 * e + 2]; cmd3 = B.commands[4 * e + 3];
         ep_len = B.episode_length_buf[e];
         fail_buf = B.fail_buf[e];
         air = B.feet_air_time[e * F + foot_slot];
         last_contact = B.last_contacts[e * F + foot_slot];
         origin_pre = ld3(B.env_origins + 3 * e);
-#pragma unroll
-        for (int k = 0; k < 17; k++) cr[k] = B.command_ranges[k];
+        crv = reinterpret_cast<const int *>(B.command_ranges)[min((int)(threadIdx.x & 63), LG_CMD_RANGE_FLOATS - 1)];
         if (lead) {
 #pragma unroll
-            for (int k = 0; k < LG_R_COUNT; k++) es[k] = scl[k] != 0.f ? B.episode_sums[(size_t)k * N + e] : 0.f;
+            for (int k = 0; k < LG_R_COUNT; k++) es[k] = HOT0(reward_scales[k]) != 0.f ? B.episode_sums[(size_t)k * N + e] : 0.f;
         }
     }
 
@@ -538,11 +567,35 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     V3 foot_p, foot_v, last_foot_v = v3(0, 0, 0);
     float foot_hmean = 0.f, foot_hmax = 0.f;  // mean / max of the 9 terrain heights around this lane's foot (a8)
     float mean_height = 0.f;         // mean over the height-sample grid of (base_z - h) is formed from this (a7)
-    const int P = H.o_n_height_points;
+    const int P = HOT0(o_n_height_points);
 
     // compiler-level memory barrier: every load above is issued before anything below (LLVM otherwise sinks each one
     // next to its consumer, where its full round trip is exposed); no hardware wait is emitted here
     asm volatile("" ::: "memory");
+    sHot[threadIdx.x] = hv0; sHot[threadIdx.x + 64] = hv1; sHot[threadIdx.x + 128] = hv2; sHot[threadIdx.x + 192] = hv3; sHot[threadIdx.x + 256] = crv;
+    sMraw[threadIdx.x] = stg0; sMraw[threadIdx.x + BLOCK] = stg1; sMraw[threadIdx.x + 2 * BLOCK] = stg2; sMraw[threadIdx.x + 3 * BLOCK] = stg3;
+    // MDP working set -> LDS for the duration of the physics (it arrived in the same load burst; parking it here keeps
+    // ~70 registers per lane free in the sub-step loop).  Layout [value][lane]: conflict-free.
+    constexpr bool STASH = DO_MDP && DO_SIM;
+    constexpr int NST = LG_R_COUNT + 36;
+    __shared__ float sSt[STASH ? NST : 1][BLOCK];
+    if (STASH) {
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < LG_R_COUNT; k++) sSt[k][t] = es[k];
+        int c = LG_R_COUNT;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            sSt[c++][t] = soft_lo[j]; sSt[c++][t] = soft_hi[j]; sSt[c++][t] = rdof_lo[j]; sSt[c++][t] = rdof_span[j];
+            sSt[c++][t] = nv_q[j]; sSt[c++][t] = nv_qd[j]; sSt[c++][t] = nv_act[j];
+        }
+        sSt[c++][t] = nv_clk[0]; sSt[c++][t] = nv_clk[1];
+        sSt[c++][t] = cmd0; sSt[c++][t] = cmd1; sSt[c++][t] = cmd2; sSt[c++][t] = cmd3;
+        sSt[c++][t] = __int_as_float(ep_len); sSt[c++][t] = __int_as_float((int)fail_buf); sSt[c++][t] = air;
+        sSt[c++][t] = __int_as_float(last_contact);
+        sSt[c++][t] = origin_pre.x; sSt[c++][t] = origin_pre.y; sSt[c++][t] = origin_pre.z;
+    }
+    __syncthreads();
     STAMP(2);
     // ---- prologue stores: only now, after every start-of-kernel load has been issued and awaited.  vmcnt counts
     //      loads and stores together in issue order, so a load queued behind stores waits for the full HBM write
@@ -572,7 +625,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         // per-env dynamics parameters (genesis_simulator.py:665-739), fetched in the prologue batch
         const float mass0 = M->mass[0] + dr_mass;
         V3 com0 = ld3(M->com[0]) + dr_com;
-        const float mu = H.o_terrain_friction * dr_fric;
+        const float mu = HOT(o_terrain_friction) * dr_fric;
         float kps[3], kds[3], arm[3], jdamp[3], jfric[3];
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -582,11 +635,11 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             jfric[j] = B.joint_friction ? dr_joint.y : M->frictionloss[d0 + j];
             jdamp[j] = B.joint_damping ? dr_joint.z : M->damping[d0 + j];
         }
-        const float dt = H.o_dt, kc = H.o_contact_k, kappa = kc * dt + H.o_contact_b, margin = H.o_contact_margin;
-        const float kl = H.o_limit_k, kapl = kl * dt + H.o_limit_b;
-        const V3 grav = v3(0.f, 0.f, H.o_gravity_z);
+        const float dt = HOT(o_dt), kc = HOT(o_contact_k), kappa = kc * dt + HOT(o_contact_b), margin = HOT(o_contact_margin);
+        const float kl = HOT(o_limit_k), kapl = kl * dt + HOT(o_limit_b);
+        const V3 grav = v3(0.f, 0.f, HOT(o_gravity_z));
         const S3 I0 = {M->inertia[0][0], M->inertia[0][1], M->inertia[0][2], M->inertia[0][3], M->inertia[0][4], M->inertia[0][5]};
-        const int fs = M->foot_sphere[leg];
+        const int fs = leg == 0 ? HOT(m_foot_sphere[0]) : (leg == 1 ? HOT(m_foot_sphere[1]) : (leg == 2 ? HOT(m_foot_sphere[2]) : HOT(m_foot_sphere[3])));
         const V3 foot_c_loc = ld3(M->sph_pos[fs]);
         const float foot_r = M->sph_r[fs];
 
@@ -603,7 +656,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             const S3 t = {M->inertia[b][0], M->inertia[b][1], M->inertia[b][2], M->inertia[b][3], M->inertia[b][4], M->inertia[b][5]};
             LIc[j] = t;
             Lqlo[j] = M->q_lo[d0 + j]; Lqhi[j] = M->q_hi[d0 + j]; Leff[j] = M->effort[d0 + j];
-            Lvlim[j] = H.o_joint_vel_clamp * M->vel_limit[d0 + j];
+            Lvlim[j] = HOT(o_joint_vel_clamp) * M->vel_limit[d0 + j];
         }
         // spheres: up to SPH0/SPH1/SPH2 on the three chain bodies (foot sphere excluded) and SPHB of the base
         // spheres dealt round-robin to the lanes of the env; counts are validated by lg_create
@@ -643,7 +696,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         STAMP(3);
         const bool jrot_identity = p.jrot_identity != 0;
 
-        for (int sub = 0; sub < H.o_decimation; sub++) {
+        for (int sub = 0; sub < HOT(o_decimation); sub++) {
             const M3 Rb = quat_to_mat(qx, qy, qz, qw);
             // ---- forward kinematics + velocities of the chain (root -> leaf) -----------------
             BodyKin K[3];
@@ -714,7 +767,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             float tau[3];
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                const float t = kps[j] * (act[j] * H.o_action_scale + q0l[j] - q[j]) - kds[j] * qd[j];
+                const float t = kps[j] * (act[j] * HOT(o_action_scale) + q0l[j] - q[j]) - kds[j] * qd[j];
                 torque[j] = t;
                 const float lim = Leff[j];
                 tau[j] = clampf(t, -lim, lim) - jdamp[j] * qd[j] - jfric[j] * clampf(qd[j] * 20.f, -1.f, 1.f);
@@ -821,8 +874,8 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             for (int j = 0; j < 3; j++) {
                 const float lo = Lqlo[j], hi = Lqhi[j];
                 lim_s[j] = 0.f; lim_e[j] = 0.f;
-                if (q[j] < lo + H.o_limit_margin) { lim_s[j] = 1.f; lim_e[j] = lo - q[j]; lact = true; }
-                else if (q[j] > hi - H.o_limit_margin) { lim_s[j] = -1.f; lim_e[j] = q[j] - hi; lact = true; }
+                if (q[j] < lo + HOT(o_limit_margin)) { lim_s[j] = 1.f; lim_e[j] = lo - q[j]; lact = true; }
+                else if (q[j] > hi - HOT(o_limit_margin)) { lim_s[j] = -1.f; lim_e[j] = q[j] - hi; lact = true; }
             }
             const int any = quad_or<LEGS>((fact || lact) ? 1 : 0);
             float dqdd[3] = {0.f, 0.f, 0.f};
@@ -858,7 +911,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                     vfree = v3(dot(cn, vf), dot(ct1, vf), dot(ct2, vf));
                 }
                 V3 resp_c = v3(0, 0, 0);  // contact-frame acceleration response to the current force set
-                for (int it = 0; it < H.o_contact_iters; it++) {
+                for (int it = 0; it < HOT(o_contact_iters); it++) {
                     // foot: velocity it would have without its own force, then the local law
                     V3 fnew = v3(0, 0, 0);
                     if (fact) {
@@ -882,8 +935,11 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                     for (int j = 0; j < 3; j++) {
                         tl[j] = 0.f;
                         if (lim_s[j] != 0.f) {
-                            const float vin = -lim_s[j] * (qd[j] + dt * (qdd[j] + dqdd[j])) + dt * lim_T[j] * J[j].dinv;
-                            const float Tn = (kl * lim_e[j] + kapl * vin) * rcp(1.f + kapl * dt * J[j].dinv);
+                            // compliance: 1/d on the first sweep, then the response measured in the previous one
+                            float C = J[j].dinv;
+                            if (it > 0 && lim_T[j] > 0.f) C = fminf(fmaxf(lim_s[j] * dqdd[j] * rcp(lim_T[j]), C), 8.f * C);
+                            const float vin = -lim_s[j] * (qd[j] + dt * (qdd[j] + dqdd[j])) + dt * lim_T[j] * C;
+                            const float Tn = (kl * lim_e[j] + kapl * vin) * rcp(1.f + kapl * dt * C);
                             lim_T[j] = fmaxf(Tn, 0.f);
                             tl[j] = lim_s[j] * lim_T[j];
                         }
@@ -904,7 +960,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             {
                 const V3 alpha = a0.a + da0.a;
                 const V3 alin = a0.l + da0.l + cross(ww, vw);   // spatial -> classical at O
-                const float mv = H.o_max_base_lin_vel, mw = H.o_max_base_ang_vel;
+                const float mv = HOT(o_max_base_lin_vel), mw = HOT(o_max_base_ang_vel);
                 vw = v3(clampf(vw.x + dt * alin.x, -mv, mv), clampf(vw.y + dt * alin.y, -mv, mv), clampf(vw.z + dt * alin.z, -mv, mv));
                 ww = v3(clampf(ww.x + dt * alpha.x, -mw, mw), clampf(ww.y + dt * alpha.y, -mw, mw), clampf(ww.z + dt * alpha.z, -mw, mw));
 #pragma unroll
@@ -937,7 +993,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             for (int j = 0; j < 3; j++) chk += q[j] + qd[j];
             const int bad = quad_or<LEGS>(isfinite(chk) ? 0 : 1);
             if (bad) {
-                pos = v3(H.o_base_init_pos[0], H.o_base_init_pos[1], H.o_base_init_pos[2]);
+                pos = v3(HOT(o_base_init_pos[0]), HOT(o_base_init_pos[1]), HOT(o_base_init_pos[2]));
                 if (B.env_origins) pos += ld3(B.env_origins + 3 * e);
                 vw = ww = v3(0, 0, 0);
                 qx = qy = qz = 0.f; qw = 1.f;
@@ -947,8 +1003,8 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             }
         }
         // out-of-terrain teleport (genesis_simulator.py:612-628)
-        if (pos.x >= H.o_bound_x[1] || pos.x <= H.o_bound_x[0] || pos.y >= H.o_bound_y[1] || pos.y <= H.o_bound_y[0]) {
-            pos = v3(H.o_base_init_pos[0], H.o_base_init_pos[1], H.o_base_init_pos[2]);
+        if (pos.x >= HOT(o_bound_x[1]) || pos.x <= HOT(o_bound_x[0]) || pos.y >= HOT(o_bound_y[1]) || pos.y <= HOT(o_bound_y[0])) {
+            pos = v3(HOT(o_base_init_pos[0]), HOT(o_base_init_pos[1]), HOT(o_base_init_pos[2]));
             if (B.env_origins) pos += ld3(B.env_origins + 3 * e);
         }
         eul.x = atan2f(2.f * (qw * qx + qy * qz), qw * qw - qx * qx - qy * qy + qz * qz);
@@ -1022,11 +1078,11 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 if (live) B.measured_heights[(size_t)e * P + k] = h;
             }
             mean_height = quad_sum<LEGS>(acc) / (float)P;
-            if (H.o_feet_terrain_info) {
-                int px = (int)((foot_p.x + H.o_border) / H.o_hscale), py = (int)((foot_p.y + H.o_border) / H.o_hscale);
-                px = min(max(px, 0), H.o_terrain_rows - 2);
-                py = min(max(py, 0), H.o_terrain_cols - 2);
-                const int C = H.o_terrain_cols, xm = max(px - 1, 0), ym = max(py - 1, 0);
+            if (HOT(o_feet_terrain_info)) {
+                int px = (int)((foot_p.x + HOT(o_border)) / HOT(o_hscale)), py = (int)((foot_p.y + HOT(o_border)) / HOT(o_hscale));
+                px = min(max(px, 0), HOT(o_terrain_rows) - 2);
+                py = min(max(py, 0), HOT(o_terrain_cols) - 2);
+                const int C = HOT(o_terrain_cols), xm = max(px - 1, 0), ym = max(py - 1, 0);
                 const int16_t *hf = p.hf;
                 // order of genesis_simulator.py:591-599
                 const int hh[9] = {hf[xm * C + py], hf[(px + 1) * C + py], hf[px * C + ym], hf[px * C + py + 1], hf[px * C + py],
@@ -1034,14 +1090,14 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 float sum = 0.f, mx = -1e30f;
 #pragma unroll
                 for (int k = 0; k < 9; k++) {
-                    const float hv = (float)hh[k] * H.o_vscale;
+                    const float hv = (float)hh[k] * HOT(o_vscale);
                     sum += hv; mx = fmaxf(mx, hv);
                     if (live) B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k] = hv;
                 }
                 foot_hmean = sum / 9.f; foot_hmax = mx;
                 // normal from RAW int16 differences over 2*hscale -- the reference does not apply the
                 // vertical scale here (genesis_simulator.py:601-606); reproduced
-                const float dx = (float)(hh[1] - hh[0]) / (H.o_hscale * 2.f), dy = (float)(hh[3] - hh[2]) / (H.o_hscale * 2.f);
+                const float dx = (float)(hh[1] - hh[0]) / (HOT(o_hscale) * 2.f), dy = (float)(hh[3] - hh[2]) / (HOT(o_hscale) * 2.f);
                 const float nn = sqrtf(dx * dx + dy * dy + 1.f);
                 if (live) st3(B.normal_vector_around_feet + ((size_t)e * F + foot_slot) * 3, v3(dx / nn, dy / nn, -1.f / nn));
             }
@@ -1075,7 +1131,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             float acc = 0.f;
             for (int k = leg; k < P; k += LEGS) acc += pos.z - B.measured_heights[(size_t)e * P + k];
             mean_height = quad_sum<LEGS>(acc) / (float)P;
-            if (H.o_feet_terrain_info) {
+            if (HOT(o_feet_terrain_info)) {
                 float sum = 0.f, mx = -1e30f;
 #pragma unroll
                 for (int k = 0; k < 9; k++) { const float hv = B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k]; sum += hv; mx = fmaxf(mx, hv); }
@@ -1086,58 +1142,74 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
 
     STAMP(5);
     if (!DO_POST && !DO_RESET) return;
+    if (STASH) {   // bring the MDP working set back from LDS
+        const int t = threadIdx.x;
+#pragma unroll
+        for (int k = 0; k < LG_R_COUNT; k++) es[k] = sSt[k][t];
+        int c = LG_R_COUNT;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            soft_lo[j] = sSt[c++][t]; soft_hi[j] = sSt[c++][t]; rdof_lo[j] = sSt[c++][t]; rdof_span[j] = sSt[c++][t];
+            nv_q[j] = sSt[c++][t]; nv_qd[j] = sSt[c++][t]; nv_act[j] = sSt[c++][t];
+        }
+        nv_clk[0] = sSt[c++][t]; nv_clk[1] = sSt[c++][t];
+        cmd0 = sSt[c++][t]; cmd1 = sSt[c++][t]; cmd2 = sSt[c++][t]; cmd3 = sSt[c++][t];
+        ep_len = __float_as_int(sSt[c++][t]); fail_buf = (long long)__float_as_int(sSt[c++][t]); air = sSt[c++][t];
+        last_contact = __float_as_int(sSt[c++][t]);
+        origin_pre.x = sSt[c++][t]; origin_pre.y = sSt[c++][t]; origin_pre.z = sSt[c++][t];
+    }
 
     // ======================= MDP: legged_robot.py:55-168, 300-334 ============================
     RandSrc rs;
-    rs.in = B.rand_in ? B.rand_in + (size_t)e * H.slots.n_slots : nullptr;
+    rs.in = B.rand_in ? B.rand_in + (size_t)e * HOT(slots.n_slots) : nullptr;
     {
-        const unsigned long long gid = (unsigned long long)(H.env_id_offset + e);
-        rs.k0 = (unsigned)(H.seed & 0xFFFFFFFFu); rs.k1 = (unsigned)(H.seed >> 32);
+        const unsigned long long gid = (unsigned long long)(HOT(env_id_offset) + e);
+        rs.k0 = (unsigned)(HOT(seed) & 0xFFFFFFFFu); rs.k1 = (unsigned)(HOT(seed) >> 32);
         rs.e_lo = (unsigned)(gid & 0xFFFFFFFFu); rs.e_hi = (unsigned)(gid >> 32);
         rs.step = (unsigned)p.counter;
     }
-    const float cdt = H.control_dt;
+    const float cdt = HOT(control_dt);
     bool reset = false, time_out = false;
     float total = 0.f;
     float *esum = B.episode_sums;
 
     // ---- periodic-gait task state (go2_wtw.py:295-346): per-env scalars + this lane's foot entries
-    const bool WTW = H.gait_mode == 1, BIPED = H.gait_mode == 2, GAIT = WTW || BIPED;
-    float *ts = B.task_state ? B.task_state + (size_t)e * H.task_state_width : nullptr;
+    const bool WTW = HOT(gait_mode) == 1, BIPED = HOT(gait_mode) == 2, GAIT = WTW || BIPED;
+    float *ts = B.task_state ? B.task_state + (size_t)e * HOT(task_state_width) : nullptr;
     float gait_time = 0.f, phi = 0.f, gait_period = 1.f, bh_tgt = 0.f, fc_tgt = 0.f, pitch_tgt = 0.f, theta = 0.f, expC = 0.f;
     if (WTW) {
         gait_time = ts[0]; phi = ts[1]; gait_period = ts[2]; bh_tgt = ts[3]; fc_tgt = ts[4]; pitch_tgt = ts[5];
         theta = ts[6 + foot_slot]; expC = ts[18 + foot_slot];
     }
     if (BIPED) {   // layout LG_TASK_STATE_BIPED (tron1_pf_ee.py:167-184)
-        gait_time = ts[0]; phi = ts[1]; gait_period = H.gait_period_fixed;
+        gait_time = ts[0]; phi = ts[1]; gait_period = HOT(gait_period_fixed);
         theta = ts[4 + foot_slot]; expC = ts[10 + foot_slot];
     }
     auto resample_behavior = [&](int slot) {   // go2_wtw.py:180-218
-        gait_period = (cr[9] - cr[8]) * rs.draw(slot) + cr[8];
-        bh_tgt = (cr[11] - cr[10]) * rs.draw(slot + 1) + cr[10];
-        fc_tgt = (cr[13] - cr[12]) * rs.draw(slot + 2) + cr[12];
-        pitch_tgt = (cr[15] - cr[14]) * rs.draw(slot + 3) + cr[14];
+        gait_period = (CR(9) - CR(8)) * rs.draw(slot) + CR(8);
+        bh_tgt = (CR(11) - CR(10)) * rs.draw(slot + 1) + CR(10);
+        fc_tgt = (CR(13) - CR(12)) * rs.draw(slot + 2) + CR(12);
+        pitch_tgt = (CR(15) - CR(14)) * rs.draw(slot + 3) + CR(14);
         // one gait index per call for the whole batch (quirk 6): env-independent Philox counter
         float ug;
         if (rs.in) ug = rs.in[slot + 4];
         else { RandSrc g = rs; g.e_lo = 0xFFFFFFFFu; g.e_hi = 0xFFFFFFFFu; ug = g.draw(slot + 4); }
-        const int ng = (int)cr[16];
+        const int ng = (int)CR(16);
         const int sel = min((int)floorf(ug * (float)ng), ng - 1);
         theta = T->theta_table[sel][foot_slot];
         // pronk / bound gaits keep the lowest clearance target (go2_wtw.py:212-218); the lower bound
         // never moves, so clamping at the env's own resample is equivalent to the reference's all-env pass
         const float t0 = T->theta_table[sel][0], t1 = T->theta_table[sel][1], t2 = T->theta_table[sel][2], t3 = T->theta_table[sel][3];
-        if (t0 == 0.f && t1 == 0.f && ((t2 == 0.f && t3 == 0.f) || (t2 == 0.5f && t3 == 0.5f))) fc_tgt = cr[12];
+        if (t0 == 0.f && t1 == 0.f && ((t2 == 0.f && t3 == 0.f) || (t2 == 0.5f && t3 == 0.5f))) fc_tgt = CR(12);
     };
 
     auto resample_commands = [&](int slot) {  // legged_robot.py:317-334
         float u0, u1, u2;
         rs.draw3(slot, u0, u1, u2);
-        cmd0 = (cr[1] - cr[0]) * u0 + cr[0];
-        cmd1 = (cr[3] - cr[2]) * u1 + cr[2];
-        if (H.heading_command) cmd3 = (cr[7] - cr[6]) * u2 + cr[6];
-        else cmd2 = (cr[5] - cr[4]) * u2 + cr[4];
+        cmd0 = (CR(1) - CR(0)) * u0 + CR(0);
+        cmd1 = (CR(3) - CR(2)) * u1 + CR(2);
+        if (HOT(heading_command)) cmd3 = (CR(7) - CR(6)) * u2 + CR(6);
+        else cmd2 = (CR(5) - CR(4)) * u2 + CR(4);
         const float keep = sqrtf(cmd0 * cmd0 + cmd1 * cmd1 + cmd2 * cmd2) > 0.2f ? 1.f : 0.f;
         cmd0 *= keep; cmd1 *= keep; cmd2 *= keep;
     };
@@ -1145,26 +1217,26 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     if (DO_POST) {
         ep_len += 1;                                                   // legged_robot.py:60
         // ---- _post_physics_step_callback (legged_robot.py:300-315) ----
-        if (ep_len % H.resample_steps == 0) resample_commands(H.slots.cb_cmd);
-        if (H.heading_command) {
+        if (ep_len % HOT(resample_steps) == 0) resample_commands(HOT(slots.cb_cmd));
+        if (HOT(heading_command)) {
             // forward = quat_apply(base_quat, [1,0,0]) (math_utils.py:34-40)
             const V3 xyz = v3(qx, qy, qz), bvec = v3(1.f, 0.f, 0.f);
             const V3 t = cross(xyz, bvec) * 2.f;
             const V3 fwd = bvec + t * qw + cross(xyz, t);
             const float heading = atan2f(fwd.y, fwd.x);
-            cmd2 = clampf(0.5f * wrap_to_pi(cmd3 - heading), H.yaw_clip[0], H.yaw_clip[1]);
+            cmd2 = clampf(0.5f * wrap_to_pi(cmd3 - heading), HOT(yaw_clip[0]), HOT(yaw_clip[1]));
         }
-        if (H.push_interval > 0 && (p.counter % H.push_interval) == 0) {   // genesis_simulator.py:150-158
-            const float m = H.max_push_vel_xy;
-            const float px = (m + m) * rs.draw(H.slots.push) - m, py = (m + m) * rs.draw(H.slots.push + 1) - m;
+        if (HOT(push_interval) > 0 && (p.counter % HOT(push_interval)) == 0) {   // genesis_simulator.py:150-158
+            const float m = HOT(max_push_vel_xy);
+            const float px = (m + m) * rs.draw(HOT(slots.push)) - m, py = (m + m) * rs.draw(HOT(slots.push) + 1) - m;
             vw.x += px; vw.y += py;
             if (lead) {
                 B.rand_push_vels[3 * e] = px; B.rand_push_vels[3 * e + 1] = py;
                 B.base_lin_vel_w[3 * e] = vw.x; B.base_lin_vel_w[3 * e + 1] = vw.y;
             }
         }
-        if (WTW && H.behavior_resample_steps > 0 && ep_len % H.behavior_resample_steps == 0)   // go2_wtw.py:258-263
-            resample_behavior(H.slots.task_cb);
+        if (WTW && HOT(behavior_resample_steps) > 0 && ep_len % HOT(behavior_resample_steps) == 0)   // go2_wtw.py:258-263
+            resample_behavior(HOT(slots.task_cb));
 #ifdef LG_DBG_RET_CALLBACK
         if (p.counter >= 0) { if (lead) B.rew_buf[e] = cmd2 + (float)ep_len; return; }
 #endif
@@ -1177,18 +1249,17 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             if ((M->term_link_mask >> (l0 + k)) & 1u) fail |= norm(f_link[k]) > 10.0f ? 1 : 0;
         fail = quad_or<LEGS>(fail);
         if (M->term_link_mask & 1u) fail |= norm(f_base) > 10.0f ? 1 : 0;
-        fail |= pg.z > H.max_projected_gravity ? 1 : 0;
+        fail |= pg.z > HOT(max_projected_gravity) ? 1 : 0;
         fail_buf += fail;
-        time_out = (float)ep_len > H.max_episode_length;
-        reset = ((float)fail_buf > H.fail_threshold) || time_out;
+        time_out = (float)ep_len > HOT(max_episode_length);
+        reset = ((float)fail_buf > HOT(fail_threshold)) || time_out;
 
 #ifdef LG_DBG_RET_TERM
         if (p.counter >= 0) { if (lead) B.rew_buf[e] = cmd2 + (float)fail_buf + (reset ? 1.f : 0.f); return; }
 #endif
         // ---- compute_reward (legged_robot.py:150-168), alphabetical order ----
-        const float (&sc)[LG_R_COUNT] = scl;
         auto add = [&](int id, float r) {
-            const float rew = r * sc[id];
+            const float rew = r * HOT(reward_scales[id]);
             total += rew;
             es[id] += rew;
         };
@@ -1201,32 +1272,32 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             const float two_pi = 6.283185307179586f;
             float ph = phi + theta;
             ph = (ph - floorf(ph)) * two_pi;                             // (phi + theta) % 1.0, operands >= 0
-            const float b_sw = H.b_swing * two_pi;
+            const float b_sw = HOT(b_swing) * two_pi;
             const float c_frc = (ph >= 0.f && ph < b_sw) ? -1.f : 0.f;
             const float c_spd = (ph >= b_sw && ph < two_pi) ? -1.f : 0.f;
             expC = c_frc;
-            return expf(quad_sum<LEGS>(c_spd * norm(foot_v) + c_frc * norm(f_link[3])));
+            return __expf(quad_sum<LEGS>(c_spd * norm(foot_v) + c_frc * norm(f_link[3])));
         };
-        if (sc[LG_R_ACTION_RATE] != 0.f) {                              // :495-497
+        if (HOT(reward_scales[LG_R_ACTION_RATE]) != 0.f) {                              // :495-497
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) { const float d = last_act[j] - act[j]; s += d * d; }
             add(LG_R_ACTION_RATE, quad_sum<LEGS>(s));
         }
-        if (sc[LG_R_ACTION_SMOOTHNESS] != 0.f) {                        // :499-503
+        if (HOT(reward_scales[LG_R_ACTION_SMOOTHNESS]) != 0.f) {                        // :499-503
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) { const float d = act[j] - 2.f * last_act[j] + llast_act[j]; s += d * d; }
             add(LG_R_ACTION_SMOOTHNESS, quad_sum<LEGS>(s));
         }
-        if (sc[LG_R_ANG_VEL_XY] != 0.f) add(LG_R_ANG_VEL_XY, bav.x * bav.x + bav.y * bav.y);   // :462-464
-        if (sc[LG_R_BASE_HEIGHT] != 0.f) {                              // :470-476
+        if (HOT(reward_scales[LG_R_ANG_VEL_XY]) != 0.f) add(LG_R_ANG_VEL_XY, bav.x * bav.x + bav.y * bav.y);   // :462-464
+        if (HOT(reward_scales[LG_R_BASE_HEIGHT]) != 0.f) {                              // :470-476
             // plane: measured_heights is the all-zero buffer of genesis_simulator.py:494 -> base z
-            const float d = (P > 0 ? mean_height : pos.z) - H.base_height_target;
+            const float d = (P > 0 ? mean_height : pos.z) - HOT(base_height_target);
             add(LG_R_BASE_HEIGHT, d * d);
         }
-        if (sc[LG_R_BIPED_PERIODIC_GAIT] != 0.f) add(LG_R_BIPED_PERIODIC_GAIT, gait_reward());  // tron1_pf_ee.py:426-433
-        if (sc[LG_R_COLLISION] != 0.f) {                                // :505-512
+        if (HOT(reward_scales[LG_R_BIPED_PERIODIC_GAIT]) != 0.f) add(LG_R_BIPED_PERIODIC_GAIT, gait_reward());  // tron1_pf_ee.py:426-433
+        if (HOT(reward_scales[LG_R_COLLISION]) != 0.f) {                                // :505-512
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; k++)
@@ -1235,19 +1306,19 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             if (M->pen_link_mask & 1u) s += norm(f_base) > 0.1f ? 1.f : 0.f;
             add(LG_R_COLLISION, s);
         }
-        if (sc[LG_R_DOF_ACC] != 0.f) {                                  // :490-493
+        if (HOT(reward_scales[LG_R_DOF_ACC]) != 0.f) {                                  // :490-493
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) { const float d = (last_qd[j] - qd[j]) / cdt; s += d * d; }
             add(LG_R_DOF_ACC, quad_sum<LEGS>(s));
         }
-        if (sc[LG_R_DOF_CLOSE_TO_DEFAULT] != 0.f) {                     // :571-573
+        if (HOT(reward_scales[LG_R_DOF_CLOSE_TO_DEFAULT]) != 0.f) {                     // :571-573
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) s += dq0[j] * dq0[j];
             add(LG_R_DOF_CLOSE_TO_DEFAULT, quad_sum<LEGS>(s));
         }
-        if (sc[LG_R_DOF_POS_LIMITS] != 0.f) {                           // :518-522
+        if (HOT(reward_scales[LG_R_DOF_POS_LIMITS]) != 0.f) {                           // :518-522
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) {
@@ -1256,108 +1327,108 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             }
             add(LG_R_DOF_POS_LIMITS, quad_sum<LEGS>(s));
         }
-        if (sc[LG_R_DOF_POS_STAND_STILL] != 0.f) {                      // :561-563
+        if (HOT(reward_scales[LG_R_DOF_POS_STAND_STILL]) != 0.f) {                      // :561-563
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) s += dq0[j] * dq0[j];
             add(LG_R_DOF_POS_STAND_STILL, quad_sum<LEGS>(s) * (cmd_xyz < 0.1f ? 1.f : 0.f));
         }
-        if (sc[LG_R_DOF_POWER] != 0.f) {                                // :486-488
+        if (HOT(reward_scales[LG_R_DOF_POWER]) != 0.f) {                                // :486-488
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) s += fabsf(torque[j] * qd[j]);
             add(LG_R_DOF_POWER, quad_sum<LEGS>(s));
         }
-        if (sc[LG_R_DOF_VEL] != 0.f) {                                  // :482-484
+        if (HOT(reward_scales[LG_R_DOF_VEL]) != 0.f) {                                  // :482-484
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) s += qd[j] * qd[j];
             add(LG_R_DOF_VEL, quad_sum<LEGS>(s));
         }
-        if (sc[LG_R_DOF_VEL_STAND_STILL] != 0.f) {                      // :557-559
+        if (HOT(reward_scales[LG_R_DOF_VEL_STAND_STILL]) != 0.f) {                      // :557-559
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) s += fabsf(qd[j]);
             add(LG_R_DOF_VEL_STAND_STILL, quad_sum<LEGS>(s) * (cmd_xyz < 0.1f ? 1.f : 0.f));
         }
-        if (sc[LG_R_FEET_AIR_TIME] != 0.f) {                            // :545-555 (stateful)
+        if (HOT(reward_scales[LG_R_FEET_AIR_TIME]) != 0.f) {                            // :545-555 (stateful)
             const int contact = f_link[3].z > 1.0f ? 1 : 0;
             const int filt = contact | last_contact;
             last_contact = contact;
             const float first = (air > 0.f ? 1.f : 0.f) * (float)filt;
             air += cdt;
-            float r = quad_sum<LEGS>((air - H.feet_air_time_threshold) * first);
+            float r = quad_sum<LEGS>((air - HOT(feet_air_time_threshold)) * first);
             r *= cmd_xy > 0.1f ? 1.f : 0.f;
             air *= filt ? 0.f : 1.f;
             add(LG_R_FEET_AIR_TIME, r);
         }
-        if (sc[LG_R_FEET_CONTACT_STAND_STILL] != 0.f) {                 // :565-569
+        if (HOT(reward_scales[LG_R_FEET_CONTACT_STAND_STILL]) != 0.f) {                 // :565-569
             const float cnt = quad_sum<LEGS>(f_link[3].z > 0.1f ? 1.f : 0.f);
             add(LG_R_FEET_CONTACT_STAND_STILL, (cnt == (float)LEGS ? 1.f : 0.f) * (cmd_xyz < 0.1f ? 1.f : 0.f));
         }
-        if (sc[LG_R_FEET_DISTANCE] != 0.f) {                            // tron1_pf_ee.py:458-463 (two feet: lane pair)
+        if (HOT(reward_scales[LG_R_FEET_DISTANCE]) != 0.f) {                            // tron1_pf_ee.py:458-463 (two feet: lane pair)
             const float ox = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(foot_p.x), 0xB1, 0xF, 0xF, false));
             const float oy = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(foot_p.y), 0xB1, 0xF, 0xF, false));
             const float dxy = sqrtf((foot_p.x - ox) * (foot_p.x - ox) + (foot_p.y - oy) * (foot_p.y - oy));
-            add(LG_R_FEET_DISTANCE, fmaxf(0.f, H.foot_distance_threshold - dxy));
+            add(LG_R_FEET_DISTANCE, fmaxf(0.f, HOT(foot_distance_threshold) - dxy));
         }
-        if (sc[LG_R_FOOT_ACC] != 0.f) {                                 // :605-608
+        if (HOT(reward_scales[LG_R_FOOT_ACC]) != 0.f) {                                 // :605-608
             const V3 a = (foot_v - last_foot_v) * (1.f / cdt);
             add(LG_R_FOOT_ACC, quad_sum<LEGS>(dot(a, a)));
         }
-        if (sc[LG_R_FOOT_CLEARANCE] != 0.f) {                           // :575-588
+        if (HOT(reward_scales[LG_R_FOOT_CLEARANCE]) != 0.f) {                           // :575-588
             const float vxy = sqrtf(foot_v.x * foot_v.x + foot_v.y * foot_v.y);
             // go2_ee.py:136-150 measures the clearance above the mean terrain height around the foot
-            const float d = foot_p.z - (H.obs_layout == LG_OBS_GO2_EE ? foot_hmean : (H.obs_layout == LG_OBS_TRON1_EE ? foot_hmax : 0.f))
-                            - H.foot_clearance_target - H.foot_height_offset;   // tron1_pf_ee.py:442-456 uses the max
+            const float d = foot_p.z - (HOT(obs_layout) == LG_OBS_GO2_EE ? foot_hmean : (HOT(obs_layout) == LG_OBS_TRON1_EE ? foot_hmax : 0.f))
+                            - HOT(foot_clearance_target) - HOT(foot_height_offset);   // tron1_pf_ee.py:442-456 uses the max
             const float err = quad_sum<LEGS>(vxy * (d * d));
-            add(LG_R_FOOT_CLEARANCE, expf(-err / H.foot_clearance_sigma));
+            add(LG_R_FOOT_CLEARANCE, __expf(-err / HOT(foot_clearance_sigma)));
         }
-        if (sc[LG_R_FOOT_LANDING_VEL] != 0.f) {                         // :590-599
+        if (HOT(reward_scales[LG_R_FOOT_LANDING_VEL]) != 0.f) {                         // :590-599
             const bool c01 = f_link[3].z > 0.1f;
-            const bool land = ((foot_p.z - H.foot_height_offset) < H.about_landing_threshold) && !c01 && (foot_v.z < 0.f);
+            const bool land = ((foot_p.z - HOT(foot_height_offset)) < HOT(about_landing_threshold)) && !c01 && (foot_v.z < 0.f);
             const float vz = land ? foot_v.z : 0.f;
             add(LG_R_FOOT_LANDING_VEL, quad_sum<LEGS>(vz * vz));
         }
-        if (sc[LG_R_HIP_POS] != 0.f) add(LG_R_HIP_POS, quad_sum<LEGS>(dq0[0] * dq0[0]));   // go2_ee.py:152-159
-        if (sc[LG_R_KEEP_BALANCE] != 0.f) add(LG_R_KEEP_BALANCE, 1.f);                      // :601-603
-        if (sc[LG_R_LIN_VEL_Z] != 0.f) add(LG_R_LIN_VEL_Z, blv.z * blv.z);                  // :458-460
-        if (sc[LG_R_ORIENTATION] != 0.f) add(LG_R_ORIENTATION, pg.x * pg.x + pg.y * pg.y);  // :466-468
-        if (sc[LG_R_QUAD_PERIODIC_GAIT] != 0.f) add(LG_R_QUAD_PERIODIC_GAIT, gait_reward());   // go2_wtw.py:472-484
-        if (sc[LG_R_TORQUES] != 0.f) {                                  // :478-480
+        if (HOT(reward_scales[LG_R_HIP_POS]) != 0.f) add(LG_R_HIP_POS, quad_sum<LEGS>(dq0[0] * dq0[0]));   // go2_ee.py:152-159
+        if (HOT(reward_scales[LG_R_KEEP_BALANCE]) != 0.f) add(LG_R_KEEP_BALANCE, 1.f);                      // :601-603
+        if (HOT(reward_scales[LG_R_LIN_VEL_Z]) != 0.f) add(LG_R_LIN_VEL_Z, blv.z * blv.z);                  // :458-460
+        if (HOT(reward_scales[LG_R_ORIENTATION]) != 0.f) add(LG_R_ORIENTATION, pg.x * pg.x + pg.y * pg.y);  // :466-468
+        if (HOT(reward_scales[LG_R_QUAD_PERIODIC_GAIT]) != 0.f) add(LG_R_QUAD_PERIODIC_GAIT, gait_reward());   // go2_wtw.py:472-484
+        if (HOT(reward_scales[LG_R_TORQUES]) != 0.f) {                                  // :478-480
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) s += torque[j] * torque[j];
             add(LG_R_TORQUES, quad_sum<LEGS>(s));
         }
-        if (sc[LG_R_TRACKING_ANG_VEL] != 0.f) {                         // :539-543
+        if (HOT(reward_scales[LG_R_TRACKING_ANG_VEL]) != 0.f) {                         // :539-543
             const float d = cmd2 - bav.z;
-            add(LG_R_TRACKING_ANG_VEL, expf(-(d * d) / H.tracking_sigma));
+            add(LG_R_TRACKING_ANG_VEL, __expf(-(d * d) / HOT(tracking_sigma)));
         }
-        if (sc[LG_R_TRACKING_BASE_HEIGHT] != 0.f) {                     // go2_wtw.py:495-500 (plane: heights are zero)
+        if (HOT(reward_scales[LG_R_TRACKING_BASE_HEIGHT]) != 0.f) {                     // go2_wtw.py:495-500 (plane: heights are zero)
             // wtw: per-env target on the plane; tron1_pf_ee.py:435-440: fixed target, mean over the height samples
-            const float d = WTW ? pos.z - bh_tgt : (P > 0 ? mean_height : pos.z) - H.base_height_target;
-            add(LG_R_TRACKING_BASE_HEIGHT, expf(-(d * d) / H.base_height_sigma));
+            const float d = WTW ? pos.z - bh_tgt : (P > 0 ? mean_height : pos.z) - HOT(base_height_target);
+            add(LG_R_TRACKING_BASE_HEIGHT, __expf(-(d * d) / HOT(base_height_sigma)));
         }
-        if (sc[LG_R_TRACKING_FOOT_CLEARANCE] != 0.f) {                  // go2_wtw.py:507-519
+        if (HOT(reward_scales[LG_R_TRACKING_FOOT_CLEARANCE]) != 0.f) {                  // go2_wtw.py:507-519
             const float vxy = sqrtf(foot_v.x * foot_v.x + foot_v.y * foot_v.y);
-            const float d = foot_p.z - fc_tgt - H.foot_height_offset;
-            add(LG_R_TRACKING_FOOT_CLEARANCE, expf(-quad_sum<LEGS>(vxy * (d * d)) / H.foot_clearance_sigma));
+            const float d = foot_p.z - fc_tgt - HOT(foot_height_offset);
+            add(LG_R_TRACKING_FOOT_CLEARANCE, __expf(-quad_sum<LEGS>(vxy * (d * d)) / HOT(foot_clearance_sigma)));
         }
-        if (sc[LG_R_TRACKING_LIN_VEL] != 0.f) {                         // :533-537
+        if (HOT(reward_scales[LG_R_TRACKING_LIN_VEL]) != 0.f) {                         // :533-537
             const float dx = cmd0 - blv.x, dy = cmd1 - blv.y;
-            add(LG_R_TRACKING_LIN_VEL, expf(-(dx * dx + dy * dy) / H.tracking_sigma));
+            add(LG_R_TRACKING_LIN_VEL, __expf(-(dx * dx + dy * dy) / HOT(tracking_sigma)));
         }
-        if (sc[LG_R_TRACKING_ORIENTATION] != 0.f) {                     // go2_wtw.py:502-505
+        if (HOT(reward_scales[LG_R_TRACKING_ORIENTATION]) != 0.f) {                     // go2_wtw.py:502-505
             const float dp = eul.y - pitch_tgt;
-            add(LG_R_TRACKING_ORIENTATION, expf(-(eul.x * eul.x + dp * dp) / H.euler_sigma));
+            add(LG_R_TRACKING_ORIENTATION, __expf(-(eul.x * eul.x + dp * dp) / HOT(euler_sigma)));
         }
 #ifdef LG_DBG_RET_REW
         if (p.counter >= 0) { if (lead) B.rew_buf[e] = total + es[0] + es[5] + es[28]; return; }
 #endif
         STAMP(7);
-        if (H.only_positive_rewards) total = fmaxf(total, 0.f);        // :161-162
-        if (sc[LG_R_TERMINATION] != 0.f) add(LG_R_TERMINATION, (reset && !time_out) ? 1.f : 0.f);  // :163-168
+        if (HOT(only_positive_rewards)) total = fmaxf(total, 0.f);        // :161-162
+        if (HOT(reward_scales[LG_R_TERMINATION]) != 0.f) add(LG_R_TERMINATION, (reset && !time_out) ? 1.f : 0.f);  // :163-168
         if (GAIT) {  // gait clock (go2_wtw.py:29-36, tron1_pf_ee.py:28-35).  The reference additionally restarts env 0's clock whenever
                      // ANY env wraps (index-flatten bug); that grid-wide coupling is deliberately not reproduced.
             gait_time += cdt;
@@ -1376,34 +1447,34 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         V3 pos_origin_override = v3(0, 0, 0);
         bool have_origin = false;
         if (reset) {
-            if (H.terrain_curriculum && p.counter > 0) {
+            if (HOT(terrain_curriculum) && p.counter > 0) {
                 // legged_robot.py:254-272 + genesis_simulator.py:140-148 (skipped on the construction-time reset,
                 // where the reference returns early because init_done is False)
                 const V3 org = origin_pre;
                 const float dx = pos.x - org.x, dy = pos.y - org.y;
                 const float dist = sqrtf(dx * dx + dy * dy);
-                const bool up = dist > H.terrain_env_length / 2.f;
-                const bool down = (dist < sqrtf(cmd0 * cmd0 + cmd1 * cmd1) * H.episode_length_s * 0.5f) && !up;
+                const bool up = dist > HOT(terrain_env_length) / 2.f;
+                const bool down = (dist < sqrtf(cmd0 * cmd0 + cmd1 * cmd1) * HOT(episode_length_s) * 0.5f) && !up;
                 int lvl = B.terrain_levels[e] + (up ? 1 : 0) - (down ? 1 : 0);
-                if (lvl >= H.max_terrain_level) lvl = min((int)floorf(rs.draw(H.slots.terrain_level) * (float)H.max_terrain_level), H.max_terrain_level - 1);
+                if (lvl >= HOT(max_terrain_level)) lvl = min((int)floorf(rs.draw(HOT(slots.terrain_level)) * (float)HOT(max_terrain_level)), HOT(max_terrain_level) - 1);
                 else lvl = max(lvl, 0);
-                const V3 norg = ld3(B.terrain_origins + ((size_t)lvl * H.terrain_cols_n + B.terrain_types[e]) * 3);
+                const V3 norg = ld3(B.terrain_origins + ((size_t)lvl * HOT(terrain_cols_n) + B.terrain_types[e]) * 3);
                 if (lead) { B.terrain_levels[e] = lvl; st3(B.env_origins + 3 * e, norg); }
                 pos_origin_override = norg; have_origin = true;
             }
-            if (WTW) { resample_behavior(H.slots.task_reset); gait_time = 0.f; phi = 0.f; }   // go2_wtw.py:124-142
-            resample_commands(H.slots.reset_cmd);
+            if (WTW) { resample_behavior(HOT(slots.task_reset)); gait_time = 0.f; phi = 0.f; }   // go2_wtw.py:124-142
+            resample_commands(HOT(slots.reset_cmd));
             // tron1_pf_ee.py:204-210: ONE coin per reset_idx call sends the whole batch to the sit pose (quirk 11)
             bool sit = false;
-            if (H.sit_percent > 0.f) {
+            if (HOT(sit_percent) > 0.f) {
                 float us;
-                if (rs.in) us = rs.in[H.slots.task_reset];
-                else { RandSrc g = rs; g.e_lo = 0xFFFFFFFFu; g.e_hi = 0xFFFFFFFFu; us = g.draw(H.slots.task_reset); }
-                sit = us < H.sit_percent;
+                if (rs.in) us = rs.in[HOT(slots.task_reset)];
+                else { RandSrc g = rs; g.e_lo = 0xFFFFFFFFu; g.e_hi = 0xFFFFFFFFu; us = g.draw(HOT(slots.task_reset)); }
+                sit = us < HOT(sit_percent);
             }
             // _reset_dofs (go2.py:17-37): default + U(range) per joint, zero velocity
             float ud[3];
-            rs.draw3(H.slots.reset_dof + d0, ud[0], ud[1], ud[2]);
+            rs.draw3(HOT(slots.reset_dof) + d0, ud[0], ud[1], ud[2]);
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 q[j] = sit ? T->sit_dof_pos[d0 + j]
@@ -1413,30 +1484,30 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 act[j] = last_act[j] = llast_act[j] = 0.f;
             }
             // _reset_root_states (go2.py:119-134)
-            pos = (sit ? ld3(T->sit_pos) : v3(H.o_base_init_pos[0], H.o_base_init_pos[1], H.o_base_init_pos[2])) + (have_origin ? pos_origin_override : origin_pre);
-            if (H.custom_origins) {
-                pos.x += H.reset_root_xy_span * rs.draw(H.slots.reset_root_xy) + H.reset_root_xy_lo;
-                pos.y += H.reset_root_xy_span * rs.draw(H.slots.reset_root_xy + 1) + H.reset_root_xy_lo;
+            pos = (sit ? ld3(T->sit_pos) : v3(HOT(o_base_init_pos[0]), HOT(o_base_init_pos[1]), HOT(o_base_init_pos[2]))) + (have_origin ? pos_origin_override : origin_pre);
+            if (HOT(custom_origins)) {
+                pos.x += HOT(reset_root_xy_span) * rs.draw(HOT(slots.reset_root_xy)) + HOT(reset_root_xy_lo);
+                pos.y += HOT(reset_root_xy_span) * rs.draw(HOT(slots.reset_root_xy) + 1) + HOT(reset_root_xy_lo);
             }
-            qx = sit ? T->sit_quat[0] : H.base_init_quat[0]; qy = sit ? T->sit_quat[1] : H.base_init_quat[1];
-            qz = sit ? T->sit_quat[2] : H.base_init_quat[2]; qw = sit ? T->sit_quat[3] : H.base_init_quat[3];
-            if (H.reset_lin_vel_span != 0.f || H.reset_ang_vel_span != 0.f || rs.in) {   // go2.py:131-133 draws U(0,0): skip
+            qx = sit ? T->sit_quat[0] : HOT(base_init_quat[0]); qy = sit ? T->sit_quat[1] : HOT(base_init_quat[1]);
+            qz = sit ? T->sit_quat[2] : HOT(base_init_quat[2]); qw = sit ? T->sit_quat[3] : HOT(base_init_quat[3]);
+            if (HOT(reset_lin_vel_span) != 0.f || HOT(reset_ang_vel_span) != 0.f || rs.in) {   // go2.py:131-133 draws U(0,0): skip
                 float a0, a1, a2, b0_, b1_, b2_;
-                rs.draw3(H.slots.reset_lin_vel, a0, a1, a2);
-                rs.draw3(H.slots.reset_ang_vel, b0_, b1_, b2_);
-                vw = v3(H.reset_lin_vel_span * a0 + H.reset_lin_vel_lo, H.reset_lin_vel_span * a1 + H.reset_lin_vel_lo,
-                        H.reset_lin_vel_span * a2 + H.reset_lin_vel_lo);
-                ww = v3(H.reset_ang_vel_span * b0_ + H.reset_ang_vel_lo, H.reset_ang_vel_span * b1_ + H.reset_ang_vel_lo,
-                        H.reset_ang_vel_span * b2_ + H.reset_ang_vel_lo);
+                rs.draw3(HOT(slots.reset_lin_vel), a0, a1, a2);
+                rs.draw3(HOT(slots.reset_ang_vel), b0_, b1_, b2_);
+                vw = v3(HOT(reset_lin_vel_span) * a0 + HOT(reset_lin_vel_lo), HOT(reset_lin_vel_span) * a1 + HOT(reset_lin_vel_lo),
+                        HOT(reset_lin_vel_span) * a2 + HOT(reset_lin_vel_lo));
+                ww = v3(HOT(reset_ang_vel_span) * b0_ + HOT(reset_ang_vel_lo), HOT(reset_ang_vel_span) * b1_ + HOT(reset_ang_vel_lo),
+                        HOT(reset_ang_vel_span) * b2_ + HOT(reset_ang_vel_lo));
             } else {
-                vw = v3(H.reset_lin_vel_lo, H.reset_lin_vel_lo, H.reset_lin_vel_lo);
-                ww = v3(H.reset_ang_vel_lo, H.reset_ang_vel_lo, H.reset_ang_vel_lo);
+                vw = v3(HOT(reset_lin_vel_lo), HOT(reset_lin_vel_lo), HOT(reset_lin_vel_lo));
+                ww = v3(HOT(reset_ang_vel_lo), HOT(reset_ang_vel_lo), HOT(reset_ang_vel_lo));
             }
             if (sit) { vw = v3(0, 0, 0); ww = v3(0, 0, 0); }        // tron1_pf_ee.py:304-309
             if (BIPED) {                                             // tron1_pf_ee.py:220-226
-                const float th0 = T->theta_table[0][0] + rs.draw(H.slots.task_reset + 1);
+                const float th0 = T->theta_table[0][0] + rs.draw(HOT(slots.task_reset) + 1);
                 theta = foot_slot == 0 ? th0 : th0 + (T->theta_table[0][1] - T->theta_table[0][0]);
-                gait_time = rs.draw(H.slots.task_reset + 2) * gait_period;
+                gait_time = rs.draw(HOT(slots.task_reset) + 2) * gait_period;
                 phi = gait_time / gait_period;
             }
             // the reference stores the commanded reset twist verbatim in the body-frame properties
@@ -1453,14 +1524,14 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                     B.actions[e * A + d0 + j] = 0.f; B.last_actions[e * A + d0 + j] = 0.f; B.llast_actions[e * A + d0 + j] = 0.f;
                 }
                 st3(B.last_feet_vel + (e * F + foot_slot) * 3, v3(0, 0, 0));
-                if (H.dr_pd_on) {   // genesis_simulator.py:735-739
+                if (HOT(dr_pd_on)) {   // genesis_simulator.py:735-739
                     float up[3], ud2[3];
-                    rs.draw3(H.slots.dr_kp + d0, up[0], up[1], up[2]);
-                    rs.draw3(H.slots.dr_kd + d0, ud2[0], ud2[1], ud2[2]);
+                    rs.draw3(HOT(slots.dr_kp) + d0, up[0], up[1], up[2]);
+                    rs.draw3(HOT(slots.dr_kd) + d0, ud2[0], ud2[1], ud2[2]);
 #pragma unroll
                     for (int j = 0; j < 3; j++) {
-                        B.kp_scale[e * A + d0 + j] = H.dr_kp_span * up[j] + H.dr_kp_lo;
-                        B.kd_scale[e * A + d0 + j] = H.dr_kd_span * ud2[j] + H.dr_kd_lo;
+                        B.kp_scale[e * A + d0 + j] = HOT(dr_kp_span) * up[j] + HOT(dr_kp_lo);
+                        B.kd_scale[e * A + d0 + j] = HOT(dr_kd_span) * ud2[j] + HOT(dr_kd_lo);
                     }
                 }
             }
@@ -1472,27 +1543,27 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 st3(B.projected_gravity + 3 * e, pg);
                 st3(B.last_base_lin_vel + 3 * e, v3(0, 0, 0)); st3(B.last_base_ang_vel + 3 * e, v3(0, 0, 0));
                 // domain randomisation (genesis_simulator.py:62-77, 665-739)
-                if (H.dr_friction_on) B.friction_values[e] = H.dr_friction_span * rs.draw(H.slots.dr_friction) + H.dr_friction_lo;
-                if (H.dr_mass_on) B.added_base_mass[e] = H.dr_mass_span * rs.draw(H.slots.dr_mass) + H.dr_mass_lo;
-                if (H.dr_com_on) {
+                if (HOT(dr_friction_on)) B.friction_values[e] = HOT(dr_friction_span) * rs.draw(HOT(slots.dr_friction)) + HOT(dr_friction_lo);
+                if (HOT(dr_mass_on)) B.added_base_mass[e] = HOT(dr_mass_span) * rs.draw(HOT(slots.dr_mass)) + HOT(dr_mass_lo);
+                if (HOT(dr_com_on)) {
                     float uc[3];
-                    rs.draw3(H.slots.dr_com, uc[0], uc[1], uc[2]);
+                    rs.draw3(HOT(slots.dr_com), uc[0], uc[1], uc[2]);
 #pragma unroll
-                    for (int k = 0; k < 3; k++) B.base_com_bias[3 * e + k] = H.dr_com_span[k] * uc[k] + H.dr_com_lo[k];
+                    for (int k = 0; k < 3; k++) B.base_com_bias[3 * e + k] = HOT(dr_com_span[k]) * uc[k] + HOT(dr_com_lo[k]);
                 }
-                if (H.dr_joint_on && B.joint_armature) {
+                if (HOT(dr_joint_on) && B.joint_armature) {
                     float uj[3];
-                    rs.draw3(H.slots.dr_joint, uj[0], uj[1], uj[2]);
-                    B.joint_armature[e] = H.dr_joint_span[0] * uj[0] + H.dr_joint_lo[0];
-                    B.joint_friction[e] = H.dr_joint_span[1] * uj[1] + H.dr_joint_lo[1];
-                    B.joint_damping[e] = H.dr_joint_span[2] * uj[2] + H.dr_joint_lo[2];
+                    rs.draw3(HOT(slots.dr_joint), uj[0], uj[1], uj[2]);
+                    B.joint_armature[e] = HOT(dr_joint_span[0]) * uj[0] + HOT(dr_joint_lo[0]);
+                    B.joint_friction[e] = HOT(dr_joint_span[1]) * uj[1] + HOT(dr_joint_lo[1]);
+                    B.joint_damping[e] = HOT(dr_joint_span[2]) * uj[2] + HOT(dr_joint_lo[2]);
                 }
                 // extras["episode"] (legged_robot.py:128-132): snapshot this env's sums + the step it reset at; the
                 // host forms the per-step means lazily from these.  (A first version used one float atomic per term
                 // per reset on a shared accumulator: ~10 us per launch of same-line atomic latency.)
 #pragma unroll
                 for (int k = 0; k < LG_R_COUNT; k++) {
-                    if (scl[k] != 0.f) { B.episode_done_sums[(size_t)k * N + e] = es[k]; es[k] = 0.f; }
+                    if (HOT(reward_scales[k]) != 0.f) { B.episode_done_sums[(size_t)k * N + e] = es[k]; es[k] = 0.f; }
                 }
                 B.episode_done_step[e] = (int)p.counter;
             }
@@ -1503,10 +1574,10 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         // ---- compute_observations + clip (legged_robot.py:48-49).  Layouts: go2.py:40-64 (45),
         //      go2_wtw.py:53-111 (61x5 | 99x5), go2_ee.py:10-75 (45x20 | 174x5 | 24 labels).  Histories are
         //      kept oldest -> newest inside obs_buf / priv_obs_buf themselves and shifted in place.
-        const int FR = H.obs_frame, PF = H.priv_frame, ST = H.obs_stack, PST = H.priv_stack;
-        float *o = B.obs_buf + (size_t)e * H.num_obs;
-        float *pv = H.num_priv_obs > 0 ? B.priv_obs_buf + (size_t)e * H.num_priv_obs : nullptr;
-        const float co = H.clip_obs;
+        const int FR = HOT(obs_frame), PF = HOT(priv_frame), ST = HOT(obs_stack), PST = HOT(priv_stack);
+        float *o = B.obs_buf + (size_t)e * HOT(num_obs);
+        float *pv = HOT(num_priv_obs) > 0 ? B.priv_obs_buf + (size_t)e * HOT(num_priv_obs) : nullptr;
+        const float co = HOT(clip_obs);
         if (live) {   // this lane's columns move one frame towards the past (zeros after a reset: go2_wtw.py:174-178)
             for (int f = 0; f + 1 < ST; f++)
                 for (int i = leg; i < FR; i += LEGS) o[f * FR + i] = reset ? 0.f : o[(f + 1) * FR + i];
@@ -1515,8 +1586,8 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                     for (int i = leg; i < PF; i += LEGS) pv[f * PF + i] = reset ? 0.f : pv[(f + 1) * PF + i];
         }
         float *on = o + (ST - 1) * FR, *pn = pv ? pv + (PST - 1) * PF : nullptr;
-        const bool nz = H.add_noise != 0;
-        const int ns = H.slots.noise;
+        const bool nz = HOT(add_noise) != 0;
+        const int ns = HOT(slots.noise);
         // uniforms for the noisy entries only (commands and actions carry zero noise scale): q, qd per lane,
         // gravity + ang vel on the lead lane
         float uq[3] = {0.5f, 0.5f, 0.5f}, uqd[3] = {0.5f, 0.5f, 0.5f}, ub[6] = {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f};
@@ -1535,7 +1606,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             }
         }
         float uact[3] = {0.5f, 0.5f, 0.5f}, uclk[2] = {0.5f, 0.5f};
-        if (nz && H.noise_act0 != 0.f) {  // uniform index: scalar load   // tron1_pf_ee.py:338-342 (quirk 4): actions and clock are noisy too
+        if (nz && HOT(noise_act0) != 0.f) {  // uniform index: scalar load   // tron1_pf_ee.py:338-342 (quirk 4): actions and clock are noisy too
             if (rs.in) {
 #pragma unroll
                 for (int j = 0; j < 3; j++) uact[j] = rs.in[ns + 9 + 2 * A + d0 + j];
@@ -1555,17 +1626,17 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         if (live) {
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                put(9 + d0 + j, (q[j] - q0l[j]) * H.obs_scale_dof_pos, uq[j], nv_q[j]);
-                put(9 + A + d0 + j, qd[j] * H.obs_scale_dof_vel, uqd[j], nv_qd[j]);
+                put(9 + d0 + j, (q[j] - q0l[j]) * HOT(obs_scale_dof_pos), uq[j], nv_q[j]);
+                put(9 + A + d0 + j, qd[j] * HOT(obs_scale_dof_vel), uqd[j], nv_qd[j]);
                 put(9 + 2 * A + d0 + j, act[j], uact[j], nv_act[j]);
             }
         }
         if (lead) {
-            put(0, cmd0 * H.obs_scale_lin_vel, 0.5f, 0.f); put(1, cmd1 * H.obs_scale_lin_vel, 0.5f, 0.f); put(2, cmd2 * H.obs_scale_ang_vel, 0.5f, 0.f);
-            put(3, pg.x, ub[0], H.noise_lead[0]); put(4, pg.y, ub[1], H.noise_lead[1]); put(5, pg.z, ub[2], H.noise_lead[2]);
-            put(6, bav.x * H.obs_scale_ang_vel, ub[3], H.noise_lead[3]); put(7, bav.y * H.obs_scale_ang_vel, ub[4], H.noise_lead[4]); put(8, bav.z * H.obs_scale_ang_vel, ub[5], H.noise_lead[5]);
+            put(0, cmd0 * HOT(obs_scale_lin_vel), 0.5f, 0.f); put(1, cmd1 * HOT(obs_scale_lin_vel), 0.5f, 0.f); put(2, cmd2 * HOT(obs_scale_ang_vel), 0.5f, 0.f);
+            put(3, pg.x, ub[0], HOT(noise_lead[0])); put(4, pg.y, ub[1], HOT(noise_lead[1])); put(5, pg.z, ub[2], HOT(noise_lead[2]));
+            put(6, bav.x * HOT(obs_scale_ang_vel), ub[3], HOT(noise_lead[3])); put(7, bav.y * HOT(obs_scale_ang_vel), ub[4], HOT(noise_lead[4])); put(8, bav.z * HOT(obs_scale_ang_vel), ub[5], HOT(noise_lead[5]));
         }
-        if (H.obs_layout == LG_OBS_GO2_WTW) {
+        if (HOT(obs_layout) == LG_OBS_GO2_WTW) {
             const float ang = 6.283185307179586f * (phi + theta);      // clock inputs (go2_wtw.py:251-256)
             if (live) {
                 const float sn = sinf(ang), cs = cosf(ang);
@@ -1582,21 +1653,21 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             }
             if (lead) {
                 put(53, gait_period, 0.5f, 0.f); put(54, bh_tgt, 0.5f, 0.f); put(55, fc_tgt, 0.5f, 0.f); put(56, pitch_tgt, 0.5f, 0.f);
-                putp(FR + 0, blv.x * H.obs_scale_lin_vel); putp(FR + 1, blv.y * H.obs_scale_lin_vel); putp(FR + 2, blv.z * H.obs_scale_lin_vel);
+                putp(FR + 0, blv.x * HOT(obs_scale_lin_vel)); putp(FR + 1, blv.y * HOT(obs_scale_lin_vel)); putp(FR + 2, blv.z * HOT(obs_scale_lin_vel));
                 putp(FR + 3, B.rand_push_vels[3 * e]); putp(FR + 4, B.rand_push_vels[3 * e + 1]);
                 putp(FR + 5, B.added_base_mass[e]); putp(FR + 6, B.friction_values[e]);
                 putp(FR + 7, B.base_com_bias[3 * e]); putp(FR + 8, B.base_com_bias[3 * e + 1]); putp(FR + 9, B.base_com_bias[3 * e + 2]);
             }
-        } else if (H.obs_layout == LG_OBS_GO2_EE) {
+        } else if (HOT(obs_layout) == LG_OBS_GO2_EE) {
             // critic frame (go2_ee.py:21-48): obs 45 | DR 31 | contact states K | heights P
             const int K = __popc(M->state_link_mask);
             const int l0 = foot_link - 3;
-            float *lab = B.labels_buf + (size_t)e * H.num_labels;
+            float *lab = B.labels_buf + (size_t)e * HOT(num_labels);
             if (live) {
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
-                    putp(FR + 7 + d0 + j, B.kp_scale[e * A + d0 + j] - H.kp_offset);
-                    putp(FR + 7 + A + d0 + j, B.kd_scale[e * A + d0 + j] - H.kd_offset);
+                    putp(FR + 7 + d0 + j, B.kp_scale[e * A + d0 + j] - HOT(kp_offset));
+                    putp(FR + 7 + A + d0 + j, B.kd_scale[e * A + d0 + j] - HOT(kd_offset));
                 }
                 // contact states are those of the physics read-back (stale for a just-reset env, as in the reference)
 #pragma unroll
@@ -1610,26 +1681,26 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                     }
                 }
                 for (int k = leg; k < P; k += LEGS) {
-                    float hv = pos.z - H.heights_offset - B.measured_heights[(size_t)e * P + k];
-                    if (H.heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * H.obs_scale_height;
+                    float hv = pos.z - HOT(heights_offset) - B.measured_heights[(size_t)e * P + k];
+                    if (HOT(heights_clip_scale)) hv = clampf(hv, -1.f, 1.f) * HOT(obs_scale_height);
                     putp(FR + 7 + 2 * A + K + k, hv);
                 }
                 // labels (go2_ee.py:69-75): v_b 3 | contact states K | foot height above the local terrain mean F
-                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmean - H.foot_height_offset, -1.f, 1.f);
+                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmean - HOT(foot_height_offset), -1.f, 1.f);
             }
             if (lead) {
-                putp(FR + 0, B.friction_values[e] - H.friction_offset); putp(FR + 1, B.added_base_mass[e]);
+                putp(FR + 0, B.friction_values[e] - HOT(friction_offset)); putp(FR + 1, B.added_base_mass[e]);
                 putp(FR + 2, B.base_com_bias[3 * e]); putp(FR + 3, B.base_com_bias[3 * e + 1]); putp(FR + 4, B.base_com_bias[3 * e + 2]);
                 putp(FR + 5, B.rand_push_vels[3 * e]); putp(FR + 6, B.rand_push_vels[3 * e + 1]);
                 if (M->state_link_mask & 1u) { const float cs = norm(f_base) > 1.f ? 1.f : 0.f; putp(FR + 7 + 2 * A, cs); lab[3] = cs; }
-                lab[0] = blv.x * H.obs_scale_lin_vel; lab[1] = blv.y * H.obs_scale_lin_vel; lab[2] = blv.z * H.obs_scale_lin_vel;
+                lab[0] = blv.x * HOT(obs_scale_lin_vel); lab[1] = blv.y * HOT(obs_scale_lin_vel); lab[2] = blv.z * HOT(obs_scale_lin_vel);
             }
-        } else if (H.obs_layout == LG_OBS_TRON1_EE) {
+        } else if (HOT(obs_layout) == LG_OBS_TRON1_EE) {
             // tron1_pf_ee.py:53-141.  actor frame: 9 + 3A + clock 2F.  critic frame: frame | DR (7 + 2A + 3) |
             // gait F | contact states K | heights P | normals 3F | clip(foot_z - h9) 9F.  labels: v_b 3 | K | F | 3F
             const int K = __popc(M->state_link_mask);
             const int l0 = foot_link - 3;
-            float *lab = B.labels_buf + (size_t)e * H.num_labels;
+            float *lab = B.labels_buf + (size_t)e * HOT(num_labels);
             const float ang = 6.283185307179586f * (phi + theta);
             const int oDR = FR, oG = FR + 7 + 2 * A + 3, oK = oG + F, oH = oK + K, oN = oH + P, oR = oN + 3 * F;
             if (live) {
@@ -1639,8 +1710,8 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 ts[4 + foot_slot] = theta; ts[6 + foot_slot] = sn; ts[6 + F + foot_slot] = cs; ts[10 + foot_slot] = expC;
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
-                    putp(oDR + 7 + d0 + j, B.kp_scale[e * A + d0 + j] - H.kp_offset);
-                    putp(oDR + 7 + A + d0 + j, B.kd_scale[e * A + d0 + j] - H.kd_offset);
+                    putp(oDR + 7 + d0 + j, B.kp_scale[e * A + d0 + j] - HOT(kp_offset));
+                    putp(oDR + 7 + A + d0 + j, B.kd_scale[e * A + d0 + j] - HOT(kd_offset));
                 }
                 putp(oG + foot_slot, expC);
 #pragma unroll
@@ -1654,8 +1725,8 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                     }
                 }
                 for (int k = leg; k < P; k += LEGS) {
-                    float hv = pos.z - H.heights_offset - B.measured_heights[(size_t)e * P + k];
-                    if (H.heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * H.obs_scale_height;
+                    float hv = pos.z - HOT(heights_offset) - B.measured_heights[(size_t)e * P + k];
+                    if (HOT(heights_clip_scale)) hv = clampf(hv, -1.f, 1.f) * HOT(obs_scale_height);
                     putp(oH + k, hv);
                 }
                 const float *nv3 = B.normal_vector_around_feet + ((size_t)e * F + foot_slot) * 3;
@@ -1664,17 +1735,17 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
 #pragma unroll
                 for (int k = 0; k < 9; k++)
                     putp(oR + 9 * foot_slot + k, clampf(foot_p.z - B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k], -1.f, 1.f));
-                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmax - H.foot_height_offset, -1.f, 1.f);
+                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmax - HOT(foot_height_offset), -1.f, 1.f);
             }
             if (lead) {
-                putp(oDR + 0, B.friction_values[e] - H.friction_offset); putp(oDR + 1, B.added_base_mass[e]);
+                putp(oDR + 0, B.friction_values[e] - HOT(friction_offset)); putp(oDR + 1, B.added_base_mass[e]);
                 putp(oDR + 2, B.base_com_bias[3 * e]); putp(oDR + 3, B.base_com_bias[3 * e + 1]); putp(oDR + 4, B.base_com_bias[3 * e + 2]);
                 putp(oDR + 5, B.rand_push_vels[3 * e]); putp(oDR + 6, B.rand_push_vels[3 * e + 1]);
                 putp(oDR + 7 + 2 * A, B.joint_armature ? B.joint_armature[e] : 0.f);
                 putp(oDR + 8 + 2 * A, B.joint_friction ? B.joint_friction[e] : 0.f);
                 putp(oDR + 9 + 2 * A, B.joint_damping ? B.joint_damping[e] : 0.f);
                 if (M->state_link_mask & 1u) { const float cst = norm(f_base) > 1.f ? 1.f : 0.f; putp(oK, cst); lab[3] = cst; }
-                lab[0] = blv.x * H.obs_scale_lin_vel; lab[1] = blv.y * H.obs_scale_lin_vel; lab[2] = blv.z * H.obs_scale_lin_vel;
+                lab[0] = blv.x * HOT(obs_scale_lin_vel); lab[1] = blv.y * HOT(obs_scale_lin_vel); lab[2] = blv.z * HOT(obs_scale_lin_vel);
             }
         }
     }
@@ -1683,10 +1754,10 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     }
     if (BIPED && lead) { ts[0] = gait_time; ts[1] = phi; ts[2] = gait_period; }
     if (BIPED && live && !DO_RESET) { ts[4 + foot_slot] = theta; ts[10 + foot_slot] = expC; }
-    if (WTW && live && !(DO_RESET && H.obs_layout == LG_OBS_GO2_WTW)) { ts[6 + foot_slot] = theta; ts[18 + foot_slot] = expC; }
+    if (WTW && live && !(DO_RESET && HOT(obs_layout) == LG_OBS_GO2_WTW)) { ts[6 + foot_slot] = theta; ts[18 + foot_slot] = expC; }
     // second action-history shift of the wtw / tron1_ee tasks (go2_wtw.py:45-46): afterwards
     // last == llast == a_t, which makes action_smoothness == action_rate
-    if (DO_RESET && H.double_shift && live) {
+    if (DO_RESET && HOT(double_shift) && live) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             B.llast_actions[e * A + d0 + j] = reset ? 0.f : last_act[j];
@@ -1709,7 +1780,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         if (DO_POST || (DO_RESET && reset)) {
 #pragma unroll
             for (int k = 0; k < LG_R_COUNT; k++)
-                if (scl[k] != 0.f) esum[(size_t)k * N + e] = es[k];
+                if (HOT(reward_scales[k]) != 0.f) esum[(size_t)k * N + e] = es[k];
         }
     }
     STAMP(11);
@@ -1733,8 +1804,9 @@ extern "C" int lg_abi_version(void) { return LG_ABI_VERSION; }
 
 static int upload_hot(LgEngine *h) {
     LgHot hot;
-    fill_hot(hot, h->task, h->opts, 3 * h->model.n_legs);
-    if (!h->d_hot) { hipError_t e = hipMalloc(&h->d_hot, sizeof(LgHot)); if (e != hipSuccess) return fail(std::string("hipMalloc(hot): ") + hipGetErrorString(e)); }
+    fill_hot(hot, h->task, h->opts, h->model);
+    if (!h->d_hot) { hipError_t e = hipMalloc(&h->d_hot, 1024); if (e != hipSuccess) return fail(std::string("hipMalloc(hot): ") + hipGetErrorString(e)); }
+    HIPCHK(hipMemset(h->d_hot, 0, 1024));
     HIPCHK(hipMemcpy(h->d_hot, &hot, sizeof(LgHot), hipMemcpyHostToDevice));
     return 0;
 }
@@ -1776,8 +1848,9 @@ extern "C" int lg_create(const LgModelDesc *model, const LgSimOptions *opts, con
     h->model = *model; h->opts = *opts; h->task = *task;
     memset(&h->bufs, 0, sizeof(h->bufs));
     hipError_t e;
-    if ((e = hipMalloc(&h->d_model, (sizeof(LgModelDesc) + 15) / 16 * 16)) != hipSuccess || (e = hipMalloc(&h->d_opts, sizeof(LgSimOptions))) != hipSuccess ||
+    if ((e = hipMalloc(&h->d_model, MODEL_STG * BLOCK * 16)) != hipSuccess || (e = hipMalloc(&h->d_opts, sizeof(LgSimOptions))) != hipSuccess ||
         (e = hipMalloc(&h->d_task, sizeof(LgTaskCfg))) != hipSuccess) { delete h; return fail(std::string("lg_create: hipMalloc: ") + hipGetErrorString(e)); }
+    HIPCHK(hipMemset(h->d_model, 0, MODEL_STG * BLOCK * 16));
     HIPCHK(hipMemcpy(h->d_model, model, sizeof(LgModelDesc), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_opts, opts, sizeof(LgSimOptions), hipMemcpyHostToDevice));
     HIPCHK(hipMemcpy(h->d_task, task, sizeof(LgTaskCfg), hipMemcpyHostToDevice));

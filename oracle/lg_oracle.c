@@ -569,9 +569,16 @@ static void env_step(const LgModelDesc *m, const LgSimOptions *o, const int16_t 
                     taul[k] = 0;
                     if (!lim_on[k]) continue;
                     /* vin: end-of-step velocity INTO the stop without the stop's own torque */
-                    real D = w.d[k + 1];
-                    real vin = -lim_s[k] * (qd[k] + dt * (qdd[k] + qd2[k])) + dt * lim_T[k] / D;
-                    real T = (kl * lim_e[k] + kapl * vin) / (1 + kapl * dt / D);
+                    /* compliance seen by the stop: 1/d_i (parent held) on the first sweep; afterwards the
+                     * response measured in the previous sweep (secant), which includes the give of the
+                     * floating base -- without it an even number of sweeps ends on an under-estimate */
+                    real C = 1 / w.d[k + 1];
+                    if (it > 0 && lim_T[k] > 0) {
+                        real Cm = lim_s[k] * qd2[k] / lim_T[k];
+                        C = Cm > C ? (Cm < 8 * C ? Cm : 8 * C) : C;
+                    }
+                    real vin = -lim_s[k] * (qd[k] + dt * (qdd[k] + qd2[k])) + dt * lim_T[k] * C;
+                    real T = (kl * lim_e[k] + kapl * vin) / (1 + kapl * dt * C);
                     lim_T[k] = T > 0 ? T : 0;
                     taul[k] = lim_s[k] * lim_T[k];
                 }
