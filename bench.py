@@ -23,7 +23,26 @@ BYTES_PER_ENV_STEP = 988          # go2 flat, f32, state read on
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
 
 
-def cpu_baseline(n_envs=512, steps=12):
+def host_threads():
+    """Threads the CPU leg may use: the cores this process is allowed on, capped at the GPU box's per-GPU share."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    return max(1, min(16, n))
+
+
+def hbm_traffic(workload_key):
+    """HBM bytes per launch from the committed PMC pass (profiles/hbm_traffic.json, written by tools/pmc_traffic.py
+    from separate rocprofv3 --pmc runs with the gfx950 FETCH_SIZE correction applied); None when not collected."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
+            return json.load(f).get(workload_key, {}).get("bytes_per_launch")
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline(n_envs=2048, steps=150):
     """The CPU oracle (C, OpenMP over envs) on a bounded sample of the same workload."""
     import numpy as np
     from hcr_genesis_lr_cl_amd import builders, config as cfgmod
@@ -35,7 +54,7 @@ def cpu_baseline(n_envs=512, steps=12):
     desc, opts = builders.make_model_desc(model, cfg), builders.make_sim_options(model, cfg)
     st = orc.HostState(model, n_envs, cfgmod.default_dof_pos(cfg), 0.34)
     rng = np.random.default_rng(1)
-    cores = os.cpu_count() or 1
+    cores = host_threads()
     act = rng.normal(size=(n_envs, 12)).astype(np.float32)
     orc.sim_step(desc, opts, st, act, "f32", threads=cores)      # warm-up
     t0 = time.perf_counter()
@@ -127,7 +146,7 @@ def main():
                                    f"(4 sub-steps dt=0.005) with synthetic N(0,1) actions",
                        "envs_total": total_envs, "parallelism": f"env-shard x{world}" + (" + all-gather(obs,rew,done)" if world > 1 and not args.no_gather else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": hbm_traffic(f"go2_flat_{n_local}"),
                          "kernel": "env_step_kernel<4,ALL>", "launch_us": launch_s * 1e6,
                          "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n_local},
         }
