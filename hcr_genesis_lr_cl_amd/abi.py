@@ -66,7 +66,7 @@ class LgSimOptions(C.Structure):
         ("kp", f32 * MAX_DOF), ("kd", f32 * MAX_DOF), ("default_dof_pos", f32 * MAX_DOF),
         ("base_init_pos", f32 * 3), ("bound_x", f32 * 2), ("bound_y", f32 * 2),
         ("terrain_rows", i32), ("terrain_cols", i32), ("hscale", f32), ("vscale", f32), ("border", f32),
-        ("n_height_points", i32), ("feet_terrain_info", i32),
+        ("n_height_points", i32), ("feet_terrain_info", i32), ("sim_layout", i32),
     ]
 
 

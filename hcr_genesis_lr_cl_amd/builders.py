@@ -29,6 +29,7 @@ def make_sim_options(model, cfg, terrain=None):
     o.terrain_friction = cfg.terrain.static_friction  # genesis_simulator.py:276
     o.limit_k, o.limit_b = cfg.hip.joint_limit_stiffness, cfg.hip.joint_limit_damping
     o.contact_iters = cfg.hip.contact_iters
+    o.sim_layout = int(getattr(cfg.hip, "sim_layout", 0))
     o.contact_margin, o.limit_margin = cfg.hip.contact_margin, cfg.hip.limit_margin
     o.max_base_lin_vel, o.max_base_ang_vel = cfg.hip.max_base_lin_vel, cfg.hip.max_base_ang_vel
     o.joint_vel_clamp = cfg.hip.joint_vel_clamp

@@ -1786,6 +1786,8 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     STAMP(11);
 }
 
+#include "lg_quad.h"
+
 // =============================== host side: the C ABI ==========================================
 static thread_local std::string g_err;
 static int fail(const std::string &m) { g_err = m; return 1; }
@@ -1910,6 +1912,23 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
             if (h->model.jrot[b][k] != ((k % 4 == 0) ? 1.f : 0.f)) p.jrot_identity = 0;
     const int threads = h->bufs.n_envs * LEGS;
     dim3 grid((threads + BLOCK - 1) / BLOCK), block(BLOCK);
+    // physics layout (lg_quad.h): one vector component per lane while the batch cannot fill the SIMDs with one leg per
+    // lane; the MDP phases then follow in a second launch on the same stream
+    const int layout = h->opts.sim_layout ? h->opts.sim_layout : (h->bufs.n_envs <= 8192 ? 2 : 1);
+    if (layout == 2 && (ph & LG_PHASE_SIM)) {
+        dim3 qgrid((threads * 4 + BLOCK - 1) / BLOCK);
+        const bool pre = (ph & LG_PHASE_PRE) != 0;
+        if (!pre && !actions) p.actions = nullptr;
+        if (pre) hipLaunchKernelGGL((quad_sim_kernel<LEGS, true>), qgrid, block, 0, st, p);
+        else hipLaunchKernelGGL((quad_sim_kernel<LEGS, false>), qgrid, block, 0, st, p);
+        HIPCHK(hipGetLastError());
+        const uint32_t rest = ph & (LG_PHASE_POST | LG_PHASE_RESET);
+        if (rest == (LG_PHASE_POST | LG_PHASE_RESET)) hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET>), grid, block, 0, st, p);
+        else if (rest == LG_PHASE_POST) hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST>), grid, block, 0, st, p);
+        else if (rest) return fail("lg_step: unsupported phase combination");
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     switch (ph) {
     case LG_PHASE_ALL: hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_ALL>), grid, block, 0, st, p); break;
     case LG_PHASE_SIM: hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_SIM>), grid, block, 0, st, p); break;

@@ -1,0 +1,763 @@
+// lg_quad.h -- physics phase with ONE VECTOR COMPONENT PER LANE (included by lg_kernel.hip).
+//
+// Why a second layout: the headline workload is 4096 envs per GPU.  With one leg per lane that is 256 waves on
+// a chip with 1024 SIMDs -- three SIMDs of every CU idle while the fourth walks a ~20 k-instruction serial
+// chain.  Here a leg is a QUAD of 4 lanes (x, y, z, w) and a Go2 env a DPP row of 16 lanes:
+//   * 3-vectors keep component c in lane c, 3x3 matrices keep ROW c in lane c, the 6x6 articulated inertia keeps
+//     rows c and c+3 in lane c.  matrix*vector and matrix*matrix become 3 / 9 fused DPP multiply-adds per lane
+//     (operand broadcast inside the quad rides on the VALU instruction), cross products 3, dot products 3;
+//   * per-joint scalars (q, qd, tau, limits, PD gains) keep joint j in lane j: the actuator law, the limit stops
+//     and the integrator handle the three joints of a leg at once;
+//   * the base quaternion keeps (x, y, z, w) in the four lanes;
+//   * sums over legs are two DPP row rotations (row_ror:4, row_ror:8).
+// The serial chain per wave shrinks ~2.7x and the launch has 4x the waves (one per SIMD at 4096 envs).  Total
+// issue slots are ~1.5x those of the leg-per-lane kernel, so that one stays the choice for large batches
+// (`LgSimOptions.sim_layout`, default: quad up to 8192 envs).
+//
+// All control flow is wave-uniform (ballot + scalar branch): a DPP read from a lane switched off by EXEC is
+// undefined, so lanes are never masked off; dead lanes (past the last env) shadow the last env and only their
+// stores are predicated.  Lane 3 of a quad carries no vector component; its values are "don't care" and never
+// reach lanes 0-2 (quad permutes used for vector work map lane 3 onto itself).
+//
+// Algorithm = lg_kernel.hip's SIM phase statement for statement (same world-aligned ABA about the base origin,
+// same contact / limit laws); tests/test_gpu_physics.py checks both layouts against the same f64 CPU restatement.
+#pragma once
+
+namespace q4 {
+
+constexpr int QP(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
+template <int CTRL> LG_DEV float dpp(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
+}
+template <int J> LG_DEV float bc(float v) { return dpp<J * 0x55>(v); }    // lane J of the quad, to all four
+LG_DEV float rot1(float v) { return dpp<QP(1, 2, 0, 3)>(v); }              // lane c <- lane (c+1)%3
+LG_DEV float rot2(float v) { return dpp<QP(2, 0, 1, 3)>(v); }              // lane c <- lane (c+2)%3
+LG_DEV float sum3(float t) { return t + rot1(t) + rot2(t); }               // x+y+z in lanes 0..2
+LG_DEV float sum4(float t) { t += dpp<QP(1, 0, 3, 2)>(t); return t + dpp<QP(2, 3, 0, 1)>(t); }
+template <int LEGS> LG_DEV float legsum(float v) {                         // sum over the legs of an env, to all
+    if (LEGS == 4) { v += dpp<0x124>(v); v += dpp<0x128>(v); }             // row_ror:4, row_ror:8
+    else if (LEGS == 2) v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F));  // lane ^ 4
+    return v;
+}
+LG_DEV int sum4i_or(int v) {
+    v |= __builtin_amdgcn_update_dpp(0, v, QP(1, 0, 3, 2), 0xF, 0xF, true);
+    return v | __builtin_amdgcn_update_dpp(0, v, QP(2, 3, 0, 1), 0xF, 0xF, true);
+}
+template <int LEGS> LG_DEV int env_or(int v) {
+    v = sum4i_or(v);
+    if (LEGS == 4) { v |= __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true); v |= __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true); }
+    else if (LEGS == 2) v |= __builtin_amdgcn_ds_swizzle(v, 0x101F);
+    return v;
+}
+
+struct QM { float c0, c1, c2; };       // 3x3: this lane's row
+struct QV6 { float a, l; };            // spatial vector [angular; linear], one component of each
+struct QI6 { QM A, B, Bt, C; };        // [A B; B^T C]: rows c of (A|B) and of (B^T|C)
+
+// lane constants
+struct Lane {
+    int c; bool is0, is1, is2, is3; float d0, d1, d2;
+    LG_DEV float sel(float a0, float a1, float a2) const { return is0 ? a0 : (is1 ? a1 : a2); }
+};
+
+LG_DEV float dot3(float a, float b) { return sum3(a * b); }
+LG_DEV float cross(float a, float b) { return rot1(a * rot1(b) - rot1(a) * b); }
+LG_DEV float mulv(const QM &m, float v) { return m.c0 * bc<0>(v) + m.c1 * bc<1>(v) + m.c2 * bc<2>(v); }
+LG_DEV QM mulmm(const QM &a, const QM &b) {     // a b
+    QM r;
+    r.c0 = a.c0 * bc<0>(b.c0) + a.c1 * bc<1>(b.c0) + a.c2 * bc<2>(b.c0);
+    r.c1 = a.c0 * bc<0>(b.c1) + a.c1 * bc<1>(b.c1) + a.c2 * bc<2>(b.c1);
+    r.c2 = a.c0 * bc<0>(b.c2) + a.c1 * bc<1>(b.c2) + a.c2 * bc<2>(b.c2);
+    return r;
+}
+LG_DEV QM mulmmt(const QM &a, const QM &b) {    // a b^T
+    QM r;
+    r.c0 = a.c0 * bc<0>(b.c0) + a.c1 * bc<0>(b.c1) + a.c2 * bc<0>(b.c2);
+    r.c1 = a.c0 * bc<1>(b.c0) + a.c1 * bc<1>(b.c1) + a.c2 * bc<1>(b.c2);
+    r.c2 = a.c0 * bc<2>(b.c0) + a.c1 * bc<2>(b.c1) + a.c2 * bc<2>(b.c2);
+    return r;
+}
+LG_DEV float multv(const Lane &L, const QM &m, float v) {   // m^T v
+    return L.sel(sum3(m.c0 * v), sum3(m.c1 * v), sum3(m.c2 * v));
+}
+LG_DEV QM operator+(const QM &a, const QM &b) { QM r = {a.c0 + b.c0, a.c1 + b.c1, a.c2 + b.c2}; return r; }
+LG_DEV QM operator-(const QM &a, const QM &b) { QM r = {a.c0 - b.c0, a.c1 - b.c1, a.c2 - b.c2}; return r; }
+LG_DEV QM operator-(const QM &a) { QM r = {-a.c0, -a.c1, -a.c2}; return r; }
+// rows of [v]x : S_cj = -[c == j-1] v_{j+1} + [c == j+1] v_{j+2}
+LG_DEV QM skew(const Lane &L, float v) {
+    const float v0 = bc<0>(v), v1 = bc<1>(v), v2 = bc<2>(v);
+    QM r;
+    r.c0 = L.d1 * v2 - L.d2 * v1;     // column 0: row 1 holds +v2, row 2 holds -v1
+    r.c1 = L.d2 * v0 - L.d0 * v2;     // column 1: row 2 holds +v0, row 0 holds -v2
+    r.c2 = L.d0 * v1 - L.d1 * v0;     // column 2: row 0 holds +v1, row 1 holds -v0
+    return r;
+}
+// inverse of a symmetric 3x3 (rows): row c of the inverse = (row c+1) x (row c+2) / det
+LG_DEV QM inv_sym(const Lane &L, const QM &m) {
+    const float u0 = rot1(m.c0), u1 = rot1(m.c1), u2 = rot1(m.c2), w0 = rot2(m.c0), w1 = rot2(m.c1), w2 = rot2(m.c2);
+    const float x0 = u1 * w2 - u2 * w1, x1 = u2 * w0 - u0 * w2, x2 = u0 * w1 - u1 * w0;
+    float det = m.c0 * x0 + m.c1 * x1 + m.c2 * x2;
+    det = L.is3 ? 1.f : det;
+    const float inv = __builtin_amdgcn_rcpf(det);
+    QM r = {x0 * inv, x1 * inv, x2 * inv};
+    return r;
+}
+LG_DEV QV6 operator+(const QV6 &a, const QV6 &b) { QV6 r = {a.a + b.a, a.l + b.l}; return r; }
+LG_DEV QV6 operator-(const QV6 &a, const QV6 &b) { QV6 r = {a.a - b.a, a.l - b.l}; return r; }
+LG_DEV QV6 operator*(const QV6 &a, float s) { QV6 r = {a.a * s, a.l * s}; return r; }
+LG_DEV float dot6(const QV6 &a, const QV6 &b) { return sum3(a.a * b.a + a.l * b.l); }
+LG_DEV QV6 muli6(const QI6 &I, const QV6 &v) {
+    const float a0 = bc<0>(v.a), a1 = bc<1>(v.a), a2 = bc<2>(v.a), l0 = bc<0>(v.l), l1 = bc<1>(v.l), l2 = bc<2>(v.l);
+    QV6 r;
+    r.a = I.A.c0 * a0 + I.A.c1 * a1 + I.A.c2 * a2 + I.B.c0 * l0 + I.B.c1 * l1 + I.B.c2 * l2;
+    r.l = I.Bt.c0 * a0 + I.Bt.c1 * a1 + I.Bt.c2 * a2 + I.C.c0 * l0 + I.C.c1 * l1 + I.C.c2 * l2;
+    return r;
+}
+LG_DEV QI6 operator+(const QI6 &a, const QI6 &b) { QI6 r = {a.A + b.A, a.B + b.B, a.Bt + b.Bt, a.C + b.C}; return r; }
+// I - U U^T dinv
+LG_DEV QI6 rank1_down(const QI6 &I, const QV6 &U, float dinv) {
+    const float ua = U.a * dinv, ul = U.l * dinv;
+    const float a0 = bc<0>(U.a), a1 = bc<1>(U.a), a2 = bc<2>(U.a), l0 = bc<0>(U.l), l1 = bc<1>(U.l), l2 = bc<2>(U.l);
+    QI6 r;
+    r.A.c0 = I.A.c0 - ua * a0; r.A.c1 = I.A.c1 - ua * a1; r.A.c2 = I.A.c2 - ua * a2;
+    r.B.c0 = I.B.c0 - ua * l0; r.B.c1 = I.B.c1 - ua * l1; r.B.c2 = I.B.c2 - ua * l2;
+    r.Bt.c0 = I.Bt.c0 - ul * a0; r.Bt.c1 = I.Bt.c1 - ul * a1; r.Bt.c2 = I.Bt.c2 - ul * a2;
+    r.C.c0 = I.C.c0 - ul * l0; r.C.c1 = I.C.c1 - ul * l1; r.C.c2 = I.C.c2 - ul * l2;
+    return r;
+}
+// inverse of an SPD 6x6 by Schur complement on the C block
+LG_DEV QI6 inv6(const Lane &L, const QI6 &N) {
+    const QM Ci = inv_sym(L, N.C);
+    const QM T = mulmm(N.B, Ci);            // B C^-1
+    const QM S = N.A - mulmm(T, N.Bt);      // A - B C^-1 B^T
+    const QM Si = inv_sym(L, S);
+    const QM Y = mulmm(Ci, N.Bt);           // C^-1 B^T = T^T
+    QI6 r;
+    r.A = Si;
+    r.B = -mulmm(Si, T);
+    r.Bt = -mulmm(Y, Si);
+    r.C = Ci - mulmm(Y, r.B);
+    return r;
+}
+// rigid-body spatial inertia about O (world axes): mass m, centre cw, rotational inertia Icw about the centre
+LG_DEV QI6 rigid(const Lane &L, float m, float cw, const QM &Icw) {
+    const float cc = dot3(cw, cw), mc = m * cw, mcc = m * cc;
+    QI6 r;
+    r.A.c0 = Icw.c0 + mcc * L.d0 - mc * bc<0>(cw);
+    r.A.c1 = Icw.c1 + mcc * L.d1 - mc * bc<1>(cw);
+    r.A.c2 = Icw.c2 + mcc * L.d2 - mc * bc<2>(cw);
+    r.B = skew(L, mc);
+    r.Bt = -r.B;
+    r.C.c0 = m * L.d0; r.C.c1 = m * L.d1; r.C.c2 = m * L.d2;
+    return r;
+}
+LG_DEV QM quat_rows(const Lane &L, float qv) {   // qv: (x, y, z, w) across the quad
+    const float w = bc<3>(qv), w2 = 2.f * w, a = w2 * w - 1.f, v2 = 2.f * qv;
+    const QM S = skew(L, qv);
+    QM r;
+    r.c0 = a * L.d0 + w2 * S.c0 + v2 * bc<0>(qv);
+    r.c1 = a * L.d1 + w2 * S.c1 + v2 * bc<1>(qv);
+    r.c2 = a * L.d2 + w2 * S.c2 + v2 * bc<2>(qv);
+    return r;
+}
+
+struct QJoint { QV6 S, U, c; float dinv, u; };
+struct QKin { QM R; float P; QV6 V; };
+struct Terr { int rows, cols; float border, ihs, vscale; const int16_t *hf; };
+
+// terrain height and unit normal at world (x, y) -- scalar form, any lane
+LG_DEV void terrain(const Terr &T, float x, float y, float &h, float &nx, float &ny, float &nz) {
+    if (T.rows <= 0) { h = 0.f; nx = ny = 0.f; nz = 1.f; return; }
+    const float gx = (x + T.border) * T.ihs, gy = (y + T.border) * T.ihs;
+    int ix = (int)floorf(gx), iy = (int)floorf(gy);
+    ix = min(max(ix, 0), T.rows - 2);
+    iy = min(max(iy, 0), T.cols - 2);
+    const float fx = fminf(fmaxf(gx - ix, 0.f), 1.f), fy = fminf(fmaxf(gy - iy, 0.f), 1.f);
+    const int16_t *q = T.hf + ix * T.cols + iy;
+    const float h00 = q[0] * T.vscale, h10 = q[T.cols] * T.vscale, h01 = q[1] * T.vscale, h11 = q[T.cols + 1] * T.vscale;
+    h = (h00 * (1 - fx) + h10 * fx) * (1 - fy) + (h01 * (1 - fx) + h11 * fx) * fy;
+    const float hx = ((h10 - h00) * (1 - fy) + (h11 - h01) * fy) * T.ihs;
+    const float hy = ((h01 - h00) * (1 - fx) + (h11 - h10) * fx) * T.ihs;
+    const float inv = rsqrtf(hx * hx + hy * hy + 1.f);
+    nx = -hx * inv; ny = -hy * inv; nz = inv;
+}
+
+// response sweeps (see resp_up / resp_down in lg_kernel.hip); du replicated, tl / dqdd in joint lanes
+LG_DEV QV6 resp_up(const QJoint (&J)[3], const QV6 &fspat, float tl, float (&du)[3]) {
+    QV6 dp = {-fspat.a, -fspat.l};
+    du[2] = bc<2>(tl) - dot6(J[2].S, dp); dp = dp + J[2].U * (du[2] * J[2].dinv);
+    du[1] = bc<1>(tl) - dot6(J[1].S, dp); dp = dp + J[1].U * (du[1] * J[1].dinv);
+    du[0] = bc<0>(tl) - dot6(J[0].S, dp); dp = dp + J[0].U * (du[0] * J[0].dinv);
+    return dp;
+}
+LG_DEV QV6 resp_down(const Lane &L, const QJoint (&J)[3], const QV6 &a0, const float (&du)[3], float &dqdd) {
+    QV6 a = a0;
+    const float d0 = (du[0] - dot6(J[0].U, a)) * J[0].dinv; a = a + J[0].S * d0;
+    const float d1 = (du[1] - dot6(J[1].U, a)) * J[1].dinv; a = a + J[1].S * d1;
+    const float d2 = (du[2] - dot6(J[2].U, a)) * J[2].dinv; a = a + J[2].S * d2;
+    dqdd = L.sel(d0, d1, d2);
+    return a;
+}
+
+}  // namespace q4
+
+// ---------------------------------------------------------------------------------------------
+template <int LEGS, bool DO_PRE>
+__global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
+    using namespace q4;
+    constexpr int A = 3 * LEGS;
+    const LgModelDesc *__restrict__ Mg = p.M;
+    __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_STG * BLOCK];
+    const LgModelDesc *M = reinterpret_cast<const LgModelDesc *>(sMraw);
+    const LgSimOptions *__restrict__ O = p.O;
+    __shared__ int sHot[256 + BLOCK];
+    int hv0, hv1, hv2, hv3;
+    {
+        const int *hp = reinterpret_cast<const int *>(p.H) + (threadIdx.x & 63);
+        hv0 = hp[0]; hv1 = hp[64]; hv2 = hp[128]; hv3 = hp[192];
+    }
+    uint4 stg0, stg1, stg2, stg3;
+    {
+        const uint4 *src = reinterpret_cast<const uint4 *>(Mg);
+        stg0 = src[threadIdx.x]; stg1 = src[threadIdx.x + BLOCK]; stg2 = src[threadIdx.x + 2 * BLOCK]; stg3 = src[threadIdx.x + 3 * BLOCK];
+    }
+    const LgBuffers &B = p.B;
+    const int tid = blockIdx.x * BLOCK + threadIdx.x;
+    Lane L;
+    L.c = tid & 3; L.is0 = L.c == 0; L.is1 = L.c == 1; L.is2 = L.c == 2; L.is3 = L.c == 3;
+    L.d0 = L.is0 ? 1.f : 0.f; L.d1 = L.is1 ? 1.f : 0.f; L.d2 = L.is2 ? 1.f : 0.f;
+    const int cj = min(L.c, 2);               // lane 3 shadows lane 2's addresses; it never stores
+    const int quad = tid >> 2, leg = quad % LEGS;
+    int e = quad / LEGS;
+    const int N = B.n_envs;
+    const bool live = e < N;
+    if (!live) e = N - 1;
+    const bool st = live && !L.is3;           // this lane stores vector components / joint values
+    const bool lead = st && leg == 0;         // ... and the per-env ones
+    const int nL = HOT0(m_n_links), F = LEGS;
+    const int b0 = 1 + 3 * leg, d0 = 3 * leg;
+    const int foot_link = leg == 0 ? HOT0(m_foot_link[0]) : (leg == 1 ? HOT0(m_foot_link[1]) : (leg == 2 ? HOT0(m_foot_link[2]) : HOT0(m_foot_link[3])));
+    int foot_slot = 0;
+#pragma unroll
+    for (int k = 0; k < LEGS; k++) foot_slot += (HOT0(m_foot_link[k]) < foot_link) ? 1 : 0;
+
+    // ---------------- start-of-kernel loads (one burst, one wait) --------------------------------
+    const int ja = e * A + d0 + cj;           // this lane's joint
+    float act, last_act = 0.f, llast_act = 0.f;
+    if (DO_PRE) {
+        const float ca = HOT0(clip_actions);
+        last_act = B.actions[ja]; llast_act = B.last_actions[ja];
+        act = clampf(p.actions[ja], -ca, ca);
+    } else {
+        act = p.actions ? p.actions[ja] : B.actions[ja];
+    }
+    float pos = B.base_pos[3 * e + cj], vw = B.base_lin_vel_w[3 * e + cj], ww = B.base_ang_vel_w[3 * e + cj];
+    float quat = B.base_quat[4 * e + L.c];
+    float q = B.dof_pos[ja], qd = B.dof_vel[ja];
+    const float snap_fv = B.feet_vel[(e * F + foot_slot) * 3 + cj];
+    const float snap_blv = B.base_lin_vel[3 * e + cj], snap_bav = B.base_ang_vel[3 * e + cj];
+    const float dr_mass = B.added_base_mass ? B.added_base_mass[e] : 0.f;
+    const float dr_com = B.base_com_bias ? B.base_com_bias[3 * e + cj] : 0.f;
+    const float dr_fric = B.friction_values ? B.friction_values[e] : 1.f;
+    const float dr_kp = B.kp_scale ? B.kp_scale[ja] : 1.f, dr_kd = B.kd_scale ? B.kd_scale[ja] : 1.f;
+    const float gain_p = O->kp[d0 + cj], gain_d = O->kd[d0 + cj], q0 = O->default_dof_pos[d0 + cj];
+    float dr_arm = 0.f, dr_jf = 0.f, dr_jd = 0.f;
+    if (B.joint_armature) { dr_arm = B.joint_armature[e]; dr_jf = B.joint_friction[e]; dr_jd = B.joint_damping[e]; }
+    const float origin = B.env_origins ? B.env_origins[3 * e + cj] : 0.f;
+
+    asm volatile("" ::: "memory");
+    sHot[threadIdx.x] = hv0; sHot[threadIdx.x + 64] = hv1; sHot[threadIdx.x + 128] = hv2; sHot[threadIdx.x + 192] = hv3;
+    sMraw[threadIdx.x] = stg0; sMraw[threadIdx.x + BLOCK] = stg1; sMraw[threadIdx.x + 2 * BLOCK] = stg2; sMraw[threadIdx.x + 3 * BLOCK] = stg3;
+    __syncthreads();
+
+    // ---------------- prologue stores ---------------------------------------------------------------
+    if (DO_PRE && st) {
+        B.llast_actions[ja] = llast_act;
+        B.last_actions[ja] = last_act;
+        B.actions[ja] = act;
+    }
+    const float last_foot_v = snap_fv;
+    if (st) {   // "last" snapshots (genesis_simulator.py:21-24)
+        B.last_dof_vel[ja] = qd;
+        B.last_feet_vel[(e * F + foot_slot) * 3 + cj] = snap_fv;
+        if (leg == 0) { B.last_base_lin_vel[3 * e + cj] = snap_blv; B.last_base_ang_vel[3 * e + cj] = snap_bav; }
+    }
+    (void)last_foot_v;
+
+    // ---------------- constants ---------------------------------------------------------------------
+    const float dt = HOT(o_dt), kc = HOT(o_contact_k), kappa = kc * dt + HOT(o_contact_b), margin = HOT(o_contact_margin);
+    const float kl = HOT(o_limit_k), kapl = kl * dt + HOT(o_limit_b), lmargin = HOT(o_limit_margin);
+    const float gravc = L.d2 * HOT(o_gravity_z);          // gravity vector, this lane's component
+    const float mu = HOT(o_terrain_friction) * dr_fric;
+    const float ascale = HOT(o_action_scale);
+    Terr TR;
+    TR.rows = HOT(o_terrain_rows); TR.cols = HOT(o_terrain_cols); TR.border = HOT(o_border); TR.ihs = 1.f / HOT(o_hscale);
+    TR.vscale = HOT(o_vscale); TR.hf = p.hf;
+    const bool hfmode = TR.rows > 0;
+    const float mass0 = M->mass[0] + dr_mass;
+    const float com0 = M->com[0][cj] + dr_com;
+    auto sym_row = [&](const float *s6) {   // rows of a symmetric 3x3 stored (xx, yy, zz, xy, xz, yz)
+        QM r = {s6[L.is0 ? 0 : (L.is1 ? 3 : 4)], s6[L.is0 ? 3 : (L.is1 ? 1 : 5)], s6[L.is0 ? 4 : (L.is1 ? 5 : 2)]};
+        return r;
+    };
+    const QM I0 = sym_row(M->inertia[0]);
+    float Lm[3], Lcom[3], Ljpos[3], Lax[3];
+    QM LIc[3], LK1[3], LK2[3];
+#pragma unroll
+    for (int j = 0; j < 3; j++) {
+        const int b = b0 + j;
+        Lm[j] = M->mass[b]; Lcom[j] = M->com[b][cj]; Ljpos[j] = M->jpos[b][cj]; Lax[j] = M->axis[b][cj];
+        LIc[j] = sym_row(M->inertia[b]);
+        LK1[j] = skew(L, Lax[j]);
+        LK2[j].c0 = Lax[j] * bc<0>(Lax[j]); LK2[j].c1 = Lax[j] * bc<1>(Lax[j]); LK2[j].c2 = Lax[j] * bc<2>(Lax[j]);
+    }
+    // joint-lane constants
+    const float Lqlo = M->q_lo[d0 + cj], Lqhi = M->q_hi[d0 + cj], Leff = M->effort[d0 + cj];
+    const float Lvlim = HOT(o_joint_vel_clamp) * M->vel_limit[d0 + cj];
+    const float kps = dr_kp * gain_p, kds = dr_kd * gain_d;
+    const float arm = B.joint_armature ? dr_arm : M->armature[d0 + cj];
+    const float jfric = B.joint_friction ? dr_jf : M->frictionloss[d0 + cj];
+    const float jdamp = B.joint_damping ? dr_jd : M->damping[d0 + cj];
+    const bool jrot_identity = p.jrot_identity != 0;
+    const int fs = leg == 0 ? HOT(m_foot_sphere[0]) : (leg == 1 ? HOT(m_foot_sphere[1]) : (leg == 2 ? HOT(m_foot_sphere[2]) : HOT(m_foot_sphere[3])));
+    const float foot_c_loc = M->sph_pos[fs][cj], foot_r = M->sph_r[fs];
+
+    // collision spheres (foot excluded): five "slots", in each the four lanes of the quad test four different
+    // spheres of the SAME body in scalar form.  slot 0: hip, 1: thigh, 2-3: calf, 4: base (4 per quad)
+    constexpr int NSLOT = 5;
+    float sx[NSLOT], sy[NSLOT], sz[NSLOT], srad[NSLOT], sw[NSLOT];
+    {
+        const int a0 = M->body_sph_start[b0], a1 = M->body_sph_start[b0 + 1], a2 = M->body_sph_start[b0 + 2], a3 = M->body_sph_start[b0 + 3];
+        const int e0 = M->body_sph_start[0], e1 = M->body_sph_start[1];
+        int idx[NSLOT];
+        idx[0] = a0 + L.c < a1 ? a0 + L.c : -1;
+        idx[1] = a1 + L.c < a2 ? a1 + L.c : -1;
+#pragma unroll
+        for (int k = 0; k < 2; k++) {          // n-th non-foot sphere of the calf, n = 4k + c
+            int s = a2 + 4 * k + L.c;
+            if (s >= fs) s++;                  // the foot sphere is one of [a2, a3): skip over it
+            idx[2 + k] = s < a3 ? s : -1;
+        }
+        idx[4] = e0 + leg * 4 + L.c < e1 ? e0 + leg * 4 + L.c : -1;
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++) {
+            const int s = max(idx[k], 0);
+            sx[k] = M->sph_pos[s][0]; sy[k] = M->sph_pos[s][1]; sz[k] = M->sph_pos[s][2];
+            srad[k] = idx[k] >= 0 ? M->sph_r[s] : -1e30f;    // an empty slot is infinitely far from any surface
+            sw[k] = M->sph_w[s];
+        }
+    }
+
+    float torque = 0.f;
+    float f_link[4] = {0.f, 0.f, 0.f, 0.f};   // net contact force on hip, thigh, calf, foot links (component)
+    float f_base = 0.f;
+
+    const int decim = HOT(o_decimation), iters = HOT(o_contact_iters);
+    const float mv = HOT(o_max_base_lin_vel), mw = HOT(o_max_base_ang_vel);
+
+    for (int sub = 0; sub < decim; sub++) {
+        const QM Rb = quat_rows(L, quat);
+        QKin K[3];
+        QJoint J[3];
+        // ---- chain kinematics (root -> leaf) --------------------------------------------------------
+        {
+            float sv, cv;
+            __sincosf(q, &sv, &cv);      // the three joint angles of the leg at once
+            QM Rp = Rb;
+            float Pp = 0.f;
+            QV6 Vp = {ww, vw};
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                K[j].P = Pp + mulv(Rp, Ljpos[j]);
+                QM Rfix = Rp;
+                if (!jrot_identity) {
+                    const float *jr = M->jrot[b0 + j] + 3 * cj;
+                    const QM jrr = {jr[0], jr[1], jr[2]};
+                    Rfix = mulmm(Rp, jrr);
+                }
+                const float s = mulv(Rfix, Lax[j]);
+                const float cq = j == 0 ? bc<0>(cv) : (j == 1 ? bc<1>(cv) : bc<2>(cv));
+                const float sq = j == 0 ? bc<0>(sv) : (j == 1 ? bc<1>(sv) : bc<2>(sv));
+                const float tq = 1.f - cq;
+                QM Rl;   // Rodrigues: c I + s [ax]x + (1 - c) ax ax^T
+                Rl.c0 = cq * L.d0 + sq * LK1[j].c0 + tq * LK2[j].c0;
+                Rl.c1 = cq * L.d1 + sq * LK1[j].c1 + tq * LK2[j].c1;
+                Rl.c2 = cq * L.d2 + sq * LK1[j].c2 + tq * LK2[j].c2;
+                K[j].R = mulmm(Rfix, Rl);
+                J[j].S.a = s;
+                J[j].S.l = cross(K[j].P, s);
+                const float qdj = j == 0 ? bc<0>(qd) : (j == 1 ? bc<1>(qd) : bc<2>(qd));
+                K[j].V.a = Vp.a + s * qdj;
+                K[j].V.l = Vp.l + J[j].S.l * qdj;
+                J[j].c.a = cross(K[j].V.a, s) * qdj;
+                J[j].c.l = (cross(K[j].V.a, J[j].S.l) + cross(K[j].V.l, s)) * qdj;
+                Rp = K[j].R; Pp = K[j].P; Vp = K[j].V;
+            }
+        }
+        // ---- body collision spheres -----------------------------------------------------------------
+        // ext[b]: spatial force about O on chain body b from its spheres; extb: on the base (this quad's share)
+        QV6 ext[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, extb = {0.f, 0.f};
+        {
+            const float px = bc<0>(pos), py = bc<1>(pos), pz = bc<2>(pos);
+            auto slot = [&](int k, const QM &R, float P, const QV6 &V, QV6 &acc) {
+                // scalar-form pose of the body in every lane
+                const float zx = bc<2>(R.c0), zy = bc<2>(R.c1), zz = bc<2>(R.c2), Pz = bc<2>(P);
+                float rx = 0.f, ry = 0.f, h = 0.f, nx = 0.f, ny = 0.f, nz = 1.f;
+                const float rz = Pz + zx * sx[k] + zy * sy[k] + zz * sz[k];
+                if (hfmode) {
+                    rx = bc<0>(P) + bc<0>(R.c0) * sx[k] + bc<0>(R.c1) * sy[k] + bc<0>(R.c2) * sz[k];
+                    ry = bc<1>(P) + bc<1>(R.c0) * sx[k] + bc<1>(R.c1) * sy[k] + bc<1>(R.c2) * sz[k];
+                    terrain(TR, px + rx, py + ry, h, nx, ny, nz);
+                }
+                const float depth = srad[k] - (pz + rz - h) * nz;
+                const bool on = depth > -margin;
+                if (__builtin_amdgcn_ballot_w64(on) != 0ull) {      // rare: some sphere of this slot, somewhere in the wave
+                    if (!hfmode) {
+                        rx = bc<0>(P) + bc<0>(R.c0) * sx[k] + bc<0>(R.c1) * sy[k] + bc<0>(R.c2) * sz[k];
+                        ry = bc<1>(P) + bc<1>(R.c0) * sx[k] + bc<1>(R.c1) * sy[k] + bc<1>(R.c2) * sz[k];
+                    }
+                    const float wx = bc<0>(V.a), wy = bc<1>(V.a), wz = bc<2>(V.a);
+                    const float vx = bc<0>(V.l) + (wy * rz - wz * ry), vy = bc<1>(V.l) + (wz * rx - wx * rz), vz = bc<2>(V.l) + (wx * ry - wy * rx);
+                    const float vn = vx * nx + vy * ny + vz * nz, wi = sw[k];
+                    const float fn = (kc * depth - kappa * vn) * rcp(1.f + kappa * dt * wi);
+                    float fx = 0.f, fy = 0.f, fz = 0.f;
+                    if (on && fn > 0.f) {
+                        const float tx = vx - nx * vn, ty = vy - ny * vn, tz = vz - nz * vn;
+                        const float vtn = sqrtf(tx * tx + ty * ty + tz * tz);
+                        const float ft = fminf(vtn * rcp(dt * wi), mu * fn);
+                        const float g = vtn > 1e-9f ? ft * rcp(vtn) : 0.f;
+                        fx = nx * fn - tx * g; fy = ny * fn - ty * g; fz = nz * fn - tz * g;
+                    }
+                    const float cx = rx - nx * srad[k], cy = ry - ny * srad[k], cz = rz - nz * srad[k];
+                    const float mx = sum4(cy * fz - cz * fy), my = sum4(cz * fx - cx * fz), mz = sum4(cx * fy - cy * fx);
+                    fx = sum4(fx); fy = sum4(fy); fz = sum4(fz);
+                    acc.a += L.sel(mx, my, mz);
+                    acc.l += L.sel(fx, fy, fz);
+                }
+            };
+            const QV6 V0 = {ww, vw};
+            slot(4, Rb, 0.f, V0, extb);
+            slot(0, K[0].R, K[0].P, K[0].V, ext[0]);
+            slot(1, K[1].R, K[1].P, K[1].V, ext[1]);
+            slot(2, K[2].R, K[2].P, K[2].V, ext[2]);
+            slot(3, K[2].R, K[2].P, K[2].V, ext[2]);
+        }
+        f_link[0] = ext[0].l; f_link[1] = ext[1].l; f_link[2] = ext[2].l;
+
+        // ---- actuation (genesis_simulator.py:630-642), three joints at once ---------------------------
+        torque = kps * (act * ascale + q0 - q) - kds * qd;
+        const float tau = clampf(torque, -Leff, Leff) - jdamp * qd - jfric * clampf(qd * 20.f, -1.f, 1.f);
+
+        // ---- ABA pass 2 (leaf -> root) ------------------------------------------------------------
+        QI6 IA;
+        QV6 pacc;
+        float dinvv = 0.f;      // 1/D of the three joints in joint lanes
+#pragma unroll
+        for (int j = 2; j >= 0; j--) {
+            const float m = Lm[j];
+            const float cw = K[j].P + mulv(K[j].R, Lcom[j]);
+            const QM Icw = mulmmt(mulmm(K[j].R, LIc[j]), K[j].R);
+            const float vc = K[j].V.l + cross(K[j].V.a, cw);
+            const float Pm = vc * m;
+            const float Lmo = mulv(Icw, K[j].V.a) + cross(cw, Pm);
+            const float fg = gravc * m;
+            QV6 pb;
+            pb.a = cross(K[j].V.a, Lmo) + cross(K[j].V.l, Pm) - cross(cw, fg) - ext[j].a;
+            pb.l = cross(K[j].V.a, Pm) - fg - ext[j].l;
+            const QI6 Ib = rigid(L, m, cw, Icw);
+            if (j == 2) { IA = Ib; pacc = pb; }
+            else { IA = IA + Ib; pacc = pacc + pb; }
+            J[j].U = muli6(IA, J[j].S);
+            const float armj = j == 0 ? bc<0>(arm) : (j == 1 ? bc<1>(arm) : bc<2>(arm));
+            const float tauj = j == 0 ? bc<0>(tau) : (j == 1 ? bc<1>(tau) : bc<2>(tau));
+            J[j].dinv = rcp(dot6(J[j].S, J[j].U) + armj);
+            J[j].u = tauj - dot6(J[j].S, pacc);
+            const QV6 Ic6 = muli6(IA, J[j].c);
+            const float k = (J[j].u - dot6(J[j].U, J[j].c)) * J[j].dinv;
+            pacc = pacc + Ic6 + J[j].U * k;
+            IA = rank1_down(IA, J[j].U, J[j].dinv);
+            if (L.c == j) dinvv = J[j].dinv;
+        }
+        // ---- base ---------------------------------------------------------------------------------
+        QI6 IA0;
+        IA0.A.c0 = legsum<LEGS>(IA.A.c0); IA0.A.c1 = legsum<LEGS>(IA.A.c1); IA0.A.c2 = legsum<LEGS>(IA.A.c2);
+        IA0.B.c0 = legsum<LEGS>(IA.B.c0); IA0.B.c1 = legsum<LEGS>(IA.B.c1); IA0.B.c2 = legsum<LEGS>(IA.B.c2);
+        IA0.Bt.c0 = legsum<LEGS>(IA.Bt.c0); IA0.Bt.c1 = legsum<LEGS>(IA.Bt.c1); IA0.Bt.c2 = legsum<LEGS>(IA.Bt.c2);
+        IA0.C.c0 = legsum<LEGS>(IA.C.c0); IA0.C.c1 = legsum<LEGS>(IA.C.c1); IA0.C.c2 = legsum<LEGS>(IA.C.c2);
+        QV6 p0 = {legsum<LEGS>(pacc.a - extb.a), legsum<LEGS>(pacc.l - extb.l)};
+        {
+            const float cw = mulv(Rb, com0);
+            const QM Icw = mulmmt(mulmm(Rb, I0), Rb);
+            IA0 = IA0 + rigid(L, mass0, cw, Icw);
+            const float vc = vw + cross(ww, cw);
+            const float Pm = vc * mass0;
+            const float Lmo = mulv(Icw, ww) + cross(cw, Pm);
+            const float fg = gravc * mass0;
+            p0.a += cross(ww, Lmo) + cross(vw, Pm) - cross(cw, fg);
+            p0.l += cross(ww, Pm) - fg;
+        }
+        const QI6 Inv = inv6(L, IA0);
+        QV6 a0 = muli6(Inv, QV6{-p0.a, -p0.l});
+        // ---- pass 3 (root -> leaf) ----------------------------------------------------------------
+        float qdd;
+        QV6 a_calf;
+        {
+            QV6 a = a0;
+            a = a + J[0].c; const float g0 = (J[0].u - dot6(J[0].U, a)) * J[0].dinv; a = a + J[0].S * g0;
+            a = a + J[1].c; const float g1 = (J[1].u - dot6(J[1].U, a)) * J[1].dinv; a = a + J[1].S * g1;
+            a = a + J[2].c; const float g2 = (J[2].u - dot6(J[2].U, a)) * J[2].dinv; a = a + J[2].S * g2;
+            qdd = L.sel(g0, g1, g2);
+            a_calf = a;
+        }
+        // ---- stage 2: foot contact (exact 3x3 W) + joint-limit stops, block-Jacobi ----------------------
+        float fc = 0.f;                       // foot force in the contact frame (n, t1, t2), component layout
+        float cn, ct1 = L.d0, ct2 = L.d1, cp, depth;
+        bool fact;
+        {
+            const float r = K[2].P + mulv(K[2].R, foot_c_loc);
+            float h, nx, ny, nz;
+            terrain(TR, bc<0>(pos) + bc<0>(r), bc<1>(pos) + bc<1>(r), h, nx, ny, nz);
+            depth = foot_r - (bc<2>(pos) + bc<2>(r) - h) * nz;
+            fact = depth > -margin;
+            cn = L.sel(nx, ny, nz);
+            cp = r - cn * foot_r;
+            if (hfmode) {   // tangent frame on a slope (identity on the plane)
+                const float t = L.d0 - nx * cn;
+                const float t1 = t * rsqrtf(dot3(t, t));
+                const bool tilt = nz < 0.999999f;
+                ct1 = tilt ? t1 : ct1;
+                ct2 = tilt ? cross(cn, t1) : ct2;
+            }
+        }
+        float lim_e = 0.f, lim_s = 0.f, lim_T = 0.f;
+        if (!L.is3) {
+            if (q < Lqlo + lmargin) { lim_s = 1.f; lim_e = Lqlo - q; }
+            else if (q > Lqhi - lmargin) { lim_s = -1.f; lim_e = q - Lqhi; }
+        }
+        float dqdd = 0.f;
+        QV6 da0 = {0.f, 0.f};
+        if (__builtin_amdgcn_ballot_w64(fact || lim_s != 0.f) != 0ull) {
+            // contact-frame projector: row r of E = axis r (n, t1, t2)
+            QM E;
+            E.c0 = L.sel(bc<0>(cn), bc<0>(ct1), bc<0>(ct2));
+            E.c1 = L.sel(bc<1>(cn), bc<1>(ct1), bc<1>(ct2));
+            E.c2 = L.sel(bc<2>(cn), bc<2>(ct1), bc<2>(ct2));
+            const QM ET = {cn, ct1, ct2};
+            QM Ac;      // dt * W, contact frame, rows
+            {
+                float du[3], dq;
+                const float axs[3] = {cn, ct1, ct2};
+                float col[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) {
+                    const QV6 fsp = {cross(cp, axs[k]), axs[k]};
+                    const QV6 dp = resp_up(J, fsp, 0.f, du);
+                    const QV6 ab = muli6(Inv, QV6{-dp.a, -dp.l});
+                    const QV6 ac = resp_down(L, J, ab, du, dq);
+                    const float ra = ac.l + cross(ac.a, cp);
+                    col[k] = dt * mulv(E, ra);
+                }
+                Ac.c0 = col[0]; Ac.c1 = col[1]; Ac.c2 = col[2];
+            }
+            float vfree;
+            {
+                const float vpt = K[2].V.l + cross(K[2].V.a, cp);
+                const float apt = a_calf.l + cross(a_calf.a, cp) + cross(K[2].V.a, vpt);
+                vfree = mulv(E, vpt + apt * dt);
+            }
+            float resp_c = 0.f;
+            for (int it = 0; it < iters; it++) {
+                // foot: velocity it would have without its own force, then the local law
+                {
+                    const float vo = vfree + resp_c * dt - mulv(Ac, fc);
+                    const float vo0 = bc<0>(vo);
+                    const float rn = kc * depth - kappa * vo0;
+                    // stick trial: rows of [1 + kappa A00, kappa A01, kappa A02; A1.; A2.]
+                    QM m;
+                    m.c0 = L.is0 ? 1.f + kappa * Ac.c0 : Ac.c0;
+                    m.c1 = L.is0 ? kappa * Ac.c1 : Ac.c1;
+                    m.c2 = L.is0 ? kappa * Ac.c2 : Ac.c2;
+                    const float rhs = L.is0 ? rn : -vo;
+                    // Cramer: column c of adj = (row c+1) x (row c+2)
+                    const float u0 = rot1(m.c0), u1 = rot1(m.c1), u2 = rot1(m.c2), w0 = rot2(m.c0), w1 = rot2(m.c1), w2 = rot2(m.c2);
+                    const float x0 = u1 * w2 - u2 * w1, x1 = u2 * w0 - u0 * w2, x2 = u0 * w1 - u1 * w0;
+                    const float det = bc<0>(m.c0 * x0 + m.c1 * x1 + m.c2 * x2);
+                    const float inv = rcp(det);
+                    float f0 = sum3(x0 * rhs) * inv, f1 = sum3(x1 * rhs) * inv, f2 = sum3(x2 * rhs) * inv;
+                    bool ok = fact && fabsf(det) >= 1e-30f && f0 > 0.f;
+                    const float A00 = bc<0>(Ac.c0), A01 = bc<0>(Ac.c1), A02 = bc<0>(Ac.c2);   // DPP stays outside the branch
+                    const float ftn = sqrtf(f1 * f1 + f2 * f2);
+                    const float iftn = rcp(ftn), e1 = f1 * iftn, e2 = f2 * iftn;
+                    const float fn = rn * rcp(1.f + kappa * (A00 + mu * (A01 * e1 + A02 * e2)));
+                    if (ftn > mu * f0) { ok = ok && fn > 0.f; f0 = fn; f1 = mu * fn * e1; f2 = mu * fn * e2; }
+                    fc = ok ? L.sel(f0, f1, f2) : 0.f;
+                }
+                float tl = 0.f;
+                {   // limit stops of the three joints (joint lanes)
+                    float C = dinvv;
+                    if (it > 0 && lim_T > 0.f) C = fminf(fmaxf(lim_s * dqdd * rcp(lim_T), C), 8.f * C);
+                    const float vin = -lim_s * (qd + dt * (qdd + dqdd)) + dt * lim_T * C;
+                    const float Tn = (kl * lim_e + kapl * vin) * rcp(1.f + kapl * dt * C);
+                    lim_T = lim_s != 0.f ? fmaxf(Tn, 0.f) : 0.f;
+                    tl = lim_s * lim_T;
+                }
+                // exact response of the whole robot to the current force set
+                const float fw = mulv(ET, fc);
+                const QV6 fsp = {cross(cp, fw), fw};
+                float du[3];
+                QV6 dp = resp_up(J, fsp, tl, du);
+                dp.a = legsum<LEGS>(dp.a); dp.l = legsum<LEGS>(dp.l);
+                da0 = muli6(Inv, QV6{-dp.a, -dp.l});
+                const QV6 ac = resp_down(L, J, da0, du, dqdd);
+                const float ra = ac.l + cross(ac.a, cp);
+                resp_c = mulv(E, ra);
+            }
+            f_link[3] = mulv(ET, fc);
+        } else {
+            f_link[3] = 0.f;
+        }
+        // ---- semi-implicit Euler ------------------------------------------------------------------
+        {
+            const float alpha = a0.a + da0.a;
+            const float alin = a0.l + da0.l + cross(ww, vw);     // spatial -> classical at O
+            vw = clampf(vw + dt * alin, -mv, mv);
+            ww = clampf(ww + dt * alpha, -mw, mw);
+            qd = clampf(qd + dt * (qdd + dqdd), -Lvlim, Lvlim);
+            q += dt * qd;
+            pos += vw * dt;
+            const float wn = sqrtf(bc<0>(dot3(ww, ww))), half = 0.5f * wn * dt;   // lane 3 (quaternion w) needs the true norm too
+            float sh, chh;
+            __sincosf(half, &sh, &chh);
+            const float sc = wn > 1e-12f ? sh * rcp(wn) : 0.5f * dt;
+            const float d = L.is3 ? 0.f : ww * sc;              // vector part of the step quaternion; scalar part chh
+            const float qw_b = bc<3>(quat);
+            const float dv = sum4(d * quat);                    // d . q_v  (lane 3 contributes 0)
+            const float nq = chh * quat + (L.is3 ? -dv : qw_b * d + cross(d, quat));
+            quat = nq * rsqrtf(sum4(nq * nq));
+        }
+        f_base = legsum<LEGS>(extb.l);
+    }  // sub-steps
+
+    // ---------------- read-back (genesis_simulator.py:35-60) ---------------------------------------
+    {   // non-finite guard: re-seat the robot
+        const float chk = quat + (L.is3 ? 0.f : pos + vw + ww + q + qd);
+        const int bad = env_or<LEGS>(isfinite(chk) ? 0 : 1);
+        const float reseat = HOT(o_base_init_pos[0]) * L.d0 + HOT(o_base_init_pos[1]) * L.d1 + HOT(o_base_init_pos[2]) * L.d2 + origin;
+        if (bad) {
+            pos = reseat; vw = 0.f; ww = 0.f; quat = L.is3 ? 1.f : 0.f;
+            q = q0; qd = 0.f; torque = 0.f;
+            f_link[0] = f_link[1] = f_link[2] = f_link[3] = 0.f; f_base = 0.f;
+        }
+        // out-of-terrain teleport (genesis_simulator.py:612-628)
+        const float px = bc<0>(pos), py = bc<1>(pos);
+        if (px >= HOT(o_bound_x[1]) || px <= HOT(o_bound_x[0]) || py >= HOT(o_bound_y[1]) || py <= HOT(o_bound_y[0])) pos = reseat;
+    }
+    const float qx = bc<0>(quat), qy = bc<1>(quat), qz = bc<2>(quat), qw = bc<3>(quat);
+    float eul;
+    {   // lanes 0 / 2: roll / yaw through one atan2f, lane 1: pitch
+        const float ay = L.is0 ? 2.f * (qw * qx + qy * qz) : 2.f * (qw * qz + qx * qy);
+        const float ax = L.is0 ? qw * qw - qx * qx - qy * qy + qz * qz : qw * qw + qx * qx - qy * qy - qz * qz;
+        const float at = atan2f(ay, ax);
+        const float sinp = 2.f * (qw * qy - qz * qx);
+        const float pit = fabsf(sinp) >= 1.f ? copysignf(1.5707963267948966f, sinp) : asinf(sinp);
+        eul = L.is1 ? pit : at;
+    }
+    const QM Rb = quat_rows(L, quat);
+    const float blv = multv(L, Rb, vw), bav = multv(L, Rb, ww);
+    const float pg = -L.sel(bc<2>(Rb.c0), bc<2>(Rb.c1), bc<2>(Rb.c2));
+    float foot_p, foot_v;
+    {   // foot frame at the final state
+        float sv, cv;
+        __sincosf(q, &sv, &cv);
+        QM Rp = Rb;
+        float Pp = 0.f;
+        QV6 Vp = {ww, vw};
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            const float P = Pp + mulv(Rp, Ljpos[j]);
+            QM Rfix = Rp;
+            if (!jrot_identity) {
+                const float *jr = M->jrot[b0 + j] + 3 * cj;
+                const QM jrr = {jr[0], jr[1], jr[2]};
+                Rfix = mulmm(Rp, jrr);
+            }
+            const float s = mulv(Rfix, Lax[j]);
+            const float cq = j == 0 ? bc<0>(cv) : (j == 1 ? bc<1>(cv) : bc<2>(cv));
+            const float sq = j == 0 ? bc<0>(sv) : (j == 1 ? bc<1>(sv) : bc<2>(sv));
+            const float qdj = j == 0 ? bc<0>(qd) : (j == 1 ? bc<1>(qd) : bc<2>(qd));
+            const float tq = 1.f - cq;
+            QM Rl;
+            Rl.c0 = cq * L.d0 + sq * LK1[j].c0 + tq * LK2[j].c0;
+            Rl.c1 = cq * L.d1 + sq * LK1[j].c1 + tq * LK2[j].c1;
+            Rl.c2 = cq * L.d2 + sq * LK1[j].c2 + tq * LK2[j].c2;
+            Vp.a = Vp.a + s * qdj;
+            Vp.l = Vp.l + cross(P, s) * qdj;
+            Rp = mulmm(Rfix, Rl);
+            Pp = P;
+        }
+        const float r = Pp + mulv(Rp, M->link_pos[foot_link][cj]);
+        foot_p = pos + r;
+        foot_v = Vp.l + cross(Vp.a, r);
+    }
+    if (st) {
+        B.dof_pos[ja] = q; B.dof_vel[ja] = qd; B.torques[ja] = torque;
+        const int l0 = foot_link - 3;
+#pragma unroll
+        for (int k = 0; k < 4; k++) B.link_contact_forces[(e * nL + l0 + k) * 3 + cj] = f_link[k];
+        B.feet_pos[(e * F + foot_slot) * 3 + cj] = foot_p;
+        B.feet_vel[(e * F + foot_slot) * 3 + cj] = foot_v;
+        if (leg == 0) {
+            B.base_pos[3 * e + cj] = pos;
+            B.base_lin_vel_w[3 * e + cj] = vw; B.base_ang_vel_w[3 * e + cj] = ww;
+            B.base_lin_vel[3 * e + cj] = blv; B.base_ang_vel[3 * e + cj] = bav;
+            B.projected_gravity[3 * e + cj] = pg; B.base_euler[3 * e + cj] = eul;
+            B.link_contact_forces[(e * nL) * 3 + cj] = f_base;
+        }
+    }
+    if (live && leg == 0) B.base_quat[4 * e + L.c] = quat;
+
+    // ---------------- terrain sampling around the base and the feet (genesis_simulator.py:552-610) ------
+    const int P = HOT(o_n_height_points);
+    if (P > 0) {
+        const float yn = rcp(fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f));
+        const float yz = qz * yn, yw = qw * yn;
+        const float px = bc<0>(pos), py = bc<1>(pos);
+        for (int k = leg * 4 + L.c; k < P; k += 4 * LEGS) {
+            const float vx = B.height_points[2 * k], vy = B.height_points[2 * k + 1];
+            const float tx = -2.f * yz * vy, ty = 2.f * yz * vx;
+            const float rx = vx + yw * tx - yz * ty, ry = vy + yw * ty + yz * tx;
+            const float h = sample_min3(O, p.hf, rx + px, ry + py);
+            if (live) B.measured_heights[(size_t)e * P + k] = h;
+        }
+        if (HOT(o_feet_terrain_info)) {
+            const float fx = bc<0>(foot_p), fy = bc<1>(foot_p);
+            int gx = (int)((fx + HOT(o_border)) / HOT(o_hscale)), gy = (int)((fy + HOT(o_border)) / HOT(o_hscale));
+            gx = min(max(gx, 0), HOT(o_terrain_rows) - 2);
+            gy = min(max(gy, 0), HOT(o_terrain_cols) - 2);
+            const int Cc = HOT(o_terrain_cols), xm = max(gx - 1, 0), ym = max(gy - 1, 0);
+            const int16_t *hf = p.hf;
+            // order of genesis_simulator.py:591-599
+            const int hh[9] = {hf[xm * Cc + gy], hf[(gx + 1) * Cc + gy], hf[gx * Cc + ym], hf[gx * Cc + gy + 1], hf[gx * Cc + gy],
+                               hf[xm * Cc + ym], hf[(gx + 1) * Cc + gy + 1], hf[xm * Cc + gy + 1], hf[(gx + 1) * Cc + ym]};
+            if (live && L.is0) {
+#pragma unroll
+                for (int k = 0; k < 9; k++) B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k] = (float)hh[k] * HOT(o_vscale);
+                const float dx = (float)(hh[1] - hh[0]) / (HOT(o_hscale) * 2.f), dy = (float)(hh[3] - hh[2]) / (HOT(o_hscale) * 2.f);
+                const float nn = sqrtf(dx * dx + dy * dy + 1.f);
+                st3(B.normal_vector_around_feet + ((size_t)e * F + foot_slot) * 3, v3(dx / nn, dy / nn, -1.f / nn));
+            }
+        }
+    }
+    if (B.link_contact_states && live) {   // genesis_simulator.py:53-55
+        const unsigned mask = M->state_link_mask;
+        const int l0 = foot_link - 3, nst = __popc(mask);
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            const float fn = sqrtf(dot3(f_link[k], f_link[k]));
+            const int l = l0 + k;
+            if (L.is0 && ((mask >> l) & 1u)) B.link_contact_states[(size_t)e * nst + __popc(mask & ((1u << l) - 1u))] = fn > 1.f ? 1.f : 0.f;
+        }
+        const float fb = sqrtf(dot3(f_base, f_base));
+        if (L.is0 && leg == 0 && (mask & 1u)) B.link_contact_states[(size_t)e * nst] = fb > 1.f ? 1.f : 0.f;
+    }
+}

@@ -95,6 +95,7 @@ typedef struct LgSimOptions {
     /* height sampling grid around the base (genesis_simulator.py:496-507,552-577) */
     int32_t n_height_points;   /* 0 = measure_heights off */
     int32_t feet_terrain_info; /* cfg.terrain.obtain_terrain_info_around_feet */
+    int32_t sim_layout;        /* physics kernel layout: 0 auto (by batch size), 1 one leg per lane, 2 one vector component per lane */
 } LgSimOptions;
 
 /* ---- reward term ids, in the alphabetical order the reference evaluates them

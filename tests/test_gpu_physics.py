@@ -17,13 +17,19 @@ TOL = dict(base_pos=2e-5, base_quat=2e-5, base_lin_vel_w=2e-3, base_ang_vel_w=1e
            last_base_lin_vel=0, last_base_ang_vel=0)
 
 
-@pytest.fixture(scope="module")
-def engine(go2):
-    import torch
+LAYOUTS = [pytest.param(1, id="leg-per-lane"), pytest.param(2, id="component-per-lane")]
+
+
+@pytest.fixture(scope="module", params=LAYOUTS)
+def engine(go2, request):
+    """Both physics kernels (LgSimOptions.sim_layout): one leg per lane, one vector component per lane."""
+    import copy, torch
     from hcr_genesis_lr_cl_amd import builders
     from hcr_genesis_lr_cl_amd.engine import Engine
     task = builders.make_task_cfg(go2["model"], go2["cfg"])
-    return Engine(go2["model"], go2["desc"], go2["opts"], task, 512, "cuda:0")
+    opts = copy.copy(go2["opts"])
+    opts.sim_layout = request.param
+    return Engine(go2["model"], go2["desc"], opts, task, 512, "cuda:0")
 
 
 def _run_both(go2, engine, seed, steps=1, airborne_frac=0.3, z_offset=0.0):
@@ -62,12 +68,14 @@ def test_free_flight_matches_oracle_tightly(go2, engine):
     assert np.abs(got["link_contact_forces"]).max() == 0.0
 
 
-def test_static_stance_on_gpu(go2):
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_static_stance_on_gpu(go2, layout):
     """The kernel alone (no oracle): stiff stance settles with sum Fz = m g on the feet."""
     import copy, torch
     from hcr_genesis_lr_cl_amd import abi, builders, config as cfgmod
     from hcr_genesis_lr_cl_amd.engine import Engine
     opts = copy.copy(go2["opts"])
+    opts.sim_layout = layout
     for k in range(12):
         opts.kp[k] = 80.0; opts.kd[k] = 1.0
     task = builders.make_task_cfg(go2["model"], go2["cfg"])
@@ -101,7 +109,7 @@ def test_extreme_actions_stay_finite(go2, engine):
 
 
 # ---- the other robot / terrain combinations of the BASELINE configs -------------------------------
-def _setup(robot, rough):
+def _setup(robot, rough, layout):
     import torch
     from hcr_genesis_lr_cl_amd import builders
     from hcr_genesis_lr_cl_amd.config import GO2EECfg, TRON1PFEECfg, GO2Cfg
@@ -109,6 +117,7 @@ def _setup(robot, rough):
     from hcr_genesis_lr_cl_amd.model_compiler import load_model
     from hcr_genesis_lr_cl_amd.terrain import Terrain
     cfg = {"go2": GO2EECfg if rough else GO2Cfg, "tron1_pf": TRON1PFEECfg}[robot]()
+    cfg.hip.sim_layout = layout
     if not rough:
         cfg.terrain.mesh_type, cfg.terrain.measure_heights, cfg.terrain.curriculum = "plane", False, False
         cfg.terrain.obtain_terrain_info_around_feet = False
@@ -126,15 +135,16 @@ def _setup(robot, rough):
     return model, cfg, desc, opts, eng, terrain
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
 @pytest.mark.parametrize("robot,rough", [("tron1_pf", False), ("go2", True), ("tron1_pf", True)])
-def test_one_control_step_matches_oracle_other_configs(robot, rough):
+def test_one_control_step_matches_oracle_other_configs(robot, rough, layout):
     """TRON1 exercises the 2-lanes-per-env instantiation, joint_rot/armature/damping tables; `rough` the
     heightfield contact (bilinear height + gradient normal) on stairs / slopes / obstacles."""
     import torch
     from hcr_genesis_lr_cl_amd import abi
     from oracle import oracle as orc
     from tests.util import random_sim_state, load_state_into_engine, engine_arrays
-    model, cfg, desc, opts, eng, terrain = _setup(robot, rough)
+    model, cfg, desc, opts, eng, terrain = _setup(robot, rough, layout)
     st, actions = random_sim_state(model, cfg, eng.n, 4)
     if rough:   # scatter the robots over the tiles and drop them onto the local ground
         rng = np.random.default_rng(8)
