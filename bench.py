@@ -75,6 +75,7 @@ def main():
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step RCCL all-gather at N>1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--kernel-timer-stride", type=int, default=8, help="time the physics kernel of every n-th step (0 = off)")
     args = ap.parse_args()
 
     import torch
@@ -114,6 +115,8 @@ def main():
 
     for i in range(args.warmup):
         one_step(i)
+    # roofline: the dominant kernel (physics) of every 8th step is bracketed by HIP events on the launch stream
+    env._engine.profile(args.kernel_timer_stride)
     if dist is not None:
         dist.barrier()
     torch.cuda.synchronize()
@@ -135,8 +138,11 @@ def main():
     if rank == 0:
         total_envs = n_local * world
         value = total_envs * args.steps / elapsed
-        launch_s = dev_ms / 1e3 / args.steps
+        kern_us, kern_n = env._engine.profile_read()
+        launch_s = kern_us * 1e-6 if kern_n else dev_ms / 1e3 / args.steps
         achieved = BYTES_PER_ENV_STEP * n_local / launch_s / 1e9
+        layout = "component-per-lane (quad_sim_kernel<4,PRE>) + env_step_kernel<4,POST|RESET>" if n_local * 16 <= 1024 * 64 \
+            else "leg-per-lane (env_step_kernel<4,ALL>)"
         out = {
             "metric": "env-steps/sec, Go2 flat 12-DOF, 4096 envs @1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -147,7 +153,8 @@ def main():
                        "envs_total": total_envs, "parallelism": f"env-shard x{world}" + (" + all-gather(obs,rew,done)" if world > 1 and not args.no_gather else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": hbm_traffic(f"go2_flat_{n_local}"),
-                         "kernel": "env_step_kernel<4,ALL>", "launch_us": launch_s * 1e6,
+                         "kernel": "physics launch of: " + layout, "launch_us": launch_s * 1e6, "samples": kern_n,
+                         "step_device_us": dev_ms * 1e3 / args.steps,
                          "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n_local},
         }
         if world == 1 and not args.no_cpu_baseline:

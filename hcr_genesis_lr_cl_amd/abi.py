@@ -207,16 +207,19 @@ def load_lib():
     lib.lg_bind.argtypes = [H, C.POINTER(LgBuffers)]
     lib.lg_step.argtypes = [H, u32, C.c_void_p, i64, C.c_void_p]
     lib.lg_time_steps.argtypes = [H, C.c_void_p, i64, i32, C.c_void_p, C.POINTER(C.c_float)]
+    lib.lg_profile.argtypes = [H, i32]
+    lib.lg_profile_read.argtypes = [H, C.POINTER(C.c_float), C.POINTER(i32)]
     lib.lg_last_error.restype = C.c_char_p
     lib.lg_abi_version.restype = C.c_int
-    for f in ("lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step", "lg_time_steps"):
+    for f in ("lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step", "lg_time_steps", "lg_profile",
+              "lg_profile_read"):
         getattr(lib, f).restype = C.c_int
     _LIB = lib
     return lib
 
 
 EXPORTS = ["lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step",
-           "lg_time_steps", "lg_last_error", "lg_abi_version"]
+           "lg_time_steps", "lg_profile", "lg_profile_read", "lg_last_error", "lg_abi_version"]
 
 
 def check(rc, lib=None):

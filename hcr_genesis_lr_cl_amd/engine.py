@@ -132,6 +132,15 @@ class Engine:
                                          C.byref(ms)), self.lib)
         return ms.value
 
+    def profile(self, stride):
+        """Time the physics kernel of every `stride`-th step with HIP events (0 = off)."""
+        abi.check(self.lib.lg_profile(self.handle, int(stride)), self.lib)
+
+    def profile_read(self):
+        us, n = C.c_float(), C.c_int32()
+        abi.check(self.lib.lg_profile_read(self.handle, C.byref(us), C.byref(n)), self.lib)
+        return us.value, n.value
+
     def close(self):
         if getattr(self, "handle", None):
             self.lib.lg_destroy(self.handle)

@@ -103,6 +103,7 @@ class LeggedRobot:
         self.extras = {}
         self._init_buffers()
         self._prepare_reward_function()
+        self._warm_rare_paths()
         self.init_done = True
 
     # ------------------------------------------------------------------------------------------
@@ -154,6 +155,19 @@ class LeggedRobot:
             r[0] = float(np.clip(r[0] - 0.5, -self.cfg.commands.max_curriculum, 0.))
             r[1] = float(np.clip(r[1] + 0.5, 0., self.cfg.commands.max_curriculum))
             self._upload_command_ranges()
+
+    def _warm_rare_paths(self):
+        """Touch, at construction, every torch op the command-curriculum gate uses (nonzero, gather, mean, compare,
+        host->device upload).  On ROCm the first use of each op loads its code object (~120 ms in total, measured);
+        left lazy that lands in the middle of a rollout, on the first gate step (1 step in 1000)."""
+        if not self.cfg.commands.curriculum:
+            return
+        ids = self.reset_buf.nonzero(as_tuple=False).flatten()
+        if len(ids) > 0:
+            k = abi.REWARD_ID["tracking_lin_vel"]
+            m = torch.mean(self._engine.buf["episode_sums"][k][ids]) / self.max_episode_length
+            bool(m > self.cfg.commands.curriculum_threshold)
+        self._upload_command_ranges()
 
     def _on_curriculum_gate(self, env_ids):
         """Task hook on command-curriculum gate steps (go2_wtw.py:119-122)."""

@@ -273,6 +273,12 @@ int lg_step(LgHandle h, uint32_t phases, const float *actions, int64_t common_st
 /* Timing helper for bench.py: enqueue `count` fused steps reusing `actions`, bracketed by
  * HIP events on `stream`; returns mean kernel-to-kernel milliseconds per step in *ms. */
 int lg_time_steps(LgHandle h, const float *actions, int64_t first_counter, int32_t count, void *stream, float *ms);
+/* Sampling timer for the roofline line of bench.py: with stride N > 0 every N-th lg_step that contains LG_PHASE_SIM
+ * brackets its physics kernel (the dominant launch) with a pair of HIP events on the caller's stream (at most 1024
+ * samples are kept); stride 0 switches it off.  lg_profile_read waits for the recorded events and returns the
+ * mean kernel duration in microseconds and the sample count, then clears the samples. */
+int lg_profile(LgHandle h, int32_t stride);
+int lg_profile_read(LgHandle h, float *mean_us, int32_t *samples);
 const char *lg_last_error(void);
 int lg_abi_version(void);
 

@@ -29,7 +29,7 @@ def timeit(ph, reps=200):
 
 
 snap = {k: v.clone() for k, v in eng.buf.items() if torch.is_tensor(v)}
-for name, ph in (("ALL", abi.PHASE_ALL), ("SIM", abi.PHASE_SIM), ("PRE|POST|RESET", abi.PHASE_PRE | abi.PHASE_POST | abi.PHASE_RESET),
+for name, ph in (("ALL", abi.PHASE_ALL), ("SIM", abi.PHASE_SIM), ("PRE|POST|RESET", abi.PHASE_PRE | abi.PHASE_POST | abi.PHASE_RESET), ("POST|RESET", abi.PHASE_POST | abi.PHASE_RESET),
                  ("PRE|SIM|POST", abi.PHASE_PRE | abi.PHASE_SIM | abi.PHASE_POST), ("RESET", abi.PHASE_RESET)):
     for k, v in snap.items():
         eng.buf[k].copy_(v)
