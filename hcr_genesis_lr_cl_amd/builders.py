@@ -217,4 +217,9 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
     t.episode_length_s = cfg.env.episode_length_s
     t.seed = int(cfg.hip.seed if seed is None else seed)
     t.env_id_offset = int(env_id_offset)
+    # history stacks: slide a window over rows with slack instead of moving the history every step (288 GB of HBM
+    # buys bandwidth: one new frame written per step, one compaction every `obs_history_slack` steps)
+    if t.obs_stack > 1 or t.priv_stack > 1:
+        slack = int(os.environ.get("LG_OBS_SLACK", getattr(cfg.hip, "obs_history_slack", 64)))   # env: tests / timing only
+        t.obs_slack = max(slack, int(t.obs_stack), int(t.priv_stack)) if slack > 0 else 0
     return t

@@ -45,6 +45,7 @@ struct LgHot {
     int32_t priv_frame;
     int32_t obs_stack;
     int32_t priv_stack;
+    int32_t obs_slack;
     float control_dt;
     float clip_actions;
     float clip_obs;
@@ -161,6 +162,7 @@ static void fill_hot(LgHot &H, const LgTaskCfg &t, const LgSimOptions &o, const 
     H.priv_frame = t.priv_frame;
     H.obs_stack = t.obs_stack;
     H.priv_stack = t.priv_stack;
+    H.obs_slack = t.obs_slack;
     H.control_dt = t.control_dt;
     H.clip_actions = t.clip_actions;
     H.clip_obs = t.clip_obs;
@@ -299,6 +301,7 @@ struct KParams {
     const float *actions;
     long long counter;
     int jrot_identity;   // every joint frame is axis-aligned with its parent at q = 0 (host-checked)
+    int obs_win;         // first frame of the observation window this launch writes (sliding history, LgTaskCfg.obs_slack)
 };
 
 #ifdef LG_DBG_STAMPS
@@ -434,6 +437,16 @@ LG_DEV float wrap_to_pi(float a) {
 }
 
 // ---------------------------------------------------------------------------------------------
+// sliding observation history ran out of slack: move the newest stack-1 frames of every row back to frames [1, stack)
+__global__ __launch_bounds__(256) void obs_compact_kernel(float *buf, int n_rows, int row, int frame, int stack, int from) {
+    const int per = (stack - 1) * frame;
+    const long long total = (long long)n_rows * per;
+    for (long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x; t < total; t += (long long)gridDim.x * blockDim.x) {
+        const int e = (int)(t / per), i = (int)(t % per);
+        buf[(size_t)e * row + frame + i] = buf[(size_t)e * row + (size_t)(from + 1) * frame + i];
+    }
+}
+
 template <int LEGS, unsigned PH>
 __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     constexpr bool DO_PRE = (PH & LG_PHASE_PRE) != 0, DO_SIM = (PH & LG_PHASE_SIM) != 0;
@@ -1577,10 +1590,18 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         //      go2_wtw.py:53-111 (61x5 | 99x5), go2_ee.py:10-75 (45x20 | 174x5 | 24 labels).  Histories are
         //      kept oldest -> newest inside obs_buf / priv_obs_buf themselves and shifted in place.
         const int FR = HOT(obs_frame), PF = HOT(priv_frame), ST = HOT(obs_stack), PST = HOT(priv_stack);
-        float *o = B.obs_buf + (size_t)e * HOT(num_obs);
-        float *pv = HOT(num_priv_obs) > 0 ? B.priv_obs_buf + (size_t)e * HOT(num_priv_obs) : nullptr;
+        const int SL = HOT(obs_slack);
+        float *o = B.obs_buf + (size_t)e * (HOT(num_obs) + SL * FR) + (size_t)p.obs_win * FR;
+        float *pv = HOT(num_priv_obs) > 0 ? B.priv_obs_buf + (size_t)e * (HOT(num_priv_obs) + SL * PF) + (size_t)p.obs_win * PF : nullptr;
         const float co = HOT(clip_obs);
-        if (live) {   // this lane's columns move one frame towards the past (zeros after a reset: go2_wtw.py:174-178)
+        if (live && SL > 0) {
+            // sliding window: the previous frames are already where this window expects them; only an env that was just
+            // reset blanks its history (go2_wtw.py:174-178)
+            if (reset) {
+                for (int i = leg; i < (ST - 1) * FR; i += LEGS) o[i] = 0.f;
+                if (pv) for (int i = leg; i < (PST - 1) * PF; i += LEGS) pv[i] = 0.f;
+            }
+        } else if (live) {   // this lane's columns move one frame towards the past (zeros after a reset)
             for (int f = 0; f + 1 < ST; f++)
                 for (int i = leg; i < FR; i += LEGS) o[f * FR + i] = reset ? 0.f : o[(f + 1) * FR + i];
             if (pv)
@@ -1801,6 +1822,7 @@ struct LgEngine {
     const int16_t *hf = nullptr;
     LgBuffers bufs; bool bound = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    int obs_win = 0;     // window of the latest stacked observation (obs_slack > 0)
     // bounded run-ahead: the host never gets more than ~128 lg_step calls ahead of the device (see lg_step)
     hipEvent_t ra_ev[4] = {nullptr, nullptr, nullptr, nullptr}; long long ra_calls = 0;
     // sampling timer of the physics kernel (lg_profile)
@@ -1853,6 +1875,8 @@ extern "C" int lg_create(const LgModelDesc *model, const LgSimOptions *opts, con
     if (validate_model(model)) return 1;
     if (!(opts->dt > 0.f) || opts->decimation < 1 || opts->decimation > 64) return fail("lg_create: bad dt/decimation");
     if (opts->contact_iters < 1 || opts->contact_iters > 16) return fail("lg_create: contact_iters must be in [1,16]");
+    if (task->obs_slack < 0 || (task->obs_slack > 0 && (task->obs_slack < task->obs_stack || task->obs_slack < task->priv_stack)))
+        return fail("lg_create: obs_slack must be 0 or at least as large as the history stacks");
     LgEngine *h = new LgEngine();
     h->model = *model; h->opts = *opts; h->task = *task;
     memset(&h->bufs, 0, sizeof(h->bufs));
@@ -1937,6 +1961,21 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
             if (h->model.jrot[b][k] != ((k % 4 == 0) ? 1.f : 0.f)) p.jrot_identity = 0;
     const int threads = h->bufs.n_envs * LEGS;
     dim3 grid((threads + BLOCK - 1) / BLOCK), block(BLOCK);
+    p.obs_win = 0;
+    if ((ph & LG_PHASE_RESET) && h->task.obs_slack > 0) {
+        // the observation written by this launch lives one frame further; out of slack -> compact first (source and
+        // destination ranges are disjoint because lg_create enforces slack >= stack)
+        const LgTaskCfg &t = h->task;
+        if (h->obs_win >= t.obs_slack) {
+            const int n = h->bufs.n_envs;
+            if (t.obs_stack > 1)
+                hipLaunchKernelGGL(obs_compact_kernel, dim3(1024), dim3(256), 0, st, h->bufs.obs_buf, n, (t.obs_stack + t.obs_slack) * t.obs_frame, t.obs_frame, t.obs_stack, h->obs_win);
+            if (t.num_priv_obs > 0 && t.priv_stack > 1)
+                hipLaunchKernelGGL(obs_compact_kernel, dim3(1024), dim3(256), 0, st, h->bufs.priv_obs_buf, n, (t.priv_stack + t.obs_slack) * t.priv_frame, t.priv_frame, t.priv_stack, h->obs_win);
+            h->obs_win = 0;
+        }
+        p.obs_win = ++h->obs_win;
+    }
     // physics layout (lg_quad.h): one vector component per lane while the batch cannot fill the SIMDs with one leg per
     // lane; the MDP phases then follow in a second launch on the same stream
     // auto: component-per-lane while that needs at most one wave per SIMD (1024 SIMDs); measured go2 crossover: 42 vs 58 us
@@ -2009,6 +2048,12 @@ extern "C" int lg_step(LgHandle h, uint32_t phases, const float *actions, int64_
         HIPCHK(hipEventRecord(h->ra_ev[slot], st));
     }
     return h->model.n_legs == 4 ? launch<4>(h, phases, actions, counter, st) : launch<2>(h, phases, actions, counter, st);
+}
+
+extern "C" int lg_obs_window(LgHandle h, int32_t *first_frame) {
+    if (!h || !first_frame) return fail("lg_obs_window: null argument");
+    *first_frame = h->task.obs_slack > 0 ? h->obs_win : 0;
+    return 0;
 }
 
 extern "C" int lg_profile(LgHandle h, int32_t stride) {

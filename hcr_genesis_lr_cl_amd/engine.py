@@ -54,6 +54,37 @@ def buffer_specs(A, L, F, K, P, num_obs, num_priv, num_labels, n_slots, hist, pr
     return s
 
 
+class _Buffers(dict):
+    """name -> device tensor.  History-stacked observations live in rows with slack frames and are exposed as the
+    window of the most recent step (LgTaskCfg.obs_slack, lg_obs_window): `buf["obs_buf"]` is that (N, stack*frame)
+    strided view, `buf.raw("obs_buf")` the whole allocation the C ABI is bound to."""
+
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.windows = {}     # name -> (frame width, stack)
+        self.first_frame = lambda: 0
+
+    def raw(self, k):
+        return dict.__getitem__(self, k)
+
+    def __getitem__(self, k):
+        t = dict.__getitem__(self, k)
+        w = self.windows.get(k)
+        if w is None:
+            return t
+        off = self.first_frame() * w[0]
+        return t[:, off:off + w[0] * w[1]]
+
+    def get(self, k, default=None):
+        return self[k] if k in self else default
+
+    def items(self):
+        return [(k, self[k]) for k in self.keys()]
+
+    def values(self):
+        return [self[k] for k in self.keys()]
+
+
 class Engine:
     def __init__(self, model, desc, opts, task, n_envs, device="cuda:0", inject_rand=False):
         if not torch.cuda.is_available():
@@ -70,8 +101,18 @@ class Engine:
         phist = (task.priv_stack, task.priv_frame) if task.priv_stack > 1 else None
         specs = buffer_specs(A, L, F, K, P, task.num_obs, task.num_priv_obs, int(task.num_labels), task.slots.n_slots,
                              None, None, int(task.task_state_width))
-        self.buf = {k: torch.zeros((self.n,) + tuple(shape), dtype=dt, device=self.device)
-                    for k, (shape, dt) in specs.items()}
+        SL = int(task.obs_slack)
+        if SL:   # rows of (stack + slack) frames; the observation is a sliding window over them
+            specs["obs_buf"] = (((task.obs_stack + SL) * task.obs_frame,), torch.float32)
+            if task.num_priv_obs:
+                specs["priv_obs_buf"] = (((task.priv_stack + SL) * task.priv_frame,), torch.float32)
+        self.buf = _Buffers({k: torch.zeros((self.n,) + tuple(shape), dtype=dt, device=self.device)
+                             for k, (shape, dt) in specs.items()})
+        if SL:
+            self.buf.windows["obs_buf"] = (int(task.obs_frame), int(task.obs_stack))
+            if task.num_priv_obs:
+                self.buf.windows["priv_obs_buf"] = (int(task.priv_frame), int(task.priv_stack))
+            self.buf.first_frame = self.obs_window
         self.buf["episode_sums"] = torch.zeros((abi.R_COUNT, self.n), device=self.device)
         self.buf["episode_done_sums"] = torch.zeros((abi.R_COUNT, self.n), device=self.device)
         self.buf["episode_done_step"] = torch.full((self.n,), -1, dtype=torch.int32, device=self.device)
@@ -92,7 +133,7 @@ class Engine:
         lb = abi.LgBuffers()
         lb.n_envs = self.n
         for name in abi.BUFFER_NAMES:
-            t = self.buf.get(name)
+            t = self.buf.raw(name) if name in self.buf else None
             if t is not None:
                 assert t.is_contiguous()
                 setattr(lb, name, t.data_ptr())
@@ -131,6 +172,12 @@ class Engine:
         abi.check(self.lib.lg_time_steps(self.handle, actions.data_ptr(), int(first_counter), int(count), stream,
                                          C.byref(ms)), self.lib)
         return ms.value
+
+    def obs_window(self):
+        """First frame of the window holding the latest stacked observation (0 without history slack)."""
+        w = C.c_int32()
+        abi.check(self.lib.lg_obs_window(self.handle, C.byref(w)), self.lib)
+        return w.value
 
     def profile(self, stride):
         """Time the physics kernel of every `stride`-th step with HIP events (0 = off)."""

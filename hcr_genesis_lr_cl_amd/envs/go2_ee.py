@@ -18,8 +18,11 @@ class LeggedRobotEE(LeggedRobot):
     def _init_buffers(self):
         super()._init_buffers()
         b = self._engine.buf
-        self.estimator_features_buf = b["obs_buf"]
         self.estimator_labels_buf = b["labels_buf"]
+
+    @property
+    def estimator_features_buf(self):
+        return self._engine.buf["obs_buf"]
 
     def step(self, actions):
         _, priv, rew, done, extras = super().step(actions)

@@ -94,17 +94,25 @@ class LeggedRobot:
         self._engine = self.simulator._engine
         b = self._engine.buf
         # base_task.py:29-37
-        self.obs_buf, self.rew_buf = b["obs_buf"], b["rew_buf"]
+        self.rew_buf = b["rew_buf"]
         self.reset_buf = b["reset_buf"].view(torch.bool)
         self.time_out_buf = b["time_out_buf"].view(torch.bool)
         self.episode_length_buf = b["episode_length_buf"]
-        self.privileged_obs_buf = b.get("priv_obs_buf")
         self.reset_buf.fill_(True)
         self.extras = {}
         self._init_buffers()
         self._prepare_reward_function()
         self._warm_rare_paths()
         self.init_done = True
+
+    # history-stacked observations are windows that move one frame per step (engine._Buffers): look them up per access
+    @property
+    def obs_buf(self):
+        return self._engine.buf["obs_buf"]
+
+    @property
+    def privileged_obs_buf(self):
+        return self._engine.buf.get("priv_obs_buf")
 
     # ------------------------------------------------------------------------------------------
     def step(self, actions):

@@ -154,6 +154,9 @@ typedef struct LgTaskCfg {
     int32_t num_obs, num_priv_obs;   /* total widths written per env (0 = none) */
     int32_t obs_frame, priv_frame;   /* single-frame widths */
     int32_t obs_stack, priv_stack;   /* history lengths */
+    int32_t obs_slack;               /* history stacks only: extra frames per row; the stacked observation is a window that
+                                      * slides one frame per step over rows of (stack + slack) frames (lg_obs_window), so a
+                                      * step writes one frame instead of moving the whole history; 0 = shift in place */
     float control_dt;                /* dt * decimation */
     float clip_actions, clip_obs;
     float max_episode_length;        /* ceil(episode_length_s / dt) as float (legged_robot.py:446) */
@@ -277,6 +280,10 @@ int lg_time_steps(LgHandle h, const float *actions, int64_t first_counter, int32
  * brackets its physics kernel (the dominant launch) with a pair of HIP events on the caller's stream (at most 1024
  * samples are kept); stride 0 switches it off.  lg_profile_read waits for the recorded events and returns the
  * mean kernel duration in microseconds and the sample count, then clears the samples. */
+/* First frame of the window that holds the most recent stacked observation: row e of obs_buf starts at
+ * obs_buf + e * (obs_stack + obs_slack) * obs_frame + *first_frame * obs_frame (same frame index for priv_obs_buf
+ * with its own stack / frame widths).  Always 0 when obs_slack == 0. */
+int lg_obs_window(LgHandle h, int32_t *first_frame);
 int lg_profile(LgHandle h, int32_t stride);
 int lg_profile_read(LgHandle h, float *mean_us, int32_t *samples);
 const char *lg_last_error(void);

@@ -11,6 +11,13 @@ from oracle import mdp_oracle as mo
 
 pytestmark = pytest.mark.gpu
 
+
+@pytest.fixture(autouse=True, params=["64", "1", "0"], ids=["history-window", "history-window-min-slack", "history-shift"])
+def history_mode(request, monkeypatch):
+    """Stacked observations three ways: sliding window with the default slack, with the smallest legal slack (a
+    compaction every `stack` steps), and the in-place shift."""
+    monkeypatch.setenv("LG_OBS_SLACK", request.param)
+
 SIM_KEYS = ("base_pos", "base_quat", "base_lin_vel_w", "base_ang_vel_w", "dof_pos", "dof_vel", "torques",
             "link_contact_forces", "feet_pos", "feet_vel", "last_dof_vel", "last_feet_vel")
 
