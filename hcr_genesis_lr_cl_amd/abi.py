@@ -210,6 +210,8 @@ def load_lib():
     lib.lg_obs_window.argtypes = [H, C.POINTER(i32)]
     lib.lg_profile.argtypes = [H, i32]
     lib.lg_profile_read.argtypes = [H, C.POINTER(C.c_float), C.POINTER(i32)]
+    lib.lg_philox.argtypes = [C.POINTER(u32 * 4), C.POINTER(u32 * 2), C.POINTER(u32 * 4)]
+    lib.lg_philox.restype = C.c_int
     lib.lg_last_error.restype = C.c_char_p
     lib.lg_abi_version.restype = C.c_int
     for f in ("lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step", "lg_time_steps", "lg_obs_window", "lg_profile",
@@ -220,7 +222,7 @@ def load_lib():
 
 
 EXPORTS = ["lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step",
-           "lg_time_steps", "lg_obs_window", "lg_profile", "lg_profile_read", "lg_last_error", "lg_abi_version"]
+           "lg_time_steps", "lg_obs_window", "lg_profile", "lg_profile_read", "lg_philox", "lg_last_error", "lg_abi_version"]
 
 
 def check(rc, lib=None):

@@ -46,6 +46,7 @@ struct LgHot {
     int32_t obs_stack;
     int32_t priv_stack;
     int32_t obs_slack;
+    int32_t reward_mask;   // bit k: reward term k has a non-zero scale (one scalar test per term instead of an LDS round trip)
     float control_dt;
     float clip_actions;
     float clip_obs;
@@ -163,6 +164,8 @@ static void fill_hot(LgHot &H, const LgTaskCfg &t, const LgSimOptions &o, const 
     H.obs_stack = t.obs_stack;
     H.priv_stack = t.priv_stack;
     H.obs_slack = t.obs_slack;
+    H.reward_mask = 0;
+    for (int i = 0; i < LG_R_COUNT; i++) if (t.reward_scales[i] != 0.f) H.reward_mask |= (int32_t)(1u << i);
     H.control_dt = t.control_dt;
     H.clip_actions = t.clip_actions;
     H.clip_obs = t.clip_obs;
@@ -266,6 +269,7 @@ static void fill_hot(LgHot &H, const LgTaskCfg &t, const LgSimOptions &o, const 
     for (int i = 0; i < 2; i++) H.o_bound_y[i] = o.bound_y[i];
 }
 
+static_assert(LG_R_COUNT <= 32, "reward mask is one dword");
 static_assert(sizeof(LgHot) <= 256 * 4, "hot block must fit four dwords per lane");
 template <typename T> struct HotGet;
 template <> struct HotGet<float> { static LG_DEV float get(int v0, int v1, int v2, int v3, int i) {
@@ -290,6 +294,9 @@ template <> struct HotLds<long long> { static LG_DEV long long get(const int *s,
 #define CR(k) (__int_as_float(sHot[256 + (k)]))
 #define HOT0(f) (HotGet<HOT_T(f)>::get(hv0, hv1, hv2, hv3, HOT_OFF(f)))   // prologue only (full exec, fresh registers)
 #define HOT(f) (HotLds<HOT_T(f)>::get(sHot, HOT_OFF(f)))
+// prologue accessor of env_step_body: lane registers in a stand-alone launch, LDS when fused behind the physics kernel
+#define HOTB(f) (FUSED ? HOT(f) : HOT0(f))
+#define RON(id) ((rmask >> (id)) & 1u)   // reward term `id` active (rmask: scalar copy of LgHot.reward_mask)
 
 struct KParams {
     const LgModelDesc *M;
@@ -425,6 +432,11 @@ struct RandSrc {
         U4 r = philox4x32_10(ctr, k0, k1);
         a = u01(r.x); b = u01(r.y); c = u01(r.z);
     }
+    LG_DEV void block4(int id, float &a, float &b, float &c, float &d) const {
+        U4 ctr = {e_lo, e_hi, step, 0x80000000u + (unsigned)id};
+        U4 r = philox4x32_10(ctr, k0, k1);
+        a = u01(r.x); b = u01(r.y); c = u01(r.z); d = u01(r.w);
+    }
 };
 
 // math_utils.py:50-53 as TorchScript executes it: `angles %= 2*pi` lowers to aten::fmod_
@@ -447,8 +459,11 @@ __global__ __launch_bounds__(256) void obs_compact_kernel(float *buf, int n_rows
     }
 }
 
-template <int LEGS, unsigned PH>
-__global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
+// The body of the leg-per-lane step.  FUSED = called from the tail of quad_sim_kernel (lg_quad.h) by the first 16 lanes of
+// the wave, one per leg of the wave's envs: the model table, the hot constants and the command ranges are already in
+// LDS, `vtid` is the leg-lane index and nothing is staged here.
+template <int LEGS, unsigned PH, bool FUSED>
+LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, const int vtid, const int vlane) {
     constexpr bool DO_PRE = (PH & LG_PHASE_PRE) != 0, DO_SIM = (PH & LG_PHASE_SIM) != 0;
     constexpr bool DO_POST = (PH & LG_PHASE_POST) != 0, DO_RESET = (PH & LG_PHASE_RESET) != 0;
     constexpr int A = LEGS * 3;
@@ -457,9 +472,8 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     unsigned long long _stamp0 = 0; (void)_stamp0;
     STAMP(0);
     // model table: device copy and LDS image are padded to MODEL_STG * BLOCK uint4 so the staging needs no predicate
-    __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_STG * BLOCK];
-    uint4 stg0, stg1, stg2, stg3;
-    {   // global -> registers now (same batch as every other start-of-kernel load); registers -> LDS after the barrier
+    uint4 stg0 = {0, 0, 0, 0}, stg1 = stg0, stg2 = stg0, stg3 = stg0;
+    if (!FUSED) {   // global -> registers now (same batch as every other start-of-kernel load); registers -> LDS after the barrier
         const uint4 *src = reinterpret_cast<const uint4 *>(p.M) + threadIdx.x;
         stg0 = src[0]; stg1 = src[BLOCK]; stg2 = src[2 * BLOCK]; stg3 = src[3 * BLOCK];
     }
@@ -468,32 +482,31 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     const LgTaskCfg *__restrict__ T = p.T;
     // hot constants: lane i of hv[k] holds dword 64*k + i of the LgHot block (three coalesced loads, one wait);
     // a field is then one v_readlane with a constant lane -- no scalar-cache round trips, no SGPR pressure
-    __shared__ int sHot[256 + BLOCK];
-    int hv0, hv1, hv2, hv3;
-    {
-        const int *hp = reinterpret_cast<const int *>(p.H) + (threadIdx.x & 63);
+    int hv0 = 0, hv1 = 0, hv2 = 0, hv3 = 0;
+    if (!FUSED) {
+        const int *hp = reinterpret_cast<const int *>(p.H) + vlane;
         hv0 = hp[0]; hv1 = hp[64]; hv2 = hp[128]; hv3 = hp[192];
     }
     const LgBuffers &B = p.B;
 
-    const int tid = blockIdx.x * BLOCK + threadIdx.x;
+    const int tid = vtid;
     const int leg = tid % LEGS;
     int e = tid / LEGS;
     const bool live = e < B.n_envs;
     if (!live) e = B.n_envs - 1;  // dead lanes shadow the last env (keeps DPP quads uniform), never store
     const bool lead = live && leg == 0;
-    const int L = HOT0(m_n_links), F = LEGS;
+    const int L = HOTB(m_n_links), F = LEGS;
     const int b0 = 1 + 3 * leg;            // first body of this lane's chain
     const int d0 = 3 * leg;                // first dof
-    const int foot_link = leg == 0 ? HOT0(m_foot_link[0]) : (leg == 1 ? HOT0(m_foot_link[1]) : (leg == 2 ? HOT0(m_foot_link[2]) : HOT0(m_foot_link[3])));
+    const int foot_link = leg == 0 ? HOTB(m_foot_link[0]) : (leg == 1 ? HOTB(m_foot_link[1]) : (leg == 2 ? HOTB(m_foot_link[2]) : HOTB(m_foot_link[3])));
     int foot_slot = 0;                     // rank of this foot among feet in link order (feet_indices)
 #pragma unroll
-    for (int k = 0; k < LEGS; k++) foot_slot += (HOT0(m_foot_link[k]) < foot_link) ? 1 : 0;
+    for (int k = 0; k < LEGS; k++) foot_slot += (HOTB(m_foot_link[k]) < foot_link) ? 1 : 0;
 
     // ---------------- PRE: clip + action history (legged_robot.py:230-239) -----------------
     float act[3], last_act[3], llast_act[3];
     if (DO_PRE) {
-        const float ca = HOT0(clip_actions);
+        const float ca = HOTB(clip_actions);
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             float prev = B.actions[e * A + d0 + j], prev2 = B.last_actions[e * A + d0 + j];
@@ -523,6 +536,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     // ---- MDP working set, fetched NOW so that the round trips overlap the physics below instead of being
     //      exposed one by one behind it (a lone wave per SIMD has nothing else to switch to) -----------------
     constexpr bool DO_MDP = DO_POST || DO_RESET;
+    const unsigned rmask0 = (unsigned)HOTB(reward_mask), rmask = rmask0;   // scalar for the whole kernel
     const int N = B.n_envs;
     float q0l[3], soft_lo[3] = {0.f, 0.f, 0.f}, soft_hi[3] = {0.f, 0.f, 0.f}, rdof_lo[3] = {0.f, 0.f, 0.f}, rdof_span[3] = {0.f, 0.f, 0.f};
     float nv_q[3] = {0.f, 0.f, 0.f}, nv_qd[3] = {0.f, 0.f, 0.f}, nv_act[3] = {0.f, 0.f, 0.f}, nv_clk[2] = {0.f, 0.f};
@@ -560,17 +574,17 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             rdof_lo[j] = T->reset_dof_lo[d0 + j]; rdof_span[j] = T->reset_dof_span[d0 + j];
             nv_q[j] = T->noise_vec[9 + d0 + j]; nv_qd[j] = T->noise_vec[9 + A + d0 + j]; nv_act[j] = T->noise_vec[9 + 2 * A + d0 + j];
         }
-        if (HOT0(obs_layout) == LG_OBS_TRON1_EE) { nv_clk[0] = T->noise_vec[9 + 3 * A + foot_slot]; nv_clk[1] = T->noise_vec[9 + 3 * A + LEGS + foot_slot]; }
+        if (HOTB(obs_layout) == LG_OBS_TRON1_EE) { nv_clk[0] = T->noise_vec[9 + 3 * A + foot_slot]; nv_clk[1] = T->noise_vec[9 + 3 * A + LEGS + foot_slot]; }
         cmd0 = B.commands[4 * e]; cmd1 = B.commands[4 * e + 1]; cmd2 = B.commands[4 * e + 2]; cmd3 = B.commands[4 * e + 3];
         ep_len = B.episode_length_buf[e];
         fail_buf = B.fail_buf[e];
         air = B.feet_air_time[e * F + foot_slot];
         last_contact = B.last_contacts[e * F + foot_slot];
         origin_pre = ld3(B.env_origins + 3 * e);
-        crv = reinterpret_cast<const int *>(B.command_ranges)[min((int)(threadIdx.x & 63), LG_CMD_RANGE_FLOATS - 1)];
+        if (!FUSED) crv = reinterpret_cast<const int *>(B.command_ranges)[min(vlane, LG_CMD_RANGE_FLOATS - 1)];
         if (lead) {
 #pragma unroll
-            for (int k = 0; k < LG_R_COUNT; k++) es[k] = HOT0(reward_scales[k]) != 0.f ? B.episode_sums[(size_t)k * N + e] : 0.f;
+            for (int k = 0; k < LG_R_COUNT; k++) es[k] = ((rmask0 >> k) & 1u) ? B.episode_sums[(size_t)k * N + e] : 0.f;
         }
     }
 
@@ -582,13 +596,15 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     V3 foot_p, foot_v, last_foot_v = v3(0, 0, 0);
     float foot_hmean = 0.f, foot_hmax = 0.f;  // mean / max of the 9 terrain heights around this lane's foot (a8)
     float mean_height = 0.f;         // mean over the height-sample grid of (base_z - h) is formed from this (a7)
-    const int P = HOT0(o_n_height_points);
+    const int P = HOTB(o_n_height_points);
 
     // compiler-level memory barrier: every load above is issued before anything below (LLVM otherwise sinks each one
     // next to its consumer, where its full round trip is exposed); no hardware wait is emitted here
     asm volatile("" ::: "memory");
-    sHot[threadIdx.x] = hv0; sHot[threadIdx.x + 64] = hv1; sHot[threadIdx.x + 128] = hv2; sHot[threadIdx.x + 192] = hv3; sHot[threadIdx.x + 256] = crv;
-    sMraw[threadIdx.x] = stg0; sMraw[threadIdx.x + BLOCK] = stg1; sMraw[threadIdx.x + 2 * BLOCK] = stg2; sMraw[threadIdx.x + 3 * BLOCK] = stg3;
+    if (!FUSED) {
+        sHot[threadIdx.x] = hv0; sHot[threadIdx.x + 64] = hv1; sHot[threadIdx.x + 128] = hv2; sHot[threadIdx.x + 192] = hv3; sHot[threadIdx.x + 256] = crv;
+        sMraw[threadIdx.x] = stg0; sMraw[threadIdx.x + BLOCK] = stg1; sMraw[threadIdx.x + 2 * BLOCK] = stg2; sMraw[threadIdx.x + 3 * BLOCK] = stg3;
+    }
     // MDP working set -> LDS for the duration of the physics (it arrived in the same load burst; parking it here keeps
     // ~70 registers per lane free in the sub-step loop).  Layout [value][lane]: conflict-free.
     constexpr bool STASH = DO_MDP && DO_SIM;
@@ -1273,8 +1289,11 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         if (p.counter >= 0) { if (lead) B.rew_buf[e] = cmd2 + (float)fail_buf + (reset ? 1.f : 0.f); return; }
 #endif
         // ---- compute_reward (legged_robot.py:150-168), alphabetical order ----
+        float scl[LG_R_COUNT];   // one burst of broadcast LDS reads instead of one exposed round trip per active term
+#pragma unroll
+        for (int k = 0; k < LG_R_COUNT; k++) scl[k] = HOT(reward_scales[k]);
         auto add = [&](int id, float r) {
-            const float rew = r * HOT(reward_scales[id]);
+            const float rew = r * scl[id];
             total += rew;
             es[id] += rew;
         };
@@ -1293,26 +1312,26 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             expC = c_frc;
             return __expf(quad_sum<LEGS>(c_spd * norm(foot_v) + c_frc * norm(f_link[3])));
         };
-        if (HOT(reward_scales[LG_R_ACTION_RATE]) != 0.f) {                              // :495-497
+        if (RON(LG_R_ACTION_RATE)) {                              // :495-497
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) { const float d = last_act[j] - act[j]; s += d * d; }
             add(LG_R_ACTION_RATE, quad_sum<LEGS>(s));
         }
-        if (HOT(reward_scales[LG_R_ACTION_SMOOTHNESS]) != 0.f) {                        // :499-503
+        if (RON(LG_R_ACTION_SMOOTHNESS)) {                        // :499-503
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) { const float d = act[j] - 2.f * last_act[j] + llast_act[j]; s += d * d; }
             add(LG_R_ACTION_SMOOTHNESS, quad_sum<LEGS>(s));
         }
-        if (HOT(reward_scales[LG_R_ANG_VEL_XY]) != 0.f) add(LG_R_ANG_VEL_XY, bav.x * bav.x + bav.y * bav.y);   // :462-464
-        if (HOT(reward_scales[LG_R_BASE_HEIGHT]) != 0.f) {                              // :470-476
+        if (RON(LG_R_ANG_VEL_XY)) add(LG_R_ANG_VEL_XY, bav.x * bav.x + bav.y * bav.y);   // :462-464
+        if (RON(LG_R_BASE_HEIGHT)) {                              // :470-476
             // plane: measured_heights is the all-zero buffer of genesis_simulator.py:494 -> base z
             const float d = (P > 0 ? mean_height : pos.z) - HOT(base_height_target);
             add(LG_R_BASE_HEIGHT, d * d);
         }
-        if (HOT(reward_scales[LG_R_BIPED_PERIODIC_GAIT]) != 0.f) add(LG_R_BIPED_PERIODIC_GAIT, gait_reward());  // tron1_pf_ee.py:426-433
-        if (HOT(reward_scales[LG_R_COLLISION]) != 0.f) {                                // :505-512
+        if (RON(LG_R_BIPED_PERIODIC_GAIT)) add(LG_R_BIPED_PERIODIC_GAIT, gait_reward());  // tron1_pf_ee.py:426-433
+        if (RON(LG_R_COLLISION)) {                                // :505-512
             float s = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; k++)
@@ -1321,19 +1340,19 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             if (M->pen_link_mask & 1u) s += norm(f_base) > 0.1f ? 1.f : 0.f;
             add(LG_R_COLLISION, s);
         }
-        if (HOT(reward_scales[LG_R_DOF_ACC]) != 0.f) {                                  // :490-493
+        if (RON(LG_R_DOF_ACC)) {                                  // :490-493
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) { const float d = (last_qd[j] - qd[j]) / cdt; s += d * d; }
             add(LG_R_DOF_ACC, quad_sum<LEGS>(s));
         }
-        if (HOT(reward_scales[LG_R_DOF_CLOSE_TO_DEFAULT]) != 0.f) {                     // :571-573
+        if (RON(LG_R_DOF_CLOSE_TO_DEFAULT)) {                     // :571-573
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) s += dq0[j] * dq0[j];
             add(LG_R_DOF_CLOSE_TO_DEFAULT, quad_sum<LEGS>(s));
         }
-        if (HOT(reward_scales[LG_R_DOF_POS_LIMITS]) != 0.f) {                           // :518-522
+        if (RON(LG_R_DOF_POS_LIMITS)) {                           // :518-522
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) {
@@ -1342,31 +1361,31 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             }
             add(LG_R_DOF_POS_LIMITS, quad_sum<LEGS>(s));
         }
-        if (HOT(reward_scales[LG_R_DOF_POS_STAND_STILL]) != 0.f) {                      // :561-563
+        if (RON(LG_R_DOF_POS_STAND_STILL)) {                      // :561-563
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) s += dq0[j] * dq0[j];
             add(LG_R_DOF_POS_STAND_STILL, quad_sum<LEGS>(s) * (cmd_xyz < 0.1f ? 1.f : 0.f));
         }
-        if (HOT(reward_scales[LG_R_DOF_POWER]) != 0.f) {                                // :486-488
+        if (RON(LG_R_DOF_POWER)) {                                // :486-488
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) s += fabsf(torque[j] * qd[j]);
             add(LG_R_DOF_POWER, quad_sum<LEGS>(s));
         }
-        if (HOT(reward_scales[LG_R_DOF_VEL]) != 0.f) {                                  // :482-484
+        if (RON(LG_R_DOF_VEL)) {                                  // :482-484
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) s += qd[j] * qd[j];
             add(LG_R_DOF_VEL, quad_sum<LEGS>(s));
         }
-        if (HOT(reward_scales[LG_R_DOF_VEL_STAND_STILL]) != 0.f) {                      // :557-559
+        if (RON(LG_R_DOF_VEL_STAND_STILL)) {                      // :557-559
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) s += fabsf(qd[j]);
             add(LG_R_DOF_VEL_STAND_STILL, quad_sum<LEGS>(s) * (cmd_xyz < 0.1f ? 1.f : 0.f));
         }
-        if (HOT(reward_scales[LG_R_FEET_AIR_TIME]) != 0.f) {                            // :545-555 (stateful)
+        if (RON(LG_R_FEET_AIR_TIME)) {                            // :545-555 (stateful)
             const int contact = f_link[3].z > 1.0f ? 1 : 0;
             const int filt = contact | last_contact;
             last_contact = contact;
@@ -1377,21 +1396,21 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             air *= filt ? 0.f : 1.f;
             add(LG_R_FEET_AIR_TIME, r);
         }
-        if (HOT(reward_scales[LG_R_FEET_CONTACT_STAND_STILL]) != 0.f) {                 // :565-569
+        if (RON(LG_R_FEET_CONTACT_STAND_STILL)) {                 // :565-569
             const float cnt = quad_sum<LEGS>(f_link[3].z > 0.1f ? 1.f : 0.f);
             add(LG_R_FEET_CONTACT_STAND_STILL, (cnt == (float)LEGS ? 1.f : 0.f) * (cmd_xyz < 0.1f ? 1.f : 0.f));
         }
-        if (HOT(reward_scales[LG_R_FEET_DISTANCE]) != 0.f) {                            // tron1_pf_ee.py:458-463 (two feet: lane pair)
+        if (RON(LG_R_FEET_DISTANCE)) {                            // tron1_pf_ee.py:458-463 (two feet: lane pair)
             const float ox = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(foot_p.x), 0xB1, 0xF, 0xF, false));
             const float oy = __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(foot_p.y), 0xB1, 0xF, 0xF, false));
             const float dxy = sqrtf((foot_p.x - ox) * (foot_p.x - ox) + (foot_p.y - oy) * (foot_p.y - oy));
             add(LG_R_FEET_DISTANCE, fmaxf(0.f, HOT(foot_distance_threshold) - dxy));
         }
-        if (HOT(reward_scales[LG_R_FOOT_ACC]) != 0.f) {                                 // :605-608
+        if (RON(LG_R_FOOT_ACC)) {                                 // :605-608
             const V3 a = (foot_v - last_foot_v) * (1.f / cdt);
             add(LG_R_FOOT_ACC, quad_sum<LEGS>(dot(a, a)));
         }
-        if (HOT(reward_scales[LG_R_FOOT_CLEARANCE]) != 0.f) {                           // :575-588
+        if (RON(LG_R_FOOT_CLEARANCE)) {                           // :575-588
             const float vxy = sqrtf(foot_v.x * foot_v.x + foot_v.y * foot_v.y);
             // go2_ee.py:136-150 measures the clearance above the mean terrain height around the foot
             const float d = foot_p.z - (HOT(obs_layout) == LG_OBS_GO2_EE ? foot_hmean : (HOT(obs_layout) == LG_OBS_TRON1_EE ? foot_hmax : 0.f))
@@ -1399,42 +1418,42 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
             const float err = quad_sum<LEGS>(vxy * (d * d));
             add(LG_R_FOOT_CLEARANCE, __expf(-err / HOT(foot_clearance_sigma)));
         }
-        if (HOT(reward_scales[LG_R_FOOT_LANDING_VEL]) != 0.f) {                         // :590-599
+        if (RON(LG_R_FOOT_LANDING_VEL)) {                         // :590-599
             const bool c01 = f_link[3].z > 0.1f;
             const bool land = ((foot_p.z - HOT(foot_height_offset)) < HOT(about_landing_threshold)) && !c01 && (foot_v.z < 0.f);
             const float vz = land ? foot_v.z : 0.f;
             add(LG_R_FOOT_LANDING_VEL, quad_sum<LEGS>(vz * vz));
         }
-        if (HOT(reward_scales[LG_R_HIP_POS]) != 0.f) add(LG_R_HIP_POS, quad_sum<LEGS>(dq0[0] * dq0[0]));   // go2_ee.py:152-159
-        if (HOT(reward_scales[LG_R_KEEP_BALANCE]) != 0.f) add(LG_R_KEEP_BALANCE, 1.f);                      // :601-603
-        if (HOT(reward_scales[LG_R_LIN_VEL_Z]) != 0.f) add(LG_R_LIN_VEL_Z, blv.z * blv.z);                  // :458-460
-        if (HOT(reward_scales[LG_R_ORIENTATION]) != 0.f) add(LG_R_ORIENTATION, pg.x * pg.x + pg.y * pg.y);  // :466-468
-        if (HOT(reward_scales[LG_R_QUAD_PERIODIC_GAIT]) != 0.f) add(LG_R_QUAD_PERIODIC_GAIT, gait_reward());   // go2_wtw.py:472-484
-        if (HOT(reward_scales[LG_R_TORQUES]) != 0.f) {                                  // :478-480
+        if (RON(LG_R_HIP_POS)) add(LG_R_HIP_POS, quad_sum<LEGS>(dq0[0] * dq0[0]));   // go2_ee.py:152-159
+        if (RON(LG_R_KEEP_BALANCE)) add(LG_R_KEEP_BALANCE, 1.f);                      // :601-603
+        if (RON(LG_R_LIN_VEL_Z)) add(LG_R_LIN_VEL_Z, blv.z * blv.z);                  // :458-460
+        if (RON(LG_R_ORIENTATION)) add(LG_R_ORIENTATION, pg.x * pg.x + pg.y * pg.y);  // :466-468
+        if (RON(LG_R_QUAD_PERIODIC_GAIT)) add(LG_R_QUAD_PERIODIC_GAIT, gait_reward());   // go2_wtw.py:472-484
+        if (RON(LG_R_TORQUES)) {                                  // :478-480
             float s = 0.f;
 #pragma unroll
             for (int j = 0; j < 3; j++) s += torque[j] * torque[j];
             add(LG_R_TORQUES, quad_sum<LEGS>(s));
         }
-        if (HOT(reward_scales[LG_R_TRACKING_ANG_VEL]) != 0.f) {                         // :539-543
+        if (RON(LG_R_TRACKING_ANG_VEL)) {                         // :539-543
             const float d = cmd2 - bav.z;
             add(LG_R_TRACKING_ANG_VEL, __expf(-(d * d) / HOT(tracking_sigma)));
         }
-        if (HOT(reward_scales[LG_R_TRACKING_BASE_HEIGHT]) != 0.f) {                     // go2_wtw.py:495-500 (plane: heights are zero)
+        if (RON(LG_R_TRACKING_BASE_HEIGHT)) {                     // go2_wtw.py:495-500 (plane: heights are zero)
             // wtw: per-env target on the plane; tron1_pf_ee.py:435-440: fixed target, mean over the height samples
             const float d = WTW ? pos.z - bh_tgt : (P > 0 ? mean_height : pos.z) - HOT(base_height_target);
             add(LG_R_TRACKING_BASE_HEIGHT, __expf(-(d * d) / HOT(base_height_sigma)));
         }
-        if (HOT(reward_scales[LG_R_TRACKING_FOOT_CLEARANCE]) != 0.f) {                  // go2_wtw.py:507-519
+        if (RON(LG_R_TRACKING_FOOT_CLEARANCE)) {                  // go2_wtw.py:507-519
             const float vxy = sqrtf(foot_v.x * foot_v.x + foot_v.y * foot_v.y);
             const float d = foot_p.z - fc_tgt - HOT(foot_height_offset);
             add(LG_R_TRACKING_FOOT_CLEARANCE, __expf(-quad_sum<LEGS>(vxy * (d * d)) / HOT(foot_clearance_sigma)));
         }
-        if (HOT(reward_scales[LG_R_TRACKING_LIN_VEL]) != 0.f) {                         // :533-537
+        if (RON(LG_R_TRACKING_LIN_VEL)) {                         // :533-537
             const float dx = cmd0 - blv.x, dy = cmd1 - blv.y;
             add(LG_R_TRACKING_LIN_VEL, __expf(-(dx * dx + dy * dy) / HOT(tracking_sigma)));
         }
-        if (HOT(reward_scales[LG_R_TRACKING_ORIENTATION]) != 0.f) {                     // go2_wtw.py:502-505
+        if (RON(LG_R_TRACKING_ORIENTATION)) {                     // go2_wtw.py:502-505
             const float dp = eul.y - pitch_tgt;
             add(LG_R_TRACKING_ORIENTATION, __expf(-(eul.x * eul.x + dp * dp) / HOT(euler_sigma)));
         }
@@ -1443,7 +1462,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
 #endif
         STAMP(7);
         if (HOT(only_positive_rewards)) total = fmaxf(total, 0.f);        // :161-162
-        if (HOT(reward_scales[LG_R_TERMINATION]) != 0.f) add(LG_R_TERMINATION, (reset && !time_out) ? 1.f : 0.f);  // :163-168
+        if (RON(LG_R_TERMINATION)) add(LG_R_TERMINATION, (reset && !time_out) ? 1.f : 0.f);  // :163-168
         if (GAIT) {  // gait clock (go2_wtw.py:29-36, tron1_pf_ee.py:28-35).  The reference additionally restarts env 0's clock whenever
                      // ANY env wraps (index-flatten bug); that grid-wide coupling is deliberately not reproduced.
             gait_time += cdt;
@@ -1578,7 +1597,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                 // per reset on a shared accumulator: ~10 us per launch of same-line atomic latency.)
 #pragma unroll
                 for (int k = 0; k < LG_R_COUNT; k++) {
-                    if (HOT(reward_scales[k]) != 0.f) { B.episode_done_sums[(size_t)k * N + e] = es[k]; es[k] = 0.f; }
+                    if (RON(k)) { B.episode_done_sums[(size_t)k * N + e] = es[k]; es[k] = 0.f; }
                 }
                 B.episode_done_step[e] = (int)p.counter;
             }
@@ -1623,9 +1642,23 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
                     for (int k = 0; k < 6; k++) ub[k] = rs.in[ns + 3 + k];
                 }
             } else {
-                rs.block3(2 * leg, uq[0], uq[1], uq[2]);
-                rs.block3(2 * leg + 1, uqd[0], uqd[1], uqd[2]);
-                if (lead) { rs.block3(2 * LEGS, ub[0], ub[1], ub[2]); rs.block3(2 * LEGS + 1, ub[3], ub[4], ub[5]); }
+                // two Philox blocks per lane, all four outputs used: the fourth ones of the env's lanes are the base's
+                // six uniforms (a call is ~800 cycles and a lead-only call stalls the whole wave)
+                float sp0, sp1;
+                rs.block4(2 * leg, uq[0], uq[1], uq[2], sp0);
+                rs.block4(2 * leg + 1, uqd[0], uqd[1], uqd[2], sp1);
+                auto bcq = [](float v, int k) {   // lane k of the quad (the env's lanes), k compile-time after unrolling
+                    const int x = __float_as_int(v);
+                    return __int_as_float(k == 0 ? __builtin_amdgcn_update_dpp(0, x, 0x00, 0xF, 0xF, false)
+                                          : (k == 1 ? __builtin_amdgcn_update_dpp(0, x, 0x55, 0xF, 0xF, false)
+                                                    : __builtin_amdgcn_update_dpp(0, x, 0xAA, 0xF, 0xF, false)));
+                };
+                if (LEGS == 4) {
+                    ub[0] = bcq(sp0, 0); ub[1] = bcq(sp1, 0); ub[2] = bcq(sp0, 1); ub[3] = bcq(sp1, 1); ub[4] = bcq(sp0, 2); ub[5] = bcq(sp1, 2);
+                } else {   // two lanes per env: one more block, same id on both lanes of the pair (only the lead's copy is used)
+                    ub[0] = sp0; ub[1] = sp1;
+                    rs.block4(2 * LEGS, ub[2], ub[3], ub[4], ub[5]);
+                }
             }
         }
         float uact[3] = {0.5f, 0.5f, 0.5f}, uclk[2] = {0.5f, 0.5f};
@@ -1803,10 +1836,17 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
         if (DO_POST || (DO_RESET && reset)) {
 #pragma unroll
             for (int k = 0; k < LG_R_COUNT; k++)
-                if (HOT(reward_scales[k]) != 0.f) esum[(size_t)k * N + e] = es[k];
+                if (RON(k)) esum[(size_t)k * N + e] = es[k];
         }
     }
     STAMP(11);
+}
+
+template <int LEGS, unsigned PH>
+__global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
+    __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_STG * BLOCK];
+    __shared__ int sHot[256 + BLOCK];
+    env_step_body<LEGS, PH, false>(p, sMraw, sHot, blockIdx.x * BLOCK + threadIdx.x, threadIdx.x & 63);
 }
 
 #include "lg_quad.h"
@@ -1986,13 +2026,20 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
         const bool pre = (ph & LG_PHASE_PRE) != 0;
         if (!pre && !actions) p.actions = nullptr;
         const int pi = prof_begin(h, st);
-        if (pre) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true>), qgrid);
-        else LG_LAUNCH(pi, (quad_sim_kernel<LEGS, false>), qgrid);
-        HIPCHK(hipGetLastError());
         const uint32_t rest = ph & (LG_PHASE_POST | LG_PHASE_RESET);
-        if (rest == (LG_PHASE_POST | LG_PHASE_RESET)) hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET>), grid, block, 0, st, p);
-        else if (rest == LG_PHASE_POST) hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST>), grid, block, 0, st, p);
-        else if (rest) return fail("lg_step: unsupported phase combination");
+        // MDP phases: in the tail of the same launch for the quadruped (measured 39.5 vs 40.6 us for go2, 69.6 vs 72.5
+        // for go2_ee), as a second launch for the biped (84.7 vs 90.6 us for tron1_pf_ee: 8 envs per wave there)
+        const bool fuse = LEGS == 4 && pre && rest != 0;
+        if (fuse && rest == (LG_PHASE_POST | LG_PHASE_RESET)) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET>), qgrid);
+        else if (fuse && rest == LG_PHASE_POST) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST>), qgrid);
+        else if (pre) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, 0u>), qgrid);
+        else LG_LAUNCH(pi, (quad_sim_kernel<LEGS, false, 0u>), qgrid);
+        HIPCHK(hipGetLastError());
+        if (!fuse && rest) {
+            if (rest == (LG_PHASE_POST | LG_PHASE_RESET)) hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET>), grid, block, 0, st, p);
+            else if (rest == LG_PHASE_POST) hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST>), grid, block, 0, st, p);
+            else return fail("lg_step: unsupported phase combination");
+        }
         HIPCHK(hipGetLastError());
         return 0;
     }
@@ -2048,6 +2095,23 @@ extern "C" int lg_step(LgHandle h, uint32_t phases, const float *actions, int64_
         HIPCHK(hipEventRecord(h->ra_ev[slot], st));
     }
     return h->model.n_legs == 4 ? launch<4>(h, phases, actions, counter, st) : launch<2>(h, phases, actions, counter, st);
+}
+
+__global__ void philox_kat_kernel(U4 c, unsigned k0, unsigned k1, unsigned *out) {
+    const U4 r = philox4x32_10(c, k0, k1);
+    out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;
+}
+
+extern "C" int lg_philox(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]) {
+    if (!counter || !key || !out) return fail("lg_philox: null argument");
+    unsigned *d = nullptr;
+    HIPCHK(hipMalloc(&d, 16));
+    const U4 c = {counter[0], counter[1], counter[2], counter[3]};
+    hipLaunchKernelGGL(philox_kat_kernel, dim3(1), dim3(1), 0, 0, c, key[0], key[1], d);
+    hipError_t e = hipMemcpy(out, d, 16, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(std::string("lg_philox: ") + hipGetErrorString(e));
+    return 0;
 }
 
 extern "C" int lg_obs_window(LgHandle h, int32_t *first_frame) {

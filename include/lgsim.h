@@ -286,6 +286,8 @@ int lg_time_steps(LgHandle h, const float *actions, int64_t first_counter, int32
 int lg_obs_window(LgHandle h, int32_t *first_frame);
 int lg_profile(LgHandle h, int32_t stride);
 int lg_profile_read(LgHandle h, float *mean_us, int32_t *samples);
+/* Diagnostic: one Philox4x32-10 block computed on the device by the kernel's own generator (known-answer tests). */
+int lg_philox(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 const char *lg_last_error(void);
 int lg_abi_version(void);
 

@@ -108,3 +108,18 @@ def test_long_random_rollout_is_sane():
     assert float(s.dof_vel.abs().max()) <= 2 * 30.1 + 1e-3
     ep = extras["episode"]
     assert torch.isfinite(torch.as_tensor(float(ep["rew_tracking_lin_vel"])))
+
+
+def test_philox_known_answers():
+    """The kernel's generator against the Random123 known-answer vectors for Philox4x32-10 (kat_vectors: zero, all-ones
+    and the pi digits cases)."""
+    import ctypes as C
+    from hcr_genesis_lr_cl_amd import abi
+    lib = abi.load_lib()
+    kat = [((0, 0, 0, 0), (0, 0), (0x6627e8d5, 0xe169c58d, 0xbc57ac4c, 0x9b00dbd8)),
+           ((0xffffffff,) * 4, (0xffffffff,) * 2, (0x408f276d, 0x41c83b0e, 0xa20bc7c6, 0x6d5451fd)),
+           ((0x243f6a88, 0x85a308d3, 0x13198a2e, 0x03707344), (0xa4093822, 0x299f31d0), (0xd16cfe09, 0x94fdcceb, 0x5001e420, 0x24126ea1))]
+    for ctr, key, want in kat:
+        c, k, o = (C.c_uint32 * 4)(*ctr), (C.c_uint32 * 2)(*key), (C.c_uint32 * 4)()
+        abi.check(lib.lg_philox(C.byref(c), C.byref(k), C.byref(o)), lib)
+        assert tuple(o) == want, [hex(v) for v in o]

@@ -42,3 +42,12 @@ eng.buf["reset_buf"].zero_(); eng.buf["reset_buf"][::64] = 1
 print(f"{'RESET (64 resets)':16s} {timeit(abi.PHASE_RESET):8.1f} us", flush=True)
 eng.buf["reset_buf"].fill_(1)
 print(f"{'RESET (all reset)':16s} {timeit(abi.PHASE_RESET):8.1f} us", flush=True)
+# MDP launch on a quiet batch: no time-outs, no command resampling (episode counters restart), no failures pending
+for k, v in snap.items():
+    eng.buf[k].copy_(v)
+eng.buf["episode_length_buf"].fill_(1)
+eng.buf["fail_buf"].zero_()
+eng.buf["link_contact_forces"].zero_()
+eng.buf["projected_gravity"].copy_(torch.tensor([0.0, 0.0, -1.0], device="cuda").expand(n, 3))
+print(f"{'POST|RESET (quiet)':16s} {timeit(abi.PHASE_POST | abi.PHASE_RESET, 150):8.1f} us", flush=True)
+print("resets during the quiet run:", int(eng.buf["reset_buf"].sum()))
