@@ -25,6 +25,8 @@
 
 namespace q4 {
 
+LG_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32 (1 ulp) without the denormal-range rescue of sqrtf
+
 constexpr int QP(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
 template <int CTRL> LG_DEV float dpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
@@ -429,7 +431,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                     float fx = 0.f, fy = 0.f, fz = 0.f;
                     if (on && fn > 0.f) {
                         const float tx = vx - nx * vn, ty = vy - ny * vn, tz = vz - nz * vn;
-                        const float vtn = sqrtf(tx * tx + ty * ty + tz * tz);
+                        const float vtn = fsqrt(tx * tx + ty * ty + tz * tz);
                         const float ft = fminf(vtn * rcp(dt * wi), mu * fn);
                         const float g = vtn > 1e-9f ? ft * rcp(vtn) : 0.f;
                         fx = nx * fn - tx * g; fy = ny * fn - ty * g; fz = nz * fn - tz * g;
@@ -592,7 +594,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                     float f0 = sum3(x0 * rhs) * inv, f1 = sum3(x1 * rhs) * inv, f2 = sum3(x2 * rhs) * inv;
                     bool ok = fact && fabsf(det) >= 1e-30f && f0 > 0.f;
                     const float A00 = bc<0>(Ac.c0), A01 = bc<0>(Ac.c1), A02 = bc<0>(Ac.c2);   // DPP stays outside the branch
-                    const float ftn = sqrtf(f1 * f1 + f2 * f2);
+                    const float ftn = fsqrt(f1 * f1 + f2 * f2);
                     const float iftn = rcp(ftn), e1 = f1 * iftn, e2 = f2 * iftn;
                     const float fn = rn * rcp(1.f + kappa * (A00 + mu * (A01 * e1 + A02 * e2)));
                     if (ftn > mu * f0) { ok = ok && fn > 0.f; f0 = fn; f1 = mu * fn * e1; f2 = mu * fn * e2; }
@@ -631,7 +633,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             qd = clampf(qd + dt * (qdd + dqdd), -Lvlim, Lvlim);
             q += dt * qd;
             pos += vw * dt;
-            const float wn = sqrtf(bc<0>(dot3(ww, ww))), half = 0.5f * wn * dt;   // lane 3 (quaternion w) needs the true norm too
+            const float wn = fsqrt(bc<0>(dot3(ww, ww))), half = 0.5f * wn * dt;   // lane 3 (quaternion w) needs the true norm too
             float sh, chh;
             __sincosf(half, &sh, &chh);
             const float sc = wn > 1e-12f ? sh * rcp(wn) : 0.5f * dt;
@@ -725,7 +727,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     // ---------------- terrain sampling around the base and the feet (genesis_simulator.py:552-610) ------
     const int P = HOT(o_n_height_points);
     if (P > 0) {
-        const float yn = rcp(fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f));
+        const float yn = rcp(fmaxf(fsqrt(qz * qz + qw * qw), 1e-9f));
         const float yz = qz * yn, yw = qw * yn;
         const float px = bc<0>(pos), py = bc<1>(pos);
         for (int k = leg * 4 + L.c; k < P; k += 4 * LEGS) {
@@ -749,7 +751,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
 #pragma unroll
                 for (int k = 0; k < 9; k++) B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k] = (float)hh[k] * HOT(o_vscale);
                 const float dx = (float)(hh[1] - hh[0]) / (HOT(o_hscale) * 2.f), dy = (float)(hh[3] - hh[2]) / (HOT(o_hscale) * 2.f);
-                const float nn = sqrtf(dx * dx + dy * dy + 1.f);
+                const float nn = fsqrt(dx * dx + dy * dy + 1.f);
                 st3(B.normal_vector_around_feet + ((size_t)e * F + foot_slot) * 3, v3(dx / nn, dy / nn, -1.f / nn));
             }
         }
@@ -759,11 +761,11 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         const int l0 = foot_link - 3, nst = __popc(mask);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
-            const float fn = sqrtf(dot3(f_link[k], f_link[k]));
+            const float fn = fsqrt(dot3(f_link[k], f_link[k]));
             const int l = l0 + k;
             if (L.is0 && ((mask >> l) & 1u)) B.link_contact_states[(size_t)e * nst + __popc(mask & ((1u << l) - 1u))] = fn > 1.f ? 1.f : 0.f;
         }
-        const float fb = sqrtf(dot3(f_base, f_base));
+        const float fb = fsqrt(dot3(f_base, f_base));
         if (L.is0 && leg == 0 && (mask & 1u)) B.link_contact_states[(size_t)e * nst] = fb > 1.f ? 1.f : 0.f;
     }
 
