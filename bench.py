@@ -141,8 +141,8 @@ def main():
         kern_us, kern_n = env._engine.profile_read()
         launch_s = kern_us * 1e-6 if kern_n else dev_ms / 1e3 / args.steps
         achieved = BYTES_PER_ENV_STEP * n_local / launch_s / 1e9
-        layout = "component-per-lane (quad_sim_kernel<4,PRE>) + env_step_kernel<4,POST|RESET>" if n_local * 16 <= 1024 * 64 \
-            else "leg-per-lane (env_step_kernel<4,ALL>)"
+        layout = "quad_sim_kernel<4,PRE,POST|RESET> (component-per-lane physics, MDP phases in its tail)" if n_local * 16 <= 1024 * 64 \
+            else "env_step_kernel<4,ALL> (leg-per-lane)"
         out = {
             "metric": "env-steps/sec, Go2 flat 12-DOF, 4096 envs @1/2/4/8 MI355X",
             "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -153,7 +153,7 @@ def main():
                        "envs_total": total_envs, "parallelism": f"env-shard x{world}" + (" + all-gather(obs,rew,done)" if world > 1 and not args.no_gather else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": hbm_traffic(f"go2_flat_{n_local}"),
-                         "kernel": "physics launch of: " + layout, "launch_us": launch_s * 1e6, "samples": kern_n,
+                         "kernel": layout, "launch_us": launch_s * 1e6, "samples": kern_n,
                          "step_device_us": dev_ms * 1e3 / args.steps,
                          "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n_local},
         }

@@ -227,6 +227,8 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         stg0 = src[threadIdx.x]; stg1 = src[threadIdx.x + BLOCK]; stg2 = src[threadIdx.x + 2 * BLOCK]; stg3 = src[threadIdx.x + 3 * BLOCK];
     }
     const LgBuffers &B = p.B;
+    unsigned long long _stamp0 = 0; (void)_stamp0;
+    STAMP(0);
     const int tid = blockIdx.x * BLOCK + threadIdx.x;
     Lane L;
     L.c = tid & 3; L.is0 = L.c == 0; L.is1 = L.c == 1; L.is2 = L.c == 2; L.is3 = L.c == 3;
@@ -333,7 +335,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     // collision spheres (foot excluded): five "slots", in each the four lanes of the quad test four different
     // spheres of the SAME body in scalar form.  slot 0: hip, 1: thigh, 2-3: calf, 4: base (4 per quad)
     constexpr int NSLOT = 5;
-    float sx[NSLOT], sy[NSLOT], sz[NSLOT], srad[NSLOT], sw[NSLOT];
+    float sx[NSLOT], sy[NSLOT], sz[NSLOT], srad[NSLOT], sden[NSLOT], sidw[NSLOT];   // sden = 1/(1 + kappa dt w), sidw = 1/(dt w)
     {
         const int a0 = M->body_sph_start[b0], a1 = M->body_sph_start[b0 + 1], a2 = M->body_sph_start[b0 + 2], a3 = M->body_sph_start[b0 + 3];
         const int e0 = M->body_sph_start[0], e1 = M->body_sph_start[1];
@@ -352,7 +354,9 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const int s = max(idx[k], 0);
             sx[k] = M->sph_pos[s][0]; sy[k] = M->sph_pos[s][1]; sz[k] = M->sph_pos[s][2];
             srad[k] = idx[k] >= 0 ? M->sph_r[s] : -1e30f;    // an empty slot is infinitely far from any surface
-            sw[k] = M->sph_w[s];
+            const float wi = M->sph_w[s];
+            sden[k] = 1.f / (1.f + kappa * dt * wi);
+            sidw[k] = 1.f / (dt * wi);
         }
     }
 
@@ -363,6 +367,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     const int decim = HOT(o_decimation), iters = HOT(o_contact_iters);
     const float mv = HOT(o_max_base_lin_vel), mw = HOT(o_max_base_ang_vel);
 
+    STAMP(12);
     for (int sub = 0; sub < decim; sub++) {
         const QM Rb = quat_rows(L, quat);
         QKin K[3];
@@ -402,6 +407,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 Rp = K[j].R; Pp = K[j].P; Vp = K[j].V;
             }
         }
+        if (sub == 0) STAMP(13);
         // ---- body collision spheres -----------------------------------------------------------------
         // ext[b]: spatial force about O on chain body b from its spheres; extb: on the base (this quad's share)
         QV6 ext[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, extb = {0.f, 0.f};
@@ -426,14 +432,14 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                     }
                     const float wx = bc<0>(V.a), wy = bc<1>(V.a), wz = bc<2>(V.a);
                     const float vx = bc<0>(V.l) + (wy * rz - wz * ry), vy = bc<1>(V.l) + (wz * rx - wx * rz), vz = bc<2>(V.l) + (wx * ry - wy * rx);
-                    const float vn = vx * nx + vy * ny + vz * nz, wi = sw[k];
-                    const float fn = (kc * depth - kappa * vn) * rcp(1.f + kappa * dt * wi);
+                    const float vn = vx * nx + vy * ny + vz * nz;
+                    const float fn = (kc * depth - kappa * vn) * sden[k];
                     float fx = 0.f, fy = 0.f, fz = 0.f;
                     if (on && fn > 0.f) {
                         const float tx = vx - nx * vn, ty = vy - ny * vn, tz = vz - nz * vn;
-                        const float vtn = fsqrt(tx * tx + ty * ty + tz * tz);
-                        const float ft = fminf(vtn * rcp(dt * wi), mu * fn);
-                        const float g = vtn > 1e-9f ? ft * rcp(vtn) : 0.f;
+                        // |f_t| = min(|v_t| / (dt w), mu f_n) along -v_t: one rsq, no sqrt / division
+                        const float s2 = tx * tx + ty * ty + tz * tz;
+                        const float g = s2 > 1e-18f ? fminf(sidw[k], mu * fn * rsqrtf(s2)) : 0.f;
                         fx = nx * fn - tx * g; fy = ny * fn - ty * g; fz = nz * fn - tz * g;
                     }
                     const float cx = rx - nx * srad[k], cy = ry - ny * srad[k], cz = rz - nz * srad[k];
@@ -452,6 +458,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         }
         f_link[0] = ext[0].l; f_link[1] = ext[1].l; f_link[2] = ext[2].l;
 
+        if (sub == 0) STAMP(14);
         // ---- actuation (genesis_simulator.py:630-642), three joints at once ---------------------------
         torque = kps * (act * ascale + q0 - q) - kds * qd;
         const float tau = clampf(torque, -Leff, Leff) - jdamp * qd - jfric * clampf(qd * 20.f, -1.f, 1.f);
@@ -486,6 +493,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             IA = rank1_down(IA, J[j].U, J[j].dinv);
             if (L.c == j) dinvv = J[j].dinv;
         }
+        if (sub == 0) STAMP(15);
         // ---- base ---------------------------------------------------------------------------------
         QI6 IA0;
         IA0.A.c0 = legsum<LEGS>(IA.A.c0); IA0.A.c1 = legsum<LEGS>(IA.A.c1); IA0.A.c2 = legsum<LEGS>(IA.A.c2);
@@ -506,6 +514,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         }
         const QI6 Inv = inv6(L, IA0);
         QV6 a0 = muli6(Inv, QV6{-p0.a, -p0.l});
+        if (sub == 0) STAMP(16);
         // ---- pass 3 (root -> leaf) ----------------------------------------------------------------
         float qdd;
         QV6 a_calf;
@@ -517,6 +526,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             qdd = L.sel(g0, g1, g2);
             a_calf = a;
         }
+        if (sub == 0) STAMP(17);
         // ---- stage 2: foot contact (exact 3x3 W) + joint-limit stops, block-Jacobi ----------------------
         float fc = 0.f;                       // foot force in the contact frame (n, t1, t2), component layout
         float cn, ct1 = L.d0, ct2 = L.d1, cp, depth;
@@ -573,6 +583,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 const float apt = a_calf.l + cross(a_calf.a, cp) + cross(K[2].V.a, vpt);
                 vfree = mulv(E, vpt + apt * dt);
             }
+            if (sub == 0) STAMP(18);
             float resp_c = 0.f;
             for (int it = 0; it < iters; it++) {
                 // foot: velocity it would have without its own force, then the local law
@@ -594,8 +605,8 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                     float f0 = sum3(x0 * rhs) * inv, f1 = sum3(x1 * rhs) * inv, f2 = sum3(x2 * rhs) * inv;
                     bool ok = fact && fabsf(det) >= 1e-30f && f0 > 0.f;
                     const float A00 = bc<0>(Ac.c0), A01 = bc<0>(Ac.c1), A02 = bc<0>(Ac.c2);   // DPP stays outside the branch
-                    const float ftn = fsqrt(f1 * f1 + f2 * f2);
-                    const float iftn = rcp(ftn), e1 = f1 * iftn, e2 = f2 * iftn;
+                    const float ft2 = f1 * f1 + f2 * f2, iftn = rsqrtf(ft2), ftn = ft2 * iftn;
+                    const float e1 = f1 * iftn, e2 = f2 * iftn;
                     const float fn = rn * rcp(1.f + kappa * (A00 + mu * (A01 * e1 + A02 * e2)));
                     if (ftn > mu * f0) { ok = ok && fn > 0.f; f0 = fn; f1 = mu * fn * e1; f2 = mu * fn * e2; }
                     fc = ok ? L.sel(f0, f1, f2) : 0.f;
@@ -624,6 +635,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         } else {
             f_link[3] = 0.f;
         }
+        if (sub == 0) STAMP(19);
         // ---- semi-implicit Euler ------------------------------------------------------------------
         {
             const float alpha = a0.a + da0.a;
@@ -643,9 +655,11 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const float nq = chh * quat + (L.is3 ? -dv : qw_b * d + cross(d, quat));
             quat = nq * rsqrtf(sum4(nq * nq));
         }
+        if (sub == 0) STAMP(20);
         f_base = legsum<LEGS>(extb.l);
     }  // sub-steps
 
+    STAMP(21);
     // ---------------- read-back (genesis_simulator.py:35-60) ---------------------------------------
     {   // non-finite guard: re-seat the robot
         const float chk = quat + (L.is3 ? 0.f : pos + vw + ww + q + qd);
@@ -769,6 +783,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         if (L.is0 && leg == 0 && (mask & 1u)) B.link_contact_states[(size_t)e * nst] = fb > 1.f ? 1.f : 0.f;
     }
 
+    STAMP(22);
     // ---------------- MDP phases in the same launch -------------------------------------------------
     if (MPH != 0) {
         // everything the MDP reads was stored above by this very wave (workgroup = one wave): a workgroup-scope fence

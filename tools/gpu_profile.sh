@@ -12,7 +12,7 @@ rocprofv3 --kernel-trace --pmc FETCH_SIZE -d gpurun_out/pmc_fetch --output-forma
 rocprofv3 --kernel-trace --pmc WRITE_SIZE -d gpurun_out/pmc_write --output-format csv -- python3 tools/prof_steady.py 4096 300 100 > /dev/null 2> gpurun_out/pmc_write.err
 F=$(find gpurun_out/pmc_fetch -name "*counter_collection.csv" | head -1)
 W=$(find gpurun_out/pmc_write -name "*counter_collection.csv" | head -1)
-python tools/pmc_traffic.py "$F" "$W" quad_sim_kernel go2_flat_4096
+python tools/pmc_traffic.py "$F" "$W" "quad_sim_kernel<4, true, 12u>" go2_flat_4096
 cp profiles/hbm_traffic.json gpurun_out/hbm_traffic.json
 S=$(find gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1)
 cp "$S" gpurun_out/kernel_stats.csv
