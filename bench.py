@@ -20,7 +20,51 @@ sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
 BYTES_PER_ENV_STEP = 988          # go2 flat, f32, state read once + written once
+# the other configs: SURVEY 8(d) "roofline env-steps/s at 8 TB/s" column (1.1e9 / 5.4e8 / 5.9e8) turned back into bytes; they
+# assume the whole observation history is rewritten every step, which the sliding window no longer does
+TASK_BYTES = {"go2": BYTES_PER_ENV_STEP, "go2_wtw": 7273, "go2_ee": 14815, "tron1_pf_ee": 13559}
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
+
+
+WORKLOADS = {"go2": "go2_flat, flat-plane contact", "go2_wtw": "go2_wtw, periodic-gait rewards + domain rand, flat plane",
+             "go2_ee": "go2_rough (go2_ee), heightfield terrain + terrain curriculum",
+             "tron1_pf_ee": "tron1_pf_rough (tron1_pf_ee), biped, heightfield terrain + terrain curriculum"}
+
+
+def ppo_rollout(env, iters, dev):
+    """the rollout loop of rsl_rl/runners/on_policy_runner.py:118-124 -- act, step, store -- with the go2
+    policy nets (rsl_rl/modules/actor_critic.py:57-82, dims legged_robot_config.py:279-281) as plain torch modules."""
+    import torch
+    import torch.nn as nn
+
+    def mlp(i, o):
+        return nn.Sequential(nn.Linear(i, 512), nn.ELU(), nn.Linear(512, 256), nn.ELU(), nn.Linear(256, 128), nn.ELU(), nn.Linear(128, o)).to(dev)
+    torch.manual_seed(1)
+    n, A, O = env.num_envs, env.num_actions, int(env.num_obs)
+    actor, critic = mlp(O, A), mlp(O, 1)
+    obs = env.get_observations()
+    obs = obs[0] if isinstance(obs, tuple) else obs
+    store = dict(obs=torch.empty(24, n, O, device=dev), act=torch.empty(24, n, A, device=dev), rew=torch.empty(24, n, device=dev),
+                 done=torch.empty(24, n, device=dev), val=torch.empty(24, n, device=dev))
+
+    def rollout():
+        nonlocal obs
+        with torch.inference_mode():
+            for t in range(24):
+                act = actor(obs) + torch.randn(n, A, device=dev)          # mean + unit-std exploration noise
+                val = critic(obs)
+                store["obs"][t], store["act"][t], store["val"][t] = obs, act, val[:, 0]
+                out = env.step(act)
+                obs, store["rew"][t], store["done"][t] = out[0], out[-3], out[-2]
+    rollout()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(iters):
+        rollout()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"value": n * 24 * iters / dt, "unit": "env-steps/s", "iters": iters, "steps_per_iter": 24,
+            "ms_per_step": dt / (24 * iters) * 1e3, "policy": "actor/critic MLP 512-256-128 ELU, f32, torch (hipBLASLt GEMMs)"}
 
 
 def host_threads():
@@ -76,6 +120,12 @@ def main():
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step RCCL all-gather at N>1")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-timer-stride", type=int, default=8, help="time the physics kernel of every n-th step (0 = off)")
+    ap.add_argument("--task", default="go2", choices=["go2", "go2_wtw", "go2_ee", "tron1_pf_ee"],
+                    help="BASELINE config to run (the headline metric is go2; the others are reported under the same keys "
+                         "with their own workload string)")
+    ap.add_argument("--ppo-rollout", type=int, default=0, metavar="ITERS",
+                    help="also time ITERS rollouts of 24 steps with the go2 actor/critic MLPs (45-512-256-128-12 / -1, ELU) "
+                         "run between the steps (SURVEY 8d ii); reported under 'ppo_rollout', never as 'value'")
     args = ap.parse_args()
 
     import torch
@@ -94,7 +144,8 @@ def main():
 
     from hcr_genesis_lr_cl_amd.envs import make_env
     n_local = args.envs_per_gpu
-    env, cfg = make_env("go2", n_local, dev, env_id_offset=rank * n_local, global_num_envs=n_local * world)
+    env, cfg = make_env(args.task, n_local, dev, env_id_offset=rank * n_local, global_num_envs=n_local * world)
+    n_obs = int(env.num_obs)
     env.reset()
     # on_policy_runner.py:105-106 init_at_random_ep_len
     g = torch.Generator(device=dev)
@@ -102,15 +153,16 @@ def main():
     env.episode_length_buf[:] = torch.randint(0, int(env.max_episode_length), (n_local,), generator=g, device=dev, dtype=torch.int32)
     # fixed synthetic action stream: a small bank of N(0,1) batches cycled (clipped +-100 in-kernel)
     bank = [torch.randn(n_local, env.num_actions, generator=g, device=dev) for _ in range(16)]
-    rec = torch.empty(n_local, 47, device=dev)
-    gathered = torch.empty(world * n_local, 47, device=dev) if world > 1 else None
+    rec = torch.empty(n_local, n_obs + 2, device=dev)
+    gathered = torch.empty(world * n_local, n_obs + 2, device=dev) if world > 1 else None
 
     def one_step(i):
-        obs, _, rew, done, _ = env.step(bank[i % len(bank)])
+        out = env.step(bank[i % len(bank)])
+        obs, rew, done = out[0], out[-3], out[-2]      # 5-tuple (go2, wtw) or 6-tuple (estimator tasks): same tail
         if gathered is not None and not args.no_gather:
-            rec[:, :45] = obs
-            rec[:, 45] = rew
-            rec[:, 46] = done
+            rec[:, :n_obs] = obs
+            rec[:, n_obs] = rew
+            rec[:, n_obs + 1] = done
             dist.all_gather_into_tensor(gathered, rec)
 
     for i in range(args.warmup):
@@ -140,23 +192,31 @@ def main():
         value = total_envs * args.steps / elapsed
         kern_us, kern_n = env._engine.profile_read()
         launch_s = kern_us * 1e-6 if kern_n else dev_ms / 1e3 / args.steps
-        achieved = BYTES_PER_ENV_STEP * n_local / launch_s / 1e9
-        layout = "quad_sim_kernel<4,PRE,POST|RESET> (component-per-lane physics, MDP phases in its tail)" if n_local * 16 <= 1024 * 64 \
-            else "env_step_kernel<4,ALL> (leg-per-lane)"
+        bytes_env = TASK_BYTES[args.task]
+        achieved = bytes_env * n_local / launch_s / 1e9
+        legs = 2 if args.task == "tron1_pf_ee" else 4
+        if n_local * legs * 4 > 1024 * 64:
+            layout = f"env_step_kernel<{legs},ALL> (leg-per-lane)"
+        elif legs == 4:
+            layout = "quad_sim_kernel<4,PRE,POST|RESET> (component-per-lane physics, MDP phases in its tail)"
+        else:
+            layout = "quad_sim_kernel<2,PRE,0> (component-per-lane physics; MDP phases follow in env_step_kernel<2,POST|RESET>)"
         out = {
-            "metric": "env-steps/sec, Go2 flat 12-DOF, 4096 envs @1/2/4/8 MI355X",
+            "metric": "env-steps/sec, Go2 flat 12-DOF, 4096 envs @1/2/4/8 MI355X" if args.task == "go2" else f"env-steps/sec, {args.task}",
             "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": f"go2_flat, {n_local} envs per GPU, flat-plane contact, fused LeggedRobot.step "
+            "config": {"workload": f"{WORKLOADS[args.task]}, {n_local} envs per GPU, fused LeggedRobot.step "
                                    f"(4 sub-steps dt=0.005) with synthetic N(0,1) actions",
                        "envs_total": total_envs, "parallelism": f"env-shard x{world}" + (" + all-gather(obs,rew,done)" if world > 1 and not args.no_gather else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": hbm_traffic(f"go2_flat_{n_local}"),
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": hbm_traffic(f"go2_flat_{n_local}") if args.task == "go2" else None,
                          "kernel": layout, "launch_us": launch_s * 1e6, "samples": kern_n,
                          "step_device_us": dev_ms * 1e3 / args.steps,
-                         "algorithmic_bytes_per_launch": BYTES_PER_ENV_STEP * n_local},
+                         "algorithmic_bytes_per_launch": bytes_env * n_local},
         }
+        if world == 1 and args.ppo_rollout > 0:
+            out["ppo_rollout"] = ppo_rollout(env, args.ppo_rollout, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

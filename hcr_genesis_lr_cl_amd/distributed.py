@@ -16,6 +16,22 @@ def shard(global_num_envs: int, world: int, rank: int):
     return rank * n, n
 
 
+def global_mean(local_sum, local_count):
+    """Mean over the envs of ALL ranks from each rank's (sum, count) -- the command-curriculum decision of
+    legged_robot.py:336-348 is a mean over the envs that reset at the gate step, wherever they live (one
+    small all-reduce every max_episode_length steps).  Every rank must call it at the gate step, also with count 0.
+    Returns (mean, total_count) as Python floats; without an initialised process group it is the local mean."""
+    import torch.distributed as dist
+    dev = local_sum.device if torch.is_tensor(local_sum) else torch.device("cpu")
+    t = torch.zeros(2, dtype=torch.float64, device=dev)
+    t[0] = local_sum
+    t[1] = float(local_count)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    s, c = float(t[0]), float(t[1])
+    return (s / c if c > 0 else 0.0), c
+
+
 class StepGather:
     """Packs one step's outputs into a (n_local, obs+2) record and all-gathers it."""
 

@@ -124,8 +124,8 @@ class LeggedRobot:
             # step, before they are zeroed (legged_robot.py:110-111, 336-348): split the launch
             self._engine.step(abi.PHASE_PRE | abi.PHASE_SIM | abi.PHASE_POST, actions, c)
             env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()
+            self._update_command_curriculum(env_ids)      # collective across ranks: called even with no local reset
             if len(env_ids) > 0:
-                self._update_command_curriculum(env_ids)
                 self._on_curriculum_gate(env_ids)
             self._engine.step(abi.PHASE_RESET, None, c)
         else:
@@ -155,10 +155,12 @@ class LeggedRobot:
 
     # ------------------------------------------------------------------------------------------
     def _update_command_curriculum(self, env_ids):
-        """legged_robot.py:336-348."""
+        """legged_robot.py:336-348; the mean runs over the resetting envs of every rank (distributed.global_mean)."""
+        from ..distributed import global_mean
         k = abi.REWARD_ID["tracking_lin_vel"]
-        mean = torch.mean(self._engine.buf["episode_sums"][k][env_ids]) / self.max_episode_length
-        if mean > self.cfg.commands.curriculum_threshold * self.reward_scales["tracking_lin_vel"]:
+        local = self._engine.buf["episode_sums"][k][env_ids].sum() if len(env_ids) > 0 else torch.zeros((), device=self.device)
+        mean, count = global_mean(local, len(env_ids))
+        if count > 0 and mean / self.max_episode_length > self.cfg.commands.curriculum_threshold * self.reward_scales["tracking_lin_vel"]:
             r = self.command_ranges["lin_vel_x"]
             r[0] = float(np.clip(r[0] - 0.5, -self.cfg.commands.max_curriculum, 0.))
             r[1] = float(np.clip(r[1] + 0.5, 0., self.cfg.commands.max_curriculum))
@@ -173,8 +175,11 @@ class LeggedRobot:
         ids = self.reset_buf.nonzero(as_tuple=False).flatten()
         if len(ids) > 0:
             k = abi.REWARD_ID["tracking_lin_vel"]
-            m = torch.mean(self._engine.buf["episode_sums"][k][ids]) / self.max_episode_length
-            bool(m > self.cfg.commands.curriculum_threshold)
+            t = torch.zeros(2, dtype=torch.float64, device=self.device)     # same ops as distributed.global_mean, no collective
+            t[0] = self._engine.buf["episode_sums"][k][ids].sum()
+            t[1] = float(len(ids))
+            float(t[0]) / max(float(t[1]), 1.0)
+            float(torch.mean(self._engine.buf["episode_sums"][k][ids]))      # task curricula use means (go2_wtw.py:220-247)
         self._upload_command_ranges()
 
     def _on_curriculum_gate(self, env_ids):

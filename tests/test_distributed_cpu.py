@@ -7,7 +7,7 @@ import numpy as np
 import torch
 import torch.multiprocessing as mp
 
-from hcr_genesis_lr_cl_amd.distributed import StepGather, shard
+from hcr_genesis_lr_cl_amd.distributed import StepGather, global_mean, shard
 
 
 def _free_port():
@@ -24,6 +24,9 @@ def _worker(rank, world, port, q):
     obs = ids[:, None] * torch.ones(1, 5) + torch.arange(5) * 0.1
     out = g(obs, ids * 2, (ids % 3 == 0).float())
     o, r, d = g.split()
+    # command-curriculum mean over the resetting envs of all ranks: rank 0 has 3 of them (sum 6), rank 1 none
+    gm = global_mean(torch.tensor(6.0) if rank == 0 else torch.tensor(0.0), 3 if rank == 0 else 0)
+    assert gm == (2.0, 3.0), gm
     q.put((rank, o.numpy().copy(), r.numpy().copy(), d.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -49,3 +52,8 @@ def test_shard_is_contiguous_and_even():
     import pytest
     with pytest.raises(ValueError):
         shard(10, 4, 0)
+
+
+def test_global_mean_without_process_group_is_local():
+    assert global_mean(torch.tensor(9.0), 3) == (3.0, 3.0)
+    assert global_mean(torch.tensor(0.0), 0) == (0.0, 0.0)
