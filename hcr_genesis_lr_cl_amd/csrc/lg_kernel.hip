@@ -308,6 +308,10 @@ struct KParams {
     const float *actions;
     long long counter;
     int jrot_identity;   // every joint frame is axis-aligned with its parent at q = 0 (host-checked)
+    // kernarg copies of the few constants the start-of-kernel load burst needs for its addresses and predicates (scalar
+    // loads that return before anything else): reading them from the hot block would put a full memory round trip in
+    // front of the burst
+    struct { int m_n_links, m_foot_link[4], obs_layout, o_n_height_points; unsigned reward_mask; float clip_actions; } k;
     int obs_win;         // first frame of the observation window this launch writes (sliding history, LgTaskCfg.obs_slack)
 };
 
@@ -463,7 +467,7 @@ __global__ __launch_bounds__(256) void obs_compact_kernel(float *buf, int n_rows
 // the wave, one per leg of the wave's envs: the model table, the hot constants and the command ranges are already in
 // LDS, `vtid` is the leg-lane index and nothing is staged here.
 template <int LEGS, unsigned PH, bool FUSED>
-LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, const int vtid, const int vlane) {
+LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF, const int vtid, const int vlane) {
     constexpr bool DO_PRE = (PH & LG_PHASE_PRE) != 0, DO_SIM = (PH & LG_PHASE_SIM) != 0;
     constexpr bool DO_POST = (PH & LG_PHASE_POST) != 0, DO_RESET = (PH & LG_PHASE_RESET) != 0;
     constexpr int A = LEGS * 3;
@@ -495,18 +499,18 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, const int v
     const bool live = e < B.n_envs;
     if (!live) e = B.n_envs - 1;  // dead lanes shadow the last env (keeps DPP quads uniform), never store
     const bool lead = live && leg == 0;
-    const int L = HOTB(m_n_links), F = LEGS;
+    const int L = p.k.m_n_links, F = LEGS;
     const int b0 = 1 + 3 * leg;            // first body of this lane's chain
     const int d0 = 3 * leg;                // first dof
-    const int foot_link = leg == 0 ? HOTB(m_foot_link[0]) : (leg == 1 ? HOTB(m_foot_link[1]) : (leg == 2 ? HOTB(m_foot_link[2]) : HOTB(m_foot_link[3])));
+    const int foot_link = leg == 0 ? p.k.m_foot_link[0] : (leg == 1 ? p.k.m_foot_link[1] : (leg == 2 ? p.k.m_foot_link[2] : p.k.m_foot_link[3]));
     int foot_slot = 0;                     // rank of this foot among feet in link order (feet_indices)
 #pragma unroll
-    for (int k = 0; k < LEGS; k++) foot_slot += (HOTB(m_foot_link[k]) < foot_link) ? 1 : 0;
+    for (int k = 0; k < LEGS; k++) foot_slot += (p.k.m_foot_link[k] < foot_link) ? 1 : 0;
 
     // ---------------- PRE: clip + action history (legged_robot.py:230-239) -----------------
     float act[3], last_act[3], llast_act[3];
     if (DO_PRE) {
-        const float ca = HOTB(clip_actions);
+        const float ca = p.k.clip_actions;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             float prev = B.actions[e * A + d0 + j], prev2 = B.last_actions[e * A + d0 + j];
@@ -536,7 +540,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, const int v
     // ---- MDP working set, fetched NOW so that the round trips overlap the physics below instead of being
     //      exposed one by one behind it (a lone wave per SIMD has nothing else to switch to) -----------------
     constexpr bool DO_MDP = DO_POST || DO_RESET;
-    const unsigned rmask0 = (unsigned)HOTB(reward_mask), rmask = rmask0;   // scalar for the whole kernel
+    const unsigned rmask0 = (unsigned)p.k.reward_mask, rmask = rmask0;   // scalar for the whole kernel
     const int N = B.n_envs;
     float q0l[3], soft_lo[3] = {0.f, 0.f, 0.f}, soft_hi[3] = {0.f, 0.f, 0.f}, rdof_lo[3] = {0.f, 0.f, 0.f}, rdof_span[3] = {0.f, 0.f, 0.f};
     float nv_q[3] = {0.f, 0.f, 0.f}, nv_qd[3] = {0.f, 0.f, 0.f}, nv_act[3] = {0.f, 0.f, 0.f}, nv_clk[2] = {0.f, 0.f};
@@ -567,14 +571,14 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, const int v
         }
         if (B.joint_armature) dr_joint = v3(B.joint_armature[e], B.joint_friction[e], B.joint_damping[e]);
     }
-    if (DO_MDP) {
+    if (DO_MDP && !FUSED) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             soft_lo[j] = T->soft_dof_lo[d0 + j]; soft_hi[j] = T->soft_dof_hi[d0 + j];
             rdof_lo[j] = T->reset_dof_lo[d0 + j]; rdof_span[j] = T->reset_dof_span[d0 + j];
             nv_q[j] = T->noise_vec[9 + d0 + j]; nv_qd[j] = T->noise_vec[9 + A + d0 + j]; nv_act[j] = T->noise_vec[9 + 2 * A + d0 + j];
         }
-        if (HOTB(obs_layout) == LG_OBS_TRON1_EE) { nv_clk[0] = T->noise_vec[9 + 3 * A + foot_slot]; nv_clk[1] = T->noise_vec[9 + 3 * A + LEGS + foot_slot]; }
+        if (p.k.obs_layout == LG_OBS_TRON1_EE) { nv_clk[0] = T->noise_vec[9 + 3 * A + foot_slot]; nv_clk[1] = T->noise_vec[9 + 3 * A + LEGS + foot_slot]; }
         cmd0 = B.commands[4 * e]; cmd1 = B.commands[4 * e + 1]; cmd2 = B.commands[4 * e + 2]; cmd3 = B.commands[4 * e + 3];
         ep_len = B.episode_length_buf[e];
         fail_buf = B.fail_buf[e];
@@ -596,7 +600,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, const int v
     V3 foot_p, foot_v, last_foot_v = v3(0, 0, 0);
     float foot_hmean = 0.f, foot_hmax = 0.f;  // mean / max of the 9 terrain heights around this lane's foot (a8)
     float mean_height = 0.f;         // mean over the height-sample grid of (base_z - h) is formed from this (a7)
-    const int P = HOTB(o_n_height_points);
+    const int P = p.k.o_n_height_points;
 
     // compiler-level memory barrier: every load above is issued before anything below (LLVM otherwise sinks each one
     // next to its consumer, where its full round trip is exposed); no hardware wait is emitted here
@@ -1173,21 +1177,22 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, const int v
 
     STAMP(5);
     if (!DO_POST && !DO_RESET) return;
-    if (STASH) {   // bring the MDP working set back from LDS
+    if (STASH || FUSED) {   // bring the MDP working set back from LDS (fused: prefetched by quad_sim_kernel's prologue)
         const int t = threadIdx.x;
+        auto SS = [&](int k) { return FUSED ? sStF[k * 16 + vlane] : sSt[k][t]; };
 #pragma unroll
-        for (int k = 0; k < LG_R_COUNT; k++) es[k] = sSt[k][t];
+        for (int k = 0; k < LG_R_COUNT; k++) es[k] = SS(k);
         int c = LG_R_COUNT;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
-            soft_lo[j] = sSt[c++][t]; soft_hi[j] = sSt[c++][t]; rdof_lo[j] = sSt[c++][t]; rdof_span[j] = sSt[c++][t];
-            nv_q[j] = sSt[c++][t]; nv_qd[j] = sSt[c++][t]; nv_act[j] = sSt[c++][t];
+            soft_lo[j] = SS(c++); soft_hi[j] = SS(c++); rdof_lo[j] = SS(c++); rdof_span[j] = SS(c++);
+            nv_q[j] = SS(c++); nv_qd[j] = SS(c++); nv_act[j] = SS(c++);
         }
-        nv_clk[0] = sSt[c++][t]; nv_clk[1] = sSt[c++][t];
-        cmd0 = sSt[c++][t]; cmd1 = sSt[c++][t]; cmd2 = sSt[c++][t]; cmd3 = sSt[c++][t];
-        ep_len = __float_as_int(sSt[c++][t]); fail_buf = (long long)__float_as_int(sSt[c++][t]); air = sSt[c++][t];
-        last_contact = __float_as_int(sSt[c++][t]);
-        origin_pre.x = sSt[c++][t]; origin_pre.y = sSt[c++][t]; origin_pre.z = sSt[c++][t];
+        nv_clk[0] = SS(c++); nv_clk[1] = SS(c++);
+        cmd0 = SS(c++); cmd1 = SS(c++); cmd2 = SS(c++); cmd3 = SS(c++);
+        ep_len = __float_as_int(SS(c++)); fail_buf = (long long)__float_as_int(SS(c++)); air = SS(c++);
+        last_contact = __float_as_int(SS(c++));
+        origin_pre.x = SS(c++); origin_pre.y = SS(c++); origin_pre.z = SS(c++);
     }
 
     // ======================= MDP: legged_robot.py:55-168, 300-334 ============================
@@ -1846,7 +1851,7 @@ template <int LEGS, unsigned PH>
 __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_STG * BLOCK];
     __shared__ int sHot[256 + BLOCK];
-    env_step_body<LEGS, PH, false>(p, sMraw, sHot, blockIdx.x * BLOCK + threadIdx.x, threadIdx.x & 63);
+    env_step_body<LEGS, PH, false>(p, sMraw, sHot, nullptr, blockIdx.x * BLOCK + threadIdx.x, threadIdx.x & 63);
 }
 
 #include "lg_quad.h"
@@ -1862,6 +1867,7 @@ struct LgEngine {
     const int16_t *hf = nullptr;
     LgBuffers bufs; bool bound = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    LgHot hot;           // host copy of the hot block (upload_hot)
     int obs_win = 0;     // window of the latest stacked observation (obs_slack > 0)
     // bounded run-ahead: the host never gets more than ~128 lg_step calls ahead of the device (see lg_step)
     hipEvent_t ra_ev[4] = {nullptr, nullptr, nullptr, nullptr}; long long ra_calls = 0;
@@ -1876,6 +1882,7 @@ extern "C" int lg_abi_version(void) { return LG_ABI_VERSION; }
 static int upload_hot(LgEngine *h) {
     LgHot hot;
     fill_hot(hot, h->task, h->opts, h->model);
+    h->hot = hot;
     if (!h->d_hot) { hipError_t e = hipMalloc(&h->d_hot, 1024); if (e != hipSuccess) return fail(std::string("hipMalloc(hot): ") + hipGetErrorString(e)); }
     HIPCHK(hipMemset(h->d_hot, 0, 1024));
     HIPCHK(hipMemcpy(h->d_hot, &hot, sizeof(LgHot), hipMemcpyHostToDevice));
@@ -1996,6 +2003,13 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
     KParams p;
     p.M = h->d_model; p.O = h->d_opts; p.T = h->d_task; p.H = h->d_hot; p.hf = h->hf; p.B = h->bufs; p.actions = actions; p.counter = counter;
     p.jrot_identity = 1;
+    {
+        const LgHot &hot = h->hot;   // refreshed by upload_hot
+        p.k.m_n_links = hot.m_n_links;
+        for (int i = 0; i < 4; i++) p.k.m_foot_link[i] = hot.m_foot_link[i];
+        p.k.obs_layout = hot.obs_layout; p.k.o_n_height_points = hot.o_n_height_points;
+        p.k.reward_mask = (unsigned)hot.reward_mask; p.k.clip_actions = hot.clip_actions;
+    }
     for (int b = 1; b < h->model.n_bodies; b++)
         for (int k = 0; k < 9; k++)
             if (h->model.jrot[b][k] != ((k % 4 == 0) ? 1.f : 0.f)) p.jrot_identity = 0;

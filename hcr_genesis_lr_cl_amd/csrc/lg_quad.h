@@ -241,18 +241,18 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     if (!live) e = N - 1;
     const bool st = live && !L.is3;           // this lane stores vector components / joint values
     const bool lead = st && leg == 0;         // ... and the per-env ones
-    const int nL = HOT0(m_n_links), F = LEGS;
+    const int nL = p.k.m_n_links, F = LEGS;
     const int b0 = 1 + 3 * leg, d0 = 3 * leg;
-    const int foot_link = leg == 0 ? HOT0(m_foot_link[0]) : (leg == 1 ? HOT0(m_foot_link[1]) : (leg == 2 ? HOT0(m_foot_link[2]) : HOT0(m_foot_link[3])));
+    const int foot_link = leg == 0 ? p.k.m_foot_link[0] : (leg == 1 ? p.k.m_foot_link[1] : (leg == 2 ? p.k.m_foot_link[2] : p.k.m_foot_link[3]));
     int foot_slot = 0;
 #pragma unroll
-    for (int k = 0; k < LEGS; k++) foot_slot += (HOT0(m_foot_link[k]) < foot_link) ? 1 : 0;
+    for (int k = 0; k < LEGS; k++) foot_slot += (p.k.m_foot_link[k] < foot_link) ? 1 : 0;
 
     // ---------------- start-of-kernel loads (one burst, one wait) --------------------------------
     const int ja = e * A + d0 + cj;           // this lane's joint
     float act, last_act = 0.f, llast_act = 0.f;
     if (DO_PRE) {
-        const float ca = HOT0(clip_actions);
+        const float ca = p.k.clip_actions;
         last_act = B.actions[ja]; llast_act = B.last_actions[ja];
         act = clampf(p.actions[ja], -ca, ca);
     } else {
@@ -273,10 +273,52 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     const float origin = B.env_origins ? B.env_origins[3 * e + cj] : 0.f;
     int crv = 0;
     if (MPH != 0) crv = reinterpret_cast<const int *>(B.command_ranges)[min((int)threadIdx.x, LG_CMD_RANGE_FLOATS - 1)];
+    // MDP working set of the wave's 16 legs, fetched by lanes 0..15 in this same burst and parked in LDS: the MDP tail
+    // (env_step_body<.., FUSED>) reads it back after the physics instead of paying the round trips then.  Layout = the
+    // stash of env_step_body (NST values x 16 lanes).
+    constexpr int NST = LG_R_COUNT + 36;
+    __shared__ float sStF[MPH != 0 ? NST * 16 : 1];
+    float wsv[MPH != 0 ? NST : 1];
+    if (MPH != 0 && threadIdx.x < 16) {
+        const LgTaskCfg *__restrict__ T = p.T;
+        const int lt = blockIdx.x * 16 + (int)threadIdx.x, legL = lt % LEGS, dL = 3 * legL;
+        const int eL = min(lt / LEGS, N - 1);
+        const int flL = legL == 0 ? p.k.m_foot_link[0] : (legL == 1 ? p.k.m_foot_link[1] : (legL == 2 ? p.k.m_foot_link[2] : p.k.m_foot_link[3]));
+        int fsL = 0;
+#pragma unroll
+        for (int k = 0; k < LEGS; k++) fsL += (p.k.m_foot_link[k] < flL) ? 1 : 0;
+#pragma unroll
+        for (int k = 0; k < LG_R_COUNT; k++) wsv[k] = B.episode_sums[(size_t)k * N + eL];   // unconditional: no branch per term
+        int c2 = LG_R_COUNT;
+#pragma unroll
+        for (int j = 0; j < 3; j++) {
+            wsv[c2++] = T->soft_dof_lo[dL + j]; wsv[c2++] = T->soft_dof_hi[dL + j];
+            wsv[c2++] = T->reset_dof_lo[dL + j]; wsv[c2++] = T->reset_dof_span[dL + j];
+            wsv[c2++] = T->noise_vec[9 + dL + j]; wsv[c2++] = T->noise_vec[9 + A + dL + j]; wsv[c2++] = T->noise_vec[9 + 2 * A + dL + j];
+        }
+        const bool clk = p.k.obs_layout == LG_OBS_TRON1_EE;
+        wsv[c2++] = clk ? T->noise_vec[9 + 3 * A + fsL] : 0.f; wsv[c2++] = clk ? T->noise_vec[9 + 3 * A + LEGS + fsL] : 0.f;
+        wsv[c2++] = B.commands[4 * eL]; wsv[c2++] = B.commands[4 * eL + 1]; wsv[c2++] = B.commands[4 * eL + 2]; wsv[c2++] = B.commands[4 * eL + 3];
+        wsv[c2++] = __int_as_float(B.episode_length_buf[eL]);
+        wsv[c2++] = __int_as_float((int)B.fail_buf[eL]);
+        wsv[c2++] = B.feet_air_time[eL * F + fsL];
+        wsv[c2++] = __int_as_float((int)B.last_contacts[eL * F + fsL]);
+        wsv[c2++] = B.env_origins[3 * eL]; wsv[c2++] = B.env_origins[3 * eL + 1]; wsv[c2++] = B.env_origins[3 * eL + 2];
+    }
 
     asm volatile("" ::: "memory");
     sHot[threadIdx.x] = hv0; sHot[threadIdx.x + 64] = hv1; sHot[threadIdx.x + 128] = hv2; sHot[threadIdx.x + 192] = hv3;
-    if (MPH != 0) sHot[threadIdx.x + 256] = crv;
+    if (MPH != 0) {
+        sHot[threadIdx.x + 256] = crv;
+        if (threadIdx.x < 16) {
+            const unsigned rm = p.k.reward_mask;
+            const bool leadL = (blockIdx.x * 16 + threadIdx.x) % LEGS == 0;
+#pragma unroll
+            for (int k = 0; k < LG_R_COUNT; k++) sStF[k * 16 + threadIdx.x] = (leadL && ((rm >> k) & 1u)) ? wsv[k] : 0.f;
+#pragma unroll
+            for (int k = LG_R_COUNT; k < NST - 2; k++) sStF[k * 16 + threadIdx.x] = wsv[k];
+        }
+    }
     sMraw[threadIdx.x] = stg0; sMraw[threadIdx.x + BLOCK] = stg1; sMraw[threadIdx.x + 2 * BLOCK] = stg2; sMraw[threadIdx.x + 3 * BLOCK] = stg3;
     __syncthreads();
 
@@ -792,6 +834,6 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __syncthreads();
         if (threadIdx.x < 16)
-            env_step_body<LEGS, MPH, true>(p, sMraw, sHot, blockIdx.x * 16 + (int)threadIdx.x, (int)threadIdx.x);
+            env_step_body<LEGS, MPH, true>(p, sMraw, sHot, sStF, blockIdx.x * 16 + (int)threadIdx.x, (int)threadIdx.x);
     }
 }

@@ -1,0 +1,23 @@
+"""Diagnostic: cycle stamps of workgroup 0 through the fused step kernel (quad physics stamps 12..22, MDP tail 5..11)."""
+import os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+from hcr_genesis_lr_cl_amd.envs import make_env
+env, cfg = make_env("go2", 4096)
+env.reset()
+g = torch.Generator(device="cuda"); g.manual_seed(1)
+env.episode_length_buf[:] = torch.randint(0, 1000, (4096,), generator=g, device="cuda", dtype=torch.int32)
+bank = [torch.randn(4096, 12, generator=g, device="cuda") for _ in range(8)]
+acc = torch.zeros(32); n = 0
+for i in range(800):
+    env.step(bank[i % 8])
+    if i >= 600:
+        torch.cuda.synchronize()
+        acc += env._engine.buf["episode_done_sums"].flatten()[:32].cpu(); n += 1
+acc /= n
+order = [(12, "quad prologue+consts"), (21, "4 sub-steps (to read-back)"), (22, "read-back + stores"), (2, "mdp: fence + prologue"), (5, "mdp: state from HBM/LDS"),
+         (6, "mdp: callback"), (7, "mdp: rewards"), (8, "mdp: post end"), (9, "mdp: reset blk"), (10, "mdp: obs"), (11, "mdp: end")]
+prev = 0.0
+for k, name in order:
+    print(f"{name:30s} +{acc[k]-prev:8.0f} cycles (cum {acc[k]:8.0f})")
+    prev = acc[k]
