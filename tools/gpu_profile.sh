@@ -16,4 +16,4 @@ python tools/pmc_traffic.py "$F" "$W" "quad_sim_kernel<4, true, 12u>" go2_flat_4
 cp profiles/hbm_traffic.json gpurun_out/hbm_traffic.json
 S=$(find gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1)
 cp "$S" gpurun_out/kernel_stats.csv
-head -5 gpurun_out/kernel_stats.csv
+head -3 gpurun_out/kernel_stats.csv | cut -c1-200
