@@ -1177,6 +1177,53 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
 
     STAMP(5);
     if (!DO_POST && !DO_RESET) return;
+    // hot constants of the MDP phases, read from LDS in ONE burst (a read at the point of use costs an exposed LDS round
+    // trip each time: every reward term and observation group sits in its own basic block, and there is one wave per SIMD)
+    const auto hc_control_dt = HOT(control_dt);
+    const auto hc_tracking_sigma = HOT(tracking_sigma);
+    const auto hc_base_height_target = HOT(base_height_target);
+    const auto hc_feet_air_time_threshold = HOT(feet_air_time_threshold);
+    const auto hc_foot_clearance_target = HOT(foot_clearance_target);
+    const auto hc_foot_height_offset = HOT(foot_height_offset);
+    const auto hc_foot_clearance_sigma = HOT(foot_clearance_sigma);
+    const auto hc_max_projected_gravity = HOT(max_projected_gravity);
+    const auto hc_max_episode_length = HOT(max_episode_length);
+    const auto hc_fail_threshold = HOT(fail_threshold);
+    const auto hc_obs_scale_lin_vel = HOT(obs_scale_lin_vel);
+    const auto hc_obs_scale_ang_vel = HOT(obs_scale_ang_vel);
+    const auto hc_obs_scale_dof_pos = HOT(obs_scale_dof_pos);
+    const auto hc_obs_scale_dof_vel = HOT(obs_scale_dof_vel);
+    const auto hc_clip_obs = HOT(clip_obs);
+    const auto hc_only_positive_rewards = HOT(only_positive_rewards);
+    const auto hc_resample_steps = HOT(resample_steps);
+    const auto hc_heading_command = HOT(heading_command);
+    const auto hc_push_interval = HOT(push_interval);
+    const auto hc_obs_layout = HOT(obs_layout);
+    const auto hc_gait_mode = HOT(gait_mode);
+    const auto hc_add_noise = HOT(add_noise);
+    const auto hc_double_shift = HOT(double_shift);
+    const auto hc_obs_frame = HOT(obs_frame);
+    const auto hc_obs_stack = HOT(obs_stack);
+    const auto hc_obs_slack = HOT(obs_slack);
+    const auto hc_priv_frame = HOT(priv_frame);
+    const auto hc_priv_stack = HOT(priv_stack);
+    const auto hc_num_obs = HOT(num_obs);
+    const auto hc_num_priv_obs = HOT(num_priv_obs);
+    const auto hc_max_push_vel_xy = HOT(max_push_vel_xy);
+    const auto hc_episode_length_s = HOT(episode_length_s);
+    const auto hc_seed = HOT(seed);
+    const auto hc_env_id_offset = HOT(env_id_offset);
+    const auto hc_heights_offset = HOT(heights_offset);
+    const auto hc_obs_scale_height = HOT(obs_scale_height);
+    const auto hc_noise_act0 = HOT(noise_act0);
+    const auto hc_about_landing_threshold = HOT(about_landing_threshold);
+    const auto hc_terrain_curriculum = HOT(terrain_curriculum);
+    const auto hc_custom_origins = HOT(custom_origins);
+    const auto hc_sit_percent = HOT(sit_percent);
+    const auto hc_behavior_resample_steps = HOT(behavior_resample_steps);
+    const auto hc_heights_clip_scale = HOT(heights_clip_scale);
+    const auto hc_num_labels = HOT(num_labels);
+    asm volatile("" ::: "memory");
     if (STASH || FUSED) {   // bring the MDP working set back from LDS (fused: prefetched by quad_sim_kernel's prologue)
         const int t = threadIdx.x;
         auto SS = [&](int k) { return FUSED ? sStF[k * 16 + vlane] : sSt[k][t]; };
@@ -1199,18 +1246,18 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     RandSrc rs;
     rs.in = B.rand_in ? B.rand_in + (size_t)e * HOT(slots.n_slots) : nullptr;
     {
-        const unsigned long long gid = (unsigned long long)(HOT(env_id_offset) + e);
-        rs.k0 = (unsigned)(HOT(seed) & 0xFFFFFFFFu); rs.k1 = (unsigned)(HOT(seed) >> 32);
+        const unsigned long long gid = (unsigned long long)(hc_env_id_offset + e);
+        rs.k0 = (unsigned)(hc_seed & 0xFFFFFFFFu); rs.k1 = (unsigned)(hc_seed >> 32);
         rs.e_lo = (unsigned)(gid & 0xFFFFFFFFu); rs.e_hi = (unsigned)(gid >> 32);
         rs.step = (unsigned)p.counter;
     }
-    const float cdt = HOT(control_dt);
+    const float cdt = hc_control_dt;
     bool reset = false, time_out = false;
     float total = 0.f;
     float *esum = B.episode_sums;
 
     // ---- periodic-gait task state (go2_wtw.py:295-346): per-env scalars + this lane's foot entries
-    const bool WTW = HOT(gait_mode) == 1, BIPED = HOT(gait_mode) == 2, GAIT = WTW || BIPED;
+    const bool WTW = hc_gait_mode == 1, BIPED = hc_gait_mode == 2, GAIT = WTW || BIPED;
     float *ts = B.task_state ? B.task_state + (size_t)e * HOT(task_state_width) : nullptr;
     float gait_time = 0.f, phi = 0.f, gait_period = 1.f, bh_tgt = 0.f, fc_tgt = 0.f, pitch_tgt = 0.f, theta = 0.f, expC = 0.f;
     if (WTW) {
@@ -1244,7 +1291,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         rs.draw3(slot, u0, u1, u2);
         cmd0 = (CR(1) - CR(0)) * u0 + CR(0);
         cmd1 = (CR(3) - CR(2)) * u1 + CR(2);
-        if (HOT(heading_command)) cmd3 = (CR(7) - CR(6)) * u2 + CR(6);
+        if (hc_heading_command) cmd3 = (CR(7) - CR(6)) * u2 + CR(6);
         else cmd2 = (CR(5) - CR(4)) * u2 + CR(4);
         const float keep = sqrtf(cmd0 * cmd0 + cmd1 * cmd1 + cmd2 * cmd2) > 0.2f ? 1.f : 0.f;
         cmd0 *= keep; cmd1 *= keep; cmd2 *= keep;
@@ -1253,8 +1300,8 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     if (DO_POST) {
         ep_len += 1;                                                   // legged_robot.py:60
         // ---- _post_physics_step_callback (legged_robot.py:300-315) ----
-        if (ep_len % HOT(resample_steps) == 0) resample_commands(HOT(slots.cb_cmd));
-        if (HOT(heading_command)) {
+        if (ep_len % hc_resample_steps == 0) resample_commands(HOT(slots.cb_cmd));
+        if (hc_heading_command) {
             // forward = quat_apply(base_quat, [1,0,0]) (math_utils.py:34-40)
             const V3 xyz = v3(qx, qy, qz), bvec = v3(1.f, 0.f, 0.f);
             const V3 t = cross(xyz, bvec) * 2.f;
@@ -1262,8 +1309,8 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             const float heading = atan2f(fwd.y, fwd.x);
             cmd2 = clampf(0.5f * wrap_to_pi(cmd3 - heading), HOT(yaw_clip[0]), HOT(yaw_clip[1]));
         }
-        if (HOT(push_interval) > 0 && (p.counter % HOT(push_interval)) == 0) {   // genesis_simulator.py:150-158
-            const float m = HOT(max_push_vel_xy);
+        if (hc_push_interval > 0 && (p.counter % hc_push_interval) == 0) {   // genesis_simulator.py:150-158
+            const float m = hc_max_push_vel_xy;
             const float px = (m + m) * rs.draw(HOT(slots.push)) - m, py = (m + m) * rs.draw(HOT(slots.push) + 1) - m;
             vw.x += px; vw.y += py;
             if (lead) {
@@ -1271,7 +1318,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 B.base_lin_vel_w[3 * e] = vw.x; B.base_lin_vel_w[3 * e + 1] = vw.y;
             }
         }
-        if (WTW && HOT(behavior_resample_steps) > 0 && ep_len % HOT(behavior_resample_steps) == 0)   // go2_wtw.py:258-263
+        if (WTW && hc_behavior_resample_steps > 0 && ep_len % hc_behavior_resample_steps == 0)   // go2_wtw.py:258-263
             resample_behavior(HOT(slots.task_cb));
 #ifdef LG_DBG_RET_CALLBACK
         if (p.counter >= 0) { if (lead) B.rew_buf[e] = cmd2 + (float)ep_len; return; }
@@ -1285,10 +1332,10 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             if ((M->term_link_mask >> (l0 + k)) & 1u) fail |= norm(f_link[k]) > 10.0f ? 1 : 0;
         fail = quad_or<LEGS>(fail);
         if (M->term_link_mask & 1u) fail |= norm(f_base) > 10.0f ? 1 : 0;
-        fail |= pg.z > HOT(max_projected_gravity) ? 1 : 0;
+        fail |= pg.z > hc_max_projected_gravity ? 1 : 0;
         fail_buf += fail;
-        time_out = (float)ep_len > HOT(max_episode_length);
-        reset = ((float)fail_buf > HOT(fail_threshold)) || time_out;
+        time_out = (float)ep_len > hc_max_episode_length;
+        reset = ((float)fail_buf > hc_fail_threshold) || time_out;
 
 #ifdef LG_DBG_RET_TERM
         if (p.counter >= 0) { if (lead) B.rew_buf[e] = cmd2 + (float)fail_buf + (reset ? 1.f : 0.f); return; }
@@ -1332,7 +1379,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         if (RON(LG_R_ANG_VEL_XY)) add(LG_R_ANG_VEL_XY, bav.x * bav.x + bav.y * bav.y);   // :462-464
         if (RON(LG_R_BASE_HEIGHT)) {                              // :470-476
             // plane: measured_heights is the all-zero buffer of genesis_simulator.py:494 -> base z
-            const float d = (P > 0 ? mean_height : pos.z) - HOT(base_height_target);
+            const float d = (P > 0 ? mean_height : pos.z) - hc_base_height_target;
             add(LG_R_BASE_HEIGHT, d * d);
         }
         if (RON(LG_R_BIPED_PERIODIC_GAIT)) add(LG_R_BIPED_PERIODIC_GAIT, gait_reward());  // tron1_pf_ee.py:426-433
@@ -1396,7 +1443,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             last_contact = contact;
             const float first = (air > 0.f ? 1.f : 0.f) * (float)filt;
             air += cdt;
-            float r = quad_sum<LEGS>((air - HOT(feet_air_time_threshold)) * first);
+            float r = quad_sum<LEGS>((air - hc_feet_air_time_threshold) * first);
             r *= cmd_xy > 0.1f ? 1.f : 0.f;
             air *= filt ? 0.f : 1.f;
             add(LG_R_FEET_AIR_TIME, r);
@@ -1418,14 +1465,14 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         if (RON(LG_R_FOOT_CLEARANCE)) {                           // :575-588
             const float vxy = sqrtf(foot_v.x * foot_v.x + foot_v.y * foot_v.y);
             // go2_ee.py:136-150 measures the clearance above the mean terrain height around the foot
-            const float d = foot_p.z - (HOT(obs_layout) == LG_OBS_GO2_EE ? foot_hmean : (HOT(obs_layout) == LG_OBS_TRON1_EE ? foot_hmax : 0.f))
-                            - HOT(foot_clearance_target) - HOT(foot_height_offset);   // tron1_pf_ee.py:442-456 uses the max
+            const float d = foot_p.z - (hc_obs_layout == LG_OBS_GO2_EE ? foot_hmean : (hc_obs_layout == LG_OBS_TRON1_EE ? foot_hmax : 0.f))
+                            - hc_foot_clearance_target - hc_foot_height_offset;   // tron1_pf_ee.py:442-456 uses the max
             const float err = quad_sum<LEGS>(vxy * (d * d));
-            add(LG_R_FOOT_CLEARANCE, __expf(-err / HOT(foot_clearance_sigma)));
+            add(LG_R_FOOT_CLEARANCE, __expf(-err / hc_foot_clearance_sigma));
         }
         if (RON(LG_R_FOOT_LANDING_VEL)) {                         // :590-599
             const bool c01 = f_link[3].z > 0.1f;
-            const bool land = ((foot_p.z - HOT(foot_height_offset)) < HOT(about_landing_threshold)) && !c01 && (foot_v.z < 0.f);
+            const bool land = ((foot_p.z - hc_foot_height_offset) < hc_about_landing_threshold) && !c01 && (foot_v.z < 0.f);
             const float vz = land ? foot_v.z : 0.f;
             add(LG_R_FOOT_LANDING_VEL, quad_sum<LEGS>(vz * vz));
         }
@@ -1442,21 +1489,21 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         }
         if (RON(LG_R_TRACKING_ANG_VEL)) {                         // :539-543
             const float d = cmd2 - bav.z;
-            add(LG_R_TRACKING_ANG_VEL, __expf(-(d * d) / HOT(tracking_sigma)));
+            add(LG_R_TRACKING_ANG_VEL, __expf(-(d * d) / hc_tracking_sigma));
         }
         if (RON(LG_R_TRACKING_BASE_HEIGHT)) {                     // go2_wtw.py:495-500 (plane: heights are zero)
             // wtw: per-env target on the plane; tron1_pf_ee.py:435-440: fixed target, mean over the height samples
-            const float d = WTW ? pos.z - bh_tgt : (P > 0 ? mean_height : pos.z) - HOT(base_height_target);
+            const float d = WTW ? pos.z - bh_tgt : (P > 0 ? mean_height : pos.z) - hc_base_height_target;
             add(LG_R_TRACKING_BASE_HEIGHT, __expf(-(d * d) / HOT(base_height_sigma)));
         }
         if (RON(LG_R_TRACKING_FOOT_CLEARANCE)) {                  // go2_wtw.py:507-519
             const float vxy = sqrtf(foot_v.x * foot_v.x + foot_v.y * foot_v.y);
-            const float d = foot_p.z - fc_tgt - HOT(foot_height_offset);
-            add(LG_R_TRACKING_FOOT_CLEARANCE, __expf(-quad_sum<LEGS>(vxy * (d * d)) / HOT(foot_clearance_sigma)));
+            const float d = foot_p.z - fc_tgt - hc_foot_height_offset;
+            add(LG_R_TRACKING_FOOT_CLEARANCE, __expf(-quad_sum<LEGS>(vxy * (d * d)) / hc_foot_clearance_sigma));
         }
         if (RON(LG_R_TRACKING_LIN_VEL)) {                         // :533-537
             const float dx = cmd0 - blv.x, dy = cmd1 - blv.y;
-            add(LG_R_TRACKING_LIN_VEL, __expf(-(dx * dx + dy * dy) / HOT(tracking_sigma)));
+            add(LG_R_TRACKING_LIN_VEL, __expf(-(dx * dx + dy * dy) / hc_tracking_sigma));
         }
         if (RON(LG_R_TRACKING_ORIENTATION)) {                     // go2_wtw.py:502-505
             const float dp = eul.y - pitch_tgt;
@@ -1466,7 +1513,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         if (p.counter >= 0) { if (lead) B.rew_buf[e] = total + es[0] + es[5] + es[28]; return; }
 #endif
         STAMP(7);
-        if (HOT(only_positive_rewards)) total = fmaxf(total, 0.f);        // :161-162
+        if (hc_only_positive_rewards) total = fmaxf(total, 0.f);        // :161-162
         if (RON(LG_R_TERMINATION)) add(LG_R_TERMINATION, (reset && !time_out) ? 1.f : 0.f);  // :163-168
         if (GAIT) {  // gait clock (go2_wtw.py:29-36, tron1_pf_ee.py:28-35).  The reference additionally restarts env 0's clock whenever
                      // ANY env wraps (index-flatten bug); that grid-wide coupling is deliberately not reproduced.
@@ -1486,14 +1533,14 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         V3 pos_origin_override = v3(0, 0, 0);
         bool have_origin = false;
         if (reset) {
-            if (HOT(terrain_curriculum) && p.counter > 0) {
+            if (hc_terrain_curriculum && p.counter > 0) {
                 // legged_robot.py:254-272 + genesis_simulator.py:140-148 (skipped on the construction-time reset,
                 // where the reference returns early because init_done is False)
                 const V3 org = origin_pre;
                 const float dx = pos.x - org.x, dy = pos.y - org.y;
                 const float dist = sqrtf(dx * dx + dy * dy);
                 const bool up = dist > HOT(terrain_env_length) / 2.f;
-                const bool down = (dist < sqrtf(cmd0 * cmd0 + cmd1 * cmd1) * HOT(episode_length_s) * 0.5f) && !up;
+                const bool down = (dist < sqrtf(cmd0 * cmd0 + cmd1 * cmd1) * hc_episode_length_s * 0.5f) && !up;
                 int lvl = B.terrain_levels[e] + (up ? 1 : 0) - (down ? 1 : 0);
                 if (lvl >= HOT(max_terrain_level)) lvl = min((int)floorf(rs.draw(HOT(slots.terrain_level)) * (float)HOT(max_terrain_level)), HOT(max_terrain_level) - 1);
                 else lvl = max(lvl, 0);
@@ -1505,11 +1552,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             resample_commands(HOT(slots.reset_cmd));
             // tron1_pf_ee.py:204-210: ONE coin per reset_idx call sends the whole batch to the sit pose (quirk 11)
             bool sit = false;
-            if (HOT(sit_percent) > 0.f) {
+            if (hc_sit_percent > 0.f) {
                 float us;
                 if (rs.in) us = rs.in[HOT(slots.task_reset)];
                 else { RandSrc g = rs; g.e_lo = 0xFFFFFFFFu; g.e_hi = 0xFFFFFFFFu; us = g.draw(HOT(slots.task_reset)); }
-                sit = us < HOT(sit_percent);
+                sit = us < hc_sit_percent;
             }
             // _reset_dofs (go2.py:17-37): default + U(range) per joint, zero velocity
             float ud[3];
@@ -1524,7 +1571,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             }
             // _reset_root_states (go2.py:119-134)
             pos = (sit ? ld3(T->sit_pos) : v3(HOT(o_base_init_pos[0]), HOT(o_base_init_pos[1]), HOT(o_base_init_pos[2]))) + (have_origin ? pos_origin_override : origin_pre);
-            if (HOT(custom_origins)) {
+            if (hc_custom_origins) {
                 pos.x += HOT(reset_root_xy_span) * rs.draw(HOT(slots.reset_root_xy)) + HOT(reset_root_xy_lo);
                 pos.y += HOT(reset_root_xy_span) * rs.draw(HOT(slots.reset_root_xy) + 1) + HOT(reset_root_xy_lo);
             }
@@ -1613,11 +1660,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         // ---- compute_observations + clip (legged_robot.py:48-49).  Layouts: go2.py:40-64 (45),
         //      go2_wtw.py:53-111 (61x5 | 99x5), go2_ee.py:10-75 (45x20 | 174x5 | 24 labels).  Histories are
         //      kept oldest -> newest inside obs_buf / priv_obs_buf themselves and shifted in place.
-        const int FR = HOT(obs_frame), PF = HOT(priv_frame), ST = HOT(obs_stack), PST = HOT(priv_stack);
-        const int SL = HOT(obs_slack);
-        float *o = B.obs_buf + (size_t)e * (HOT(num_obs) + SL * FR) + (size_t)p.obs_win * FR;
-        float *pv = HOT(num_priv_obs) > 0 ? B.priv_obs_buf + (size_t)e * (HOT(num_priv_obs) + SL * PF) + (size_t)p.obs_win * PF : nullptr;
-        const float co = HOT(clip_obs);
+        const int FR = hc_obs_frame, PF = hc_priv_frame, ST = hc_obs_stack, PST = hc_priv_stack;
+        const int SL = hc_obs_slack;
+        float *o = B.obs_buf + (size_t)e * (hc_num_obs + SL * FR) + (size_t)p.obs_win * FR;
+        float *pv = hc_num_priv_obs > 0 ? B.priv_obs_buf + (size_t)e * (hc_num_priv_obs + SL * PF) + (size_t)p.obs_win * PF : nullptr;
+        const float co = hc_clip_obs;
         if (live && SL > 0) {
             // sliding window: the previous frames are already where this window expects them; only an env that was just
             // reset blanks its history (go2_wtw.py:174-178)
@@ -1633,7 +1680,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     for (int i = leg; i < PF; i += LEGS) pv[f * PF + i] = reset ? 0.f : pv[(f + 1) * PF + i];
         }
         float *on = o + (ST - 1) * FR, *pn = pv ? pv + (PST - 1) * PF : nullptr;
-        const bool nz = HOT(add_noise) != 0;
+        const bool nz = hc_add_noise != 0;
         const int ns = HOT(slots.noise);
         // uniforms for the noisy entries only (commands and actions carry zero noise scale): q, qd per lane,
         // gravity + ang vel on the lead lane
@@ -1667,7 +1714,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             }
         }
         float uact[3] = {0.5f, 0.5f, 0.5f}, uclk[2] = {0.5f, 0.5f};
-        if (nz && HOT(noise_act0) != 0.f) {  // uniform index: scalar load   // tron1_pf_ee.py:338-342 (quirk 4): actions and clock are noisy too
+        if (nz && hc_noise_act0 != 0.f) {  // uniform index: scalar load   // tron1_pf_ee.py:338-342 (quirk 4): actions and clock are noisy too
             if (rs.in) {
 #pragma unroll
                 for (int j = 0; j < 3; j++) uact[j] = rs.in[ns + 9 + 2 * A + d0 + j];
@@ -1687,17 +1734,17 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         if (live) {
 #pragma unroll
             for (int j = 0; j < 3; j++) {
-                put(9 + d0 + j, (q[j] - q0l[j]) * HOT(obs_scale_dof_pos), uq[j], nv_q[j]);
-                put(9 + A + d0 + j, qd[j] * HOT(obs_scale_dof_vel), uqd[j], nv_qd[j]);
+                put(9 + d0 + j, (q[j] - q0l[j]) * hc_obs_scale_dof_pos, uq[j], nv_q[j]);
+                put(9 + A + d0 + j, qd[j] * hc_obs_scale_dof_vel, uqd[j], nv_qd[j]);
                 put(9 + 2 * A + d0 + j, act[j], uact[j], nv_act[j]);
             }
         }
         if (lead) {
-            put(0, cmd0 * HOT(obs_scale_lin_vel), 0.5f, 0.f); put(1, cmd1 * HOT(obs_scale_lin_vel), 0.5f, 0.f); put(2, cmd2 * HOT(obs_scale_ang_vel), 0.5f, 0.f);
+            put(0, cmd0 * hc_obs_scale_lin_vel, 0.5f, 0.f); put(1, cmd1 * hc_obs_scale_lin_vel, 0.5f, 0.f); put(2, cmd2 * hc_obs_scale_ang_vel, 0.5f, 0.f);
             put(3, pg.x, ub[0], HOT(noise_lead[0])); put(4, pg.y, ub[1], HOT(noise_lead[1])); put(5, pg.z, ub[2], HOT(noise_lead[2]));
-            put(6, bav.x * HOT(obs_scale_ang_vel), ub[3], HOT(noise_lead[3])); put(7, bav.y * HOT(obs_scale_ang_vel), ub[4], HOT(noise_lead[4])); put(8, bav.z * HOT(obs_scale_ang_vel), ub[5], HOT(noise_lead[5]));
+            put(6, bav.x * hc_obs_scale_ang_vel, ub[3], HOT(noise_lead[3])); put(7, bav.y * hc_obs_scale_ang_vel, ub[4], HOT(noise_lead[4])); put(8, bav.z * hc_obs_scale_ang_vel, ub[5], HOT(noise_lead[5]));
         }
-        if (HOT(obs_layout) == LG_OBS_GO2_WTW) {
+        if (hc_obs_layout == LG_OBS_GO2_WTW) {
             const float ang = 6.283185307179586f * (phi + theta);      // clock inputs (go2_wtw.py:251-256)
             if (live) {
                 const float sn = sinf(ang), cs = cosf(ang);
@@ -1714,16 +1761,16 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             }
             if (lead) {
                 put(53, gait_period, 0.5f, 0.f); put(54, bh_tgt, 0.5f, 0.f); put(55, fc_tgt, 0.5f, 0.f); put(56, pitch_tgt, 0.5f, 0.f);
-                putp(FR + 0, blv.x * HOT(obs_scale_lin_vel)); putp(FR + 1, blv.y * HOT(obs_scale_lin_vel)); putp(FR + 2, blv.z * HOT(obs_scale_lin_vel));
+                putp(FR + 0, blv.x * hc_obs_scale_lin_vel); putp(FR + 1, blv.y * hc_obs_scale_lin_vel); putp(FR + 2, blv.z * hc_obs_scale_lin_vel);
                 putp(FR + 3, B.rand_push_vels[3 * e]); putp(FR + 4, B.rand_push_vels[3 * e + 1]);
                 putp(FR + 5, B.added_base_mass[e]); putp(FR + 6, B.friction_values[e]);
                 putp(FR + 7, B.base_com_bias[3 * e]); putp(FR + 8, B.base_com_bias[3 * e + 1]); putp(FR + 9, B.base_com_bias[3 * e + 2]);
             }
-        } else if (HOT(obs_layout) == LG_OBS_GO2_EE) {
+        } else if (hc_obs_layout == LG_OBS_GO2_EE) {
             // critic frame (go2_ee.py:21-48): obs 45 | DR 31 | contact states K | heights P
             const int K = __popc(M->state_link_mask);
             const int l0 = foot_link - 3;
-            float *lab = B.labels_buf + (size_t)e * HOT(num_labels);
+            float *lab = B.labels_buf + (size_t)e * hc_num_labels;
             if (live) {
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
@@ -1742,26 +1789,26 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     }
                 }
                 for (int k = leg; k < P; k += LEGS) {
-                    float hv = pos.z - HOT(heights_offset) - B.measured_heights[(size_t)e * P + k];
-                    if (HOT(heights_clip_scale)) hv = clampf(hv, -1.f, 1.f) * HOT(obs_scale_height);
+                    float hv = pos.z - hc_heights_offset - B.measured_heights[(size_t)e * P + k];
+                    if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
                     putp(FR + 7 + 2 * A + K + k, hv);
                 }
                 // labels (go2_ee.py:69-75): v_b 3 | contact states K | foot height above the local terrain mean F
-                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmean - HOT(foot_height_offset), -1.f, 1.f);
+                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmean - hc_foot_height_offset, -1.f, 1.f);
             }
             if (lead) {
                 putp(FR + 0, B.friction_values[e] - HOT(friction_offset)); putp(FR + 1, B.added_base_mass[e]);
                 putp(FR + 2, B.base_com_bias[3 * e]); putp(FR + 3, B.base_com_bias[3 * e + 1]); putp(FR + 4, B.base_com_bias[3 * e + 2]);
                 putp(FR + 5, B.rand_push_vels[3 * e]); putp(FR + 6, B.rand_push_vels[3 * e + 1]);
                 if (M->state_link_mask & 1u) { const float cs = norm(f_base) > 1.f ? 1.f : 0.f; putp(FR + 7 + 2 * A, cs); lab[3] = cs; }
-                lab[0] = blv.x * HOT(obs_scale_lin_vel); lab[1] = blv.y * HOT(obs_scale_lin_vel); lab[2] = blv.z * HOT(obs_scale_lin_vel);
+                lab[0] = blv.x * hc_obs_scale_lin_vel; lab[1] = blv.y * hc_obs_scale_lin_vel; lab[2] = blv.z * hc_obs_scale_lin_vel;
             }
-        } else if (HOT(obs_layout) == LG_OBS_TRON1_EE) {
+        } else if (hc_obs_layout == LG_OBS_TRON1_EE) {
             // tron1_pf_ee.py:53-141.  actor frame: 9 + 3A + clock 2F.  critic frame: frame | DR (7 + 2A + 3) |
             // gait F | contact states K | heights P | normals 3F | clip(foot_z - h9) 9F.  labels: v_b 3 | K | F | 3F
             const int K = __popc(M->state_link_mask);
             const int l0 = foot_link - 3;
-            float *lab = B.labels_buf + (size_t)e * HOT(num_labels);
+            float *lab = B.labels_buf + (size_t)e * hc_num_labels;
             const float ang = 6.283185307179586f * (phi + theta);
             const int oDR = FR, oG = FR + 7 + 2 * A + 3, oK = oG + F, oH = oK + K, oN = oH + P, oR = oN + 3 * F;
             if (live) {
@@ -1786,8 +1833,8 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     }
                 }
                 for (int k = leg; k < P; k += LEGS) {
-                    float hv = pos.z - HOT(heights_offset) - B.measured_heights[(size_t)e * P + k];
-                    if (HOT(heights_clip_scale)) hv = clampf(hv, -1.f, 1.f) * HOT(obs_scale_height);
+                    float hv = pos.z - hc_heights_offset - B.measured_heights[(size_t)e * P + k];
+                    if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
                     putp(oH + k, hv);
                 }
                 const float *nv3 = B.normal_vector_around_feet + ((size_t)e * F + foot_slot) * 3;
@@ -1796,7 +1843,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
 #pragma unroll
                 for (int k = 0; k < 9; k++)
                     putp(oR + 9 * foot_slot + k, clampf(foot_p.z - B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k], -1.f, 1.f));
-                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmax - HOT(foot_height_offset), -1.f, 1.f);
+                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmax - hc_foot_height_offset, -1.f, 1.f);
             }
             if (lead) {
                 putp(oDR + 0, B.friction_values[e] - HOT(friction_offset)); putp(oDR + 1, B.added_base_mass[e]);
@@ -1806,7 +1853,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 putp(oDR + 8 + 2 * A, B.joint_friction ? B.joint_friction[e] : 0.f);
                 putp(oDR + 9 + 2 * A, B.joint_damping ? B.joint_damping[e] : 0.f);
                 if (M->state_link_mask & 1u) { const float cst = norm(f_base) > 1.f ? 1.f : 0.f; putp(oK, cst); lab[3] = cst; }
-                lab[0] = blv.x * HOT(obs_scale_lin_vel); lab[1] = blv.y * HOT(obs_scale_lin_vel); lab[2] = blv.z * HOT(obs_scale_lin_vel);
+                lab[0] = blv.x * hc_obs_scale_lin_vel; lab[1] = blv.y * hc_obs_scale_lin_vel; lab[2] = blv.z * hc_obs_scale_lin_vel;
             }
         }
     }
@@ -1815,10 +1862,10 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     }
     if (BIPED && lead) { ts[0] = gait_time; ts[1] = phi; ts[2] = gait_period; }
     if (BIPED && live && !DO_RESET) { ts[4 + foot_slot] = theta; ts[10 + foot_slot] = expC; }
-    if (WTW && live && !(DO_RESET && HOT(obs_layout) == LG_OBS_GO2_WTW)) { ts[6 + foot_slot] = theta; ts[18 + foot_slot] = expC; }
+    if (WTW && live && !(DO_RESET && hc_obs_layout == LG_OBS_GO2_WTW)) { ts[6 + foot_slot] = theta; ts[18 + foot_slot] = expC; }
     // second action-history shift of the wtw / tron1_ee tasks (go2_wtw.py:45-46): afterwards
     // last == llast == a_t, which makes action_smoothness == action_rate
-    if (DO_RESET && HOT(double_shift) && live) {
+    if (DO_RESET && hc_double_shift && live) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             B.llast_actions[e * A + d0 + j] = reset ? 0.f : last_act[j];
