@@ -1286,9 +1286,10 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         if (t0 == 0.f && t1 == 0.f && ((t2 == 0.f && t3 == 0.f) || (t2 == 0.5f && t3 == 0.5f))) fc_tgt = CR(12);
     };
 
-    auto resample_commands = [&](int slot) {  // legged_robot.py:317-334
+    auto resample_commands = [&](int slot, const float *pre = nullptr) {  // legged_robot.py:317-334
         float u0, u1, u2;
-        rs.draw3(slot, u0, u1, u2);
+        if (pre) { u0 = pre[0]; u1 = pre[1]; u2 = pre[2]; }
+        else rs.draw3(slot, u0, u1, u2);
         cmd0 = (CR(1) - CR(0)) * u0 + CR(0);
         cmd1 = (CR(3) - CR(2)) * u1 + CR(2);
         if (hc_heading_command) cmd3 = (CR(7) - CR(6)) * u2 + CR(6);
@@ -1533,6 +1534,23 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         V3 pos_origin_override = v3(0, 0, 0);
         bool have_origin = false;
         if (reset) {
+            // env-level uniforms of a reset (commands, friction, mass, CoM, root twist): ONE Philox block per lane of the env,
+            // shared inside the quad, instead of one call per quantity on the lead lane (a call is ~800 cycles and the launch
+            // ends with its slowest wave, which is always one that resets).  Injected draws keep their slots.
+            float eu[16];
+            const bool bundle = LEGS == 4 && !rs.in;
+            if (bundle) {
+                float b[4];
+                rs.block4(0x200 + leg, b[0], b[1], b[2], b[3]);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int x = __float_as_int(b[k]);
+                    eu[0 + k] = __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x00, 0xF, 0xF, false));
+                    eu[4 + k] = __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x55, 0xF, 0xF, false));
+                    eu[8 + k] = __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xAA, 0xF, 0xF, false));
+                    eu[12 + k] = __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xFF, 0xF, 0xF, false));
+                }
+            }
             if (hc_terrain_curriculum && p.counter > 0) {
                 // legged_robot.py:254-272 + genesis_simulator.py:140-148 (skipped on the construction-time reset,
                 // where the reference returns early because init_done is False)
@@ -1549,7 +1567,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 pos_origin_override = norg; have_origin = true;
             }
             if (WTW) { resample_behavior(HOT(slots.task_reset)); gait_time = 0.f; phi = 0.f; }   // go2_wtw.py:124-142
-            resample_commands(HOT(slots.reset_cmd));
+            resample_commands(HOT(slots.reset_cmd), bundle ? eu : nullptr);
             // tron1_pf_ee.py:204-210: ONE coin per reset_idx call sends the whole batch to the sit pose (quirk 11)
             bool sit = false;
             if (hc_sit_percent > 0.f) {
@@ -1579,8 +1597,8 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             qz = sit ? T->sit_quat[2] : HOT(base_init_quat[2]); qw = sit ? T->sit_quat[3] : HOT(base_init_quat[3]);
             if (HOT(reset_lin_vel_span) != 0.f || HOT(reset_ang_vel_span) != 0.f || rs.in) {   // go2.py:131-133 draws U(0,0): skip
                 float a0, a1, a2, b0_, b1_, b2_;
-                rs.draw3(HOT(slots.reset_lin_vel), a0, a1, a2);
-                rs.draw3(HOT(slots.reset_ang_vel), b0_, b1_, b2_);
+                if (bundle) { a0 = eu[8]; a1 = eu[9]; a2 = eu[10]; b0_ = eu[12]; b1_ = eu[13]; b2_ = eu[14]; }
+                else { rs.draw3(HOT(slots.reset_lin_vel), a0, a1, a2); rs.draw3(HOT(slots.reset_ang_vel), b0_, b1_, b2_); }
                 vw = v3(HOT(reset_lin_vel_span) * a0 + HOT(reset_lin_vel_lo), HOT(reset_lin_vel_span) * a1 + HOT(reset_lin_vel_lo),
                         HOT(reset_lin_vel_span) * a2 + HOT(reset_lin_vel_lo));
                 ww = v3(HOT(reset_ang_vel_span) * b0_ + HOT(reset_ang_vel_lo), HOT(reset_ang_vel_span) * b1_ + HOT(reset_ang_vel_lo),
@@ -1629,11 +1647,12 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 st3(B.projected_gravity + 3 * e, pg);
                 st3(B.last_base_lin_vel + 3 * e, v3(0, 0, 0)); st3(B.last_base_ang_vel + 3 * e, v3(0, 0, 0));
                 // domain randomisation (genesis_simulator.py:62-77, 665-739)
-                if (HOT(dr_friction_on)) B.friction_values[e] = HOT(dr_friction_span) * rs.draw(HOT(slots.dr_friction)) + HOT(dr_friction_lo);
-                if (HOT(dr_mass_on)) B.added_base_mass[e] = HOT(dr_mass_span) * rs.draw(HOT(slots.dr_mass)) + HOT(dr_mass_lo);
+                if (HOT(dr_friction_on)) B.friction_values[e] = HOT(dr_friction_span) * (bundle ? eu[3] : rs.draw(HOT(slots.dr_friction))) + HOT(dr_friction_lo);
+                if (HOT(dr_mass_on)) B.added_base_mass[e] = HOT(dr_mass_span) * (bundle ? eu[7] : rs.draw(HOT(slots.dr_mass))) + HOT(dr_mass_lo);
                 if (HOT(dr_com_on)) {
                     float uc[3];
-                    rs.draw3(HOT(slots.dr_com), uc[0], uc[1], uc[2]);
+                    if (bundle) { uc[0] = eu[4]; uc[1] = eu[5]; uc[2] = eu[6]; }
+                    else rs.draw3(HOT(slots.dr_com), uc[0], uc[1], uc[2]);
 #pragma unroll
                     for (int k = 0; k < 3; k++) B.base_com_bias[3 * e + k] = HOT(dr_com_span[k]) * uc[k] + HOT(dr_com_lo[k]);
                 }
