@@ -229,6 +229,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     const LgBuffers &B = p.B;
     unsigned long long _stamp0 = 0; (void)_stamp0;
     STAMP(0);
+    STAMPB(4096);
     const int tid = blockIdx.x * BLOCK + threadIdx.x;
     Lane L;
     L.c = tid & 3; L.is0 = L.c == 0; L.is1 = L.c == 1; L.is2 = L.c == 2; L.is3 = L.c == 3;
@@ -826,6 +827,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     }
 
     STAMP(22);
+    STAMPB(8192);
     // ---------------- MDP phases in the same launch -------------------------------------------------
     if (MPH != 0) {
         // everything the MDP reads was stored above by this very wave (workgroup = one wave): a workgroup-scope fence
@@ -836,4 +838,5 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         if (threadIdx.x < 16)
             env_step_body<LEGS, MPH, true>(p, sMraw, sHot, sStF, blockIdx.x * 16 + (int)threadIdx.x, (int)threadIdx.x);
     }
+    STAMPB(12288);
 }
