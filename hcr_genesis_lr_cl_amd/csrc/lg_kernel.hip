@@ -320,8 +320,13 @@ struct KParams {
 #define STAMP(i) do { if (blockIdx.x == 0 && threadIdx.x == 0) { unsigned long long _t; \
     asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); \
     p.B.episode_done_sums[i] = (float)(_t - _stamp0); if (i == 0) _stamp0 = _t; } } while (0)
+// per-workgroup stamp (every block): slot base + blockIdx.x
+#define STAMPB(base) do { if (threadIdx.x == 0) { unsigned long long _t; \
+    asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(_t) :: "memory"); \
+    p.B.episode_done_sums[(base) + blockIdx.x] = (float)(_t & 0xFFFFFFull); } } while (0)
 #else
 #define STAMP(i) do { } while (0)
+#define STAMPB(base) do { } while (0)
 #endif
 
 LG_DEV V3 ld3(const float *p) { return v3(p[0], p[1], p[2]); }
