@@ -311,7 +311,9 @@ struct KParams {
     // kernarg copies of the few constants the start-of-kernel load burst needs for its addresses and predicates (scalar
     // loads that return before anything else): reading them from the hot block would put a full memory round trip in
     // front of the burst
-    struct { int m_n_links, m_foot_link[4], obs_layout, o_n_height_points; unsigned reward_mask; float clip_actions; } k;
+    struct { int m_n_links, m_foot_link[4], obs_layout, o_n_height_points; unsigned reward_mask; float clip_actions;
+             int joint_axis[3];   // per joint index: 0/1/2 if that joint's axis is +-e_x/e_y/e_z on every leg, else -1 (lg_quad.h joint_rot)
+    } k;
     int obs_win;         // first frame of the observation window this launch writes (sliding history, LgTaskCfg.obs_slack)
 };
 
@@ -2080,6 +2082,17 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
         for (int i = 0; i < 4; i++) p.k.m_foot_link[i] = hot.m_foot_link[i];
         p.k.obs_layout = hot.obs_layout; p.k.o_n_height_points = hot.o_n_height_points;
         p.k.reward_mask = (unsigned)hot.reward_mask; p.k.clip_actions = hot.clip_actions;
+        for (int j = 0; j < 3; j++) {
+            int code = -2;
+            for (int l = 0; l < LEGS; l++) {
+                const float *ax = h->model.axis[1 + 3 * l + j];
+                int c = -1;
+                for (int k = 0; k < 3; k++)
+                    if (fabsf(fabsf(ax[k]) - 1.f) < 1e-6f && fabsf(ax[(k + 1) % 3]) < 1e-6f && fabsf(ax[(k + 2) % 3]) < 1e-6f) c = k;
+                code = (code == -2 || code == c) ? c : -1;
+            }
+            p.k.joint_axis[j] = code;
+        }
     }
     for (int b = 1; b < h->model.n_bodies; b++)
         for (int k = 0; k < 9; k++)
@@ -2105,7 +2118,10 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
     // lane; the MDP phases then follow in a second launch on the same stream
     // auto: component-per-lane while that needs at most one wave per SIMD (1024 SIMDs); measured go2 crossover: 42 vs 58 us
     // at 4096 envs, 92 vs 60 us at 16384
-    const int layout = h->opts.sim_layout ? h->opts.sim_layout : ((long long)threads * 4 <= 1024LL * BLOCK ? 2 : 1);
+    // the component-per-lane kernel is specialised for identity joint frames and hip-x / thigh-y / knee-y axes (lg_quad.h)
+    const bool quad_ok = p.jrot_identity && p.k.joint_axis[0] == 0 && p.k.joint_axis[1] == 1 && p.k.joint_axis[2] == 1;
+    if (h->opts.sim_layout == 2 && !quad_ok) return fail("lg_step: sim_layout 2 needs identity joint frames and x / y / y joint axes");
+    const int layout = h->opts.sim_layout ? h->opts.sim_layout : ((quad_ok && (long long)threads * 4 <= 1024LL * BLOCK) ? 2 : 1);
     if (layout == 2 && (ph & LG_PHASE_SIM)) {
         dim3 qgrid((threads * 4 + BLOCK - 1) / BLOCK);
         const bool pre = (ph & LG_PHASE_PRE) != 0;

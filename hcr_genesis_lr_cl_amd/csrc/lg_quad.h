@@ -25,6 +25,8 @@
 
 namespace q4 {
 
+constexpr int QUAD_AXES[3] = {0, 1, 1};
+
 LG_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32 (1 ulp) without the denormal-range rescue of sqrtf
 
 constexpr int QP(int a, int b, int c, int d) { return a | (b << 2) | (c << 4) | (d << 6); }
@@ -161,6 +163,28 @@ LG_DEV QM quat_rows(const Lane &L, float qv) {   // qv: (x, y, z, w) across the 
     r.c1 = a * L.d1 + w2 * S.c1 + v2 * bc<1>(qv);
     r.c2 = a * L.d2 + w2 * S.c2 + v2 * bc<2>(qv);
     return r;
+}
+
+// joint axis in world axes and child rotation R = Rp * Rot(axis, angle).  Axis code AK (compile time): 0/1/2 = the joint axis
+// is +-e_x / e_y / e_z of the parent frame -- then the axis is a (signed) column of Rp and the product only mixes the other
+// two columns, 5 instructions instead of 30; -1 = general axis (Rodrigues + 3x3 product).  This kernel is built for the
+// hip-x / thigh-y / knee-y chains of both robots in scope (QUAD_AXES); lg_step checks the model and falls back to the
+// leg-per-lane kernel, which takes any axes and joint frames, otherwise.
+// `ax`: the axis, this lane's component; `cq`, `sq`: cos / sin of the joint angle, replicated.
+template <int AK> LG_DEV void joint_rot(const Lane &L, const QM &Rp, float ax, float cq, float sq, QM &R, float &s) {
+    if (AK == 0) { const float g = bc<0>(ax), sg = sq * g; s = Rp.c0 * g; R.c0 = Rp.c0; R.c1 = cq * Rp.c1 + sg * Rp.c2; R.c2 = cq * Rp.c2 - sg * Rp.c1; }
+    else if (AK == 1) { const float g = bc<1>(ax), sg = sq * g; s = Rp.c1 * g; R.c1 = Rp.c1; R.c0 = cq * Rp.c0 - sg * Rp.c2; R.c2 = cq * Rp.c2 + sg * Rp.c0; }
+    else if (AK == 2) { const float g = bc<2>(ax), sg = sq * g; s = Rp.c2 * g; R.c2 = Rp.c2; R.c0 = cq * Rp.c0 + sg * Rp.c1; R.c1 = cq * Rp.c1 - sg * Rp.c0; }
+    else {
+        s = mulv(Rp, ax);
+        const QM K1 = skew(L, ax);
+        const float tq = 1.f - cq, a0 = tq * ax;
+        QM Rl;   // Rodrigues: c I + s [ax]x + (1 - c) ax ax^T
+        Rl.c0 = cq * L.d0 + sq * K1.c0 + a0 * bc<0>(ax);
+        Rl.c1 = cq * L.d1 + sq * K1.c1 + a0 * bc<1>(ax);
+        Rl.c2 = cq * L.d2 + sq * K1.c2 + a0 * bc<2>(ax);
+        R = mulmm(Rp, Rl);
+    }
 }
 
 struct QJoint { QV6 S, U, c; float dinv, u; };
@@ -355,14 +379,12 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     };
     const QM I0 = sym_row(M->inertia[0]);
     float Lm[3], Lcom[3], Ljpos[3], Lax[3];
-    QM LIc[3], LK1[3], LK2[3];
+    QM LIc[3];
 #pragma unroll
     for (int j = 0; j < 3; j++) {
         const int b = b0 + j;
         Lm[j] = M->mass[b]; Lcom[j] = M->com[b][cj]; Ljpos[j] = M->jpos[b][cj]; Lax[j] = M->axis[b][cj];
         LIc[j] = sym_row(M->inertia[b]);
-        LK1[j] = skew(L, Lax[j]);
-        LK2[j].c0 = Lax[j] * bc<0>(Lax[j]); LK2[j].c1 = Lax[j] * bc<1>(Lax[j]); LK2[j].c2 = Lax[j] * bc<2>(Lax[j]);
     }
     // joint-lane constants
     const float Lqlo = M->q_lo[d0 + cj], Lqhi = M->q_hi[d0 + cj], Leff = M->effort[d0 + cj];
@@ -371,7 +393,6 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     const float arm = B.joint_armature ? dr_arm : M->armature[d0 + cj];
     const float jfric = B.joint_friction ? dr_jf : M->frictionloss[d0 + cj];
     const float jdamp = B.joint_damping ? dr_jd : M->damping[d0 + cj];
-    const bool jrot_identity = p.jrot_identity != 0;
     const int fs = leg == 0 ? HOT(m_foot_sphere[0]) : (leg == 1 ? HOT(m_foot_sphere[1]) : (leg == 2 ? HOT(m_foot_sphere[2]) : HOT(m_foot_sphere[3])));
     const float foot_c_loc = M->sph_pos[fs][cj], foot_r = M->sph_r[fs];
 
@@ -425,21 +446,12 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
 #pragma unroll
             for (int j = 0; j < 3; j++) {
                 K[j].P = Pp + mulv(Rp, Ljpos[j]);
-                QM Rfix = Rp;
-                if (!jrot_identity) {
-                    const float *jr = M->jrot[b0 + j] + 3 * cj;
-                    const QM jrr = {jr[0], jr[1], jr[2]};
-                    Rfix = mulmm(Rp, jrr);
-                }
-                const float s = mulv(Rfix, Lax[j]);
                 const float cq = j == 0 ? bc<0>(cv) : (j == 1 ? bc<1>(cv) : bc<2>(cv));
                 const float sq = j == 0 ? bc<0>(sv) : (j == 1 ? bc<1>(sv) : bc<2>(sv));
-                const float tq = 1.f - cq;
-                QM Rl;   // Rodrigues: c I + s [ax]x + (1 - c) ax ax^T
-                Rl.c0 = cq * L.d0 + sq * LK1[j].c0 + tq * LK2[j].c0;
-                Rl.c1 = cq * L.d1 + sq * LK1[j].c1 + tq * LK2[j].c1;
-                Rl.c2 = cq * L.d2 + sq * LK1[j].c2 + tq * LK2[j].c2;
-                K[j].R = mulmm(Rfix, Rl);
+                float s;
+                if (j == 0) joint_rot<QUAD_AXES[0]>(L, Rp, Lax[j], cq, sq, K[j].R, s);
+                else if (j == 1) joint_rot<QUAD_AXES[1]>(L, Rp, Lax[j], cq, sq, K[j].R, s);
+                else joint_rot<QUAD_AXES[2]>(L, Rp, Lax[j], cq, sq, K[j].R, s);
                 J[j].S.a = s;
                 J[j].S.l = cross(K[j].P, s);
                 const float qdj = j == 0 ? bc<0>(qd) : (j == 1 ? bc<1>(qd) : bc<2>(qd));
@@ -740,24 +752,17 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
             const float P = Pp + mulv(Rp, Ljpos[j]);
-            QM Rfix = Rp;
-            if (!jrot_identity) {
-                const float *jr = M->jrot[b0 + j] + 3 * cj;
-                const QM jrr = {jr[0], jr[1], jr[2]};
-                Rfix = mulmm(Rp, jrr);
-            }
-            const float s = mulv(Rfix, Lax[j]);
             const float cq = j == 0 ? bc<0>(cv) : (j == 1 ? bc<1>(cv) : bc<2>(cv));
             const float sq = j == 0 ? bc<0>(sv) : (j == 1 ? bc<1>(sv) : bc<2>(sv));
             const float qdj = j == 0 ? bc<0>(qd) : (j == 1 ? bc<1>(qd) : bc<2>(qd));
-            const float tq = 1.f - cq;
-            QM Rl;
-            Rl.c0 = cq * L.d0 + sq * LK1[j].c0 + tq * LK2[j].c0;
-            Rl.c1 = cq * L.d1 + sq * LK1[j].c1 + tq * LK2[j].c1;
-            Rl.c2 = cq * L.d2 + sq * LK1[j].c2 + tq * LK2[j].c2;
+            float s;
+            QM Rn;
+            if (j == 0) joint_rot<QUAD_AXES[0]>(L, Rp, Lax[j], cq, sq, Rn, s);
+            else if (j == 1) joint_rot<QUAD_AXES[1]>(L, Rp, Lax[j], cq, sq, Rn, s);
+            else joint_rot<QUAD_AXES[2]>(L, Rp, Lax[j], cq, sq, Rn, s);
             Vp.a = Vp.a + s * qdj;
             Vp.l = Vp.l + cross(P, s) * qdj;
-            Rp = mulmm(Rfix, Rl);
+            Rp = Rn;
             Pp = P;
         }
         const float r = Pp + mulv(Rp, M->link_pos[foot_link][cj]);
