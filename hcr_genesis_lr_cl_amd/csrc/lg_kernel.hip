@@ -605,9 +605,17 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     V3 f_link[4];                    // net contact force on this leg's hip, thigh, calf, foot (world)
     V3 f_base = v3(0, 0, 0);         // net contact force on the base (whole env)
     V3 foot_p, foot_v, last_foot_v = v3(0, 0, 0);
+    // this lane's share of the sampled terrain heights (k = leg + i * LEGS), kept in registers from the moment they are
+    // sampled / loaded until the observation is written: one batch of independent loads instead of a dependent
+    // load -> store chain per entry in each consumer
+    constexpr int HMAX = 26;
+    float hts[HMAX];
+#pragma unroll
+    for (int i = 0; i < HMAX; i++) hts[i] = 0.f;
+    const int P = p.k.o_n_height_points;
+    const bool hreg = P <= HMAX * LEGS;
     float foot_hmean = 0.f, foot_hmax = 0.f;  // mean / max of the 9 terrain heights around this lane's foot (a8)
     float mean_height = 0.f;         // mean over the height-sample grid of (base_z - h) is formed from this (a7)
-    const int P = p.k.o_n_height_points;
 
     // compiler-level memory barrier: every load above is issued before anything below (LLVM otherwise sinks each one
     // next to its consumer, where its full round trip is exposed); no hardware wait is emitted here
@@ -1110,14 +1118,30 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             const float yn = rcp(fmaxf(sqrtf(qz * qz + qw * qw), 1e-9f));
             const float yz = qz * yn, yw = qw * yn;
             float acc = 0.f;
-            for (int k = leg; k < P; k += LEGS) {
+            auto sample_k = [&](int k) {
                 const float vx = B.height_points[2 * k], vy = B.height_points[2 * k + 1];
                 // quat_apply with xyz = (0, 0, yz): t = 2 xyz x v; r = v + w t + xyz x t
                 const float tx = -2.f * yz * vy, ty = 2.f * yz * vx;
                 const float rx = vx + yw * tx - yz * ty, ry = vy + yw * ty + yz * tx;
-                const float h = sample_min3(O, p.hf, rx + pos.x, ry + pos.y);
-                acc += pos.z - h;
-                if (live) B.measured_heights[(size_t)e * P + k] = h;
+                return sample_min3(O, p.hf, rx + pos.x, ry + pos.y);
+            };
+            if (hreg) {
+#pragma unroll
+                for (int i = 0; i < HMAX; i++) {
+                    const int k = leg + i * LEGS;
+                    if (k < P) {
+                        const float h = sample_k(k);
+                        hts[i] = h;
+                        acc += pos.z - h;
+                        if (live) B.measured_heights[(size_t)e * P + k] = h;
+                    }
+                }
+            } else {
+                for (int k = leg; k < P; k += LEGS) {
+                    const float h = sample_k(k);
+                    acc += pos.z - h;
+                    if (live) B.measured_heights[(size_t)e * P + k] = h;
+                }
             }
             mean_height = quad_sum<LEGS>(acc) / (float)P;
             if (HOT(o_feet_terrain_info)) {
@@ -1171,7 +1195,15 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         for (int j = 0; j < 3; j++) { last_qd[j] = B.last_dof_vel[e * A + d0 + j]; torque[j] = B.torques[e * A + d0 + j]; }
         if (P > 0) {
             float acc = 0.f;
-            for (int k = leg; k < P; k += LEGS) acc += pos.z - B.measured_heights[(size_t)e * P + k];
+            if (hreg) {
+                const float *__restrict__ mh = B.measured_heights + (size_t)e * P;
+#pragma unroll
+                for (int i = 0; i < HMAX; i++) hts[i] = mh[min(leg + i * LEGS, P - 1)];      // independent loads, clamped index
+#pragma unroll
+                for (int i = 0; i < HMAX; i++) acc += (leg + i * LEGS < P) ? pos.z - hts[i] : 0.f;
+            } else {
+                for (int k = leg; k < P; k += LEGS) acc += pos.z - B.measured_heights[(size_t)e * P + k];
+            }
             mean_height = quad_sum<LEGS>(acc) / (float)P;
             if (HOT(o_feet_terrain_info)) {
                 float sum = 0.f, mx = -1e30f;
@@ -1814,10 +1846,20 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                         lab[3 + idx] = cs;
                     }
                 }
-                for (int k = leg; k < P; k += LEGS) {
-                    float hv = pos.z - hc_heights_offset - B.measured_heights[(size_t)e * P + k];
-                    if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
-                    putp(FR + 7 + 2 * A + K + k, hv);
+                if (hreg) {
+#pragma unroll
+                    for (int i = 0; i < HMAX; i++) {
+                        const int k = leg + i * LEGS;
+                        float hv = pos.z - hc_heights_offset - hts[i];
+                        if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
+                        if (k < P) putp(FR + 7 + 2 * A + K + k, hv);
+                    }
+                } else {
+                    for (int k = leg; k < P; k += LEGS) {
+                        float hv = pos.z - hc_heights_offset - B.measured_heights[(size_t)e * P + k];
+                        if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
+                        putp(FR + 7 + 2 * A + K + k, hv);
+                    }
                 }
                 // labels (go2_ee.py:69-75): v_b 3 | contact states K | foot height above the local terrain mean F
                 lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmean - hc_foot_height_offset, -1.f, 1.f);
@@ -1858,10 +1900,20 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                         lab[3 + idx] = cst;
                     }
                 }
-                for (int k = leg; k < P; k += LEGS) {
-                    float hv = pos.z - hc_heights_offset - B.measured_heights[(size_t)e * P + k];
-                    if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
-                    putp(oH + k, hv);
+                if (hreg) {
+#pragma unroll
+                    for (int i = 0; i < HMAX; i++) {
+                        const int k = leg + i * LEGS;
+                        float hv = pos.z - hc_heights_offset - hts[i];
+                        if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
+                        if (k < P) putp(oH + k, hv);
+                    }
+                } else {
+                    for (int k = leg; k < P; k += LEGS) {
+                        float hv = pos.z - hc_heights_offset - B.measured_heights[(size_t)e * P + k];
+                        if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
+                        putp(oH + k, hv);
+                    }
                 }
                 const float *nv3 = B.normal_vector_around_feet + ((size_t)e * F + foot_slot) * 3;
 #pragma unroll
