@@ -1723,12 +1723,23 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         float *o = B.obs_buf + (size_t)e * (hc_num_obs + SL * FR) + (size_t)p.obs_win * FR;
         float *pv = hc_num_priv_obs > 0 ? B.priv_obs_buf + (size_t)e * (hc_num_priv_obs + SL * PF) + (size_t)p.obs_win * PF : nullptr;
         const float co = hc_clip_obs;
-        if (live && SL > 0) {
+        if (SL > 0) {
             // sliding window: the previous frames are already where this window expects them; only an env that was just
-            // reset blanks its history (go2_wtw.py:174-178)
-            if (reset) {
-                for (int i = leg; i < (ST - 1) * FR; i += LEGS) o[i] = 0.f;
-                if (pv) for (int i = leg; i < (PST - 1) * PF; i += LEGS) pv[i] = 0.f;
+            // reset blanks its history (go2_wtw.py:174-178).  All active lanes of the wave blank each such env together:
+            // left to the env's own 2-4 lanes that is up to 750 stores per lane (tron1: 9 x 31 + 9 x 134 floats), and the
+            // biped resets often
+            unsigned long long rm = __builtin_amdgcn_ballot_w64(live && reset && leg == 0);
+            const int nl = FUSED ? 16 : BLOCK;
+            while (rm) {
+                const int bit = __builtin_ctzll(rm);
+                rm &= rm - 1;
+                const int er = (vtid - vlane + bit) / LEGS;
+                float *orow = B.obs_buf + (size_t)er * (hc_num_obs + SL * FR) + (size_t)p.obs_win * FR;
+                for (int i = vlane; i < (ST - 1) * FR; i += nl) orow[i] = 0.f;
+                if (hc_num_priv_obs > 0) {
+                    float *prow = B.priv_obs_buf + (size_t)er * (hc_num_priv_obs + SL * PF) + (size_t)p.obs_win * PF;
+                    for (int i = vlane; i < (PST - 1) * PF; i += nl) prow[i] = 0.f;
+                }
             }
         } else if (live) {   // this lane's columns move one frame towards the past (zeros after a reset)
             for (int f = 0; f + 1 < ST; f++)

@@ -3,11 +3,11 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from hcr_genesis_lr_cl_amd.envs import make_env
-env, cfg = make_env("go2", 4096)
+env, cfg = make_env(sys.argv[1] if len(sys.argv) > 1 else "go2", 4096)
 env.reset()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 env.episode_length_buf[:] = torch.randint(0, 1000, (4096,), generator=g, device="cuda", dtype=torch.int32)
-bank = [torch.randn(4096, 12, generator=g, device="cuda") for _ in range(8)]
+bank = [torch.randn(4096, env.num_actions, generator=g, device="cuda") for _ in range(8)]
 names = ["start", "lds staged", "prologue loads", "lane consts", "sub-steps", "sim epilogue", "callback", "rewards", "post end", "reset blk", "obs", "end"]
 acc = torch.zeros(12)
 n = 0
