@@ -1576,20 +1576,32 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             // env-level uniforms of a reset (commands, friction, mass, CoM, root twist): ONE Philox block per lane of the env,
             // shared inside the quad, instead of one call per quantity on the lead lane (a call is ~800 cycles and the launch
             // ends with its slowest wave, which is always one that resets).  Injected draws keep their slots.
-            float eu[16];
-            const bool bundle = LEGS == 4 && !rs.in;
+            constexpr int NB = LEGS == 4 ? 1 : 3;          // blocks per lane: 16 uniforms per quadruped env, 24 per biped env
+            float eu[4 * LEGS * NB];
+            const bool bundle = !rs.in;
             if (bundle) {
-                float b[4];
-                rs.block4(0x200 + leg, b[0], b[1], b[2], b[3]);
 #pragma unroll
-                for (int k = 0; k < 4; k++) {
-                    const int x = __float_as_int(b[k]);
-                    eu[0 + k] = __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x00, 0xF, 0xF, false));
-                    eu[4 + k] = __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x55, 0xF, 0xF, false));
-                    eu[8 + k] = __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xAA, 0xF, 0xF, false));
-                    eu[12 + k] = __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xFF, 0xF, 0xF, false));
+                for (int b_ = 0; b_ < NB; b_++) {
+                    float b[4];
+                    rs.block4(0x200 + leg * NB + b_, b[0], b[1], b[2], b[3]);
+#pragma unroll
+                    for (int k = 0; k < 4; k++) {
+                        const int x = __float_as_int(b[k]);
+                        if (LEGS == 4) {
+                            eu[0 + k] = __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x00, 0xF, 0xF, false));
+                            eu[4 + k] = __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0x55, 0xF, 0xF, false));
+                            eu[8 + k] = __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xAA, 0xF, 0xF, false));
+                            eu[12 + k] = __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xFF, 0xF, 0xF, false));
+                        } else {   // lane pairs (0,1) and (2,3) of the quad are two envs
+                            eu[4 * b_ + k] = __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xA0, 0xF, 0xF, false));               // quad_perm [0,0,2,2]
+                            eu[4 * (NB + b_) + k] = __int_as_float(__builtin_amdgcn_update_dpp(0, x, 0xF5, 0xF, 0xF, false));        // quad_perm [1,1,3,3]
+                        }
+                    }
                 }
             }
+            // slots of eu[]: 0-2 commands, 3 friction, 4-6 CoM, 7 mass, 8-10 root lin vel, 12-14 root ang vel; biped only:
+            // 16-18 joint armature / friction / damping, 19-20 gait phase offsets, 21 terrain level
+            constexpr bool EU2 = LEGS == 2;
             if (hc_terrain_curriculum && p.counter > 0) {
                 // legged_robot.py:254-272 + genesis_simulator.py:140-148 (skipped on the construction-time reset,
                 // where the reference returns early because init_done is False)
@@ -1599,7 +1611,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 const bool up = dist > HOT(terrain_env_length) / 2.f;
                 const bool down = (dist < sqrtf(cmd0 * cmd0 + cmd1 * cmd1) * hc_episode_length_s * 0.5f) && !up;
                 int lvl = B.terrain_levels[e] + (up ? 1 : 0) - (down ? 1 : 0);
-                if (lvl >= HOT(max_terrain_level)) lvl = min((int)floorf(rs.draw(HOT(slots.terrain_level)) * (float)HOT(max_terrain_level)), HOT(max_terrain_level) - 1);
+                if (lvl >= HOT(max_terrain_level)) lvl = min((int)floorf(((bundle && EU2) ? eu[EU2 ? 21 : 0] : rs.draw(HOT(slots.terrain_level))) * (float)HOT(max_terrain_level)), HOT(max_terrain_level) - 1);
                 else lvl = max(lvl, 0);
                 const V3 norg = ld3(B.terrain_origins + ((size_t)lvl * HOT(terrain_cols_n) + B.terrain_types[e]) * 3);
                 if (lead) { B.terrain_levels[e] = lvl; st3(B.env_origins + 3 * e, norg); }
@@ -1648,9 +1660,9 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             }
             if (sit) { vw = v3(0, 0, 0); ww = v3(0, 0, 0); }        // tron1_pf_ee.py:304-309
             if (BIPED) {                                             // tron1_pf_ee.py:220-226
-                const float th0 = T->theta_table[0][0] + rs.draw(HOT(slots.task_reset) + 1);
+                const float th0 = T->theta_table[0][0] + ((bundle && EU2) ? eu[EU2 ? 19 : 0] : rs.draw(HOT(slots.task_reset) + 1));
                 theta = foot_slot == 0 ? th0 : th0 + (T->theta_table[0][1] - T->theta_table[0][0]);
-                gait_time = rs.draw(HOT(slots.task_reset) + 2) * gait_period;
+                gait_time = ((bundle && EU2) ? eu[EU2 ? 20 : 0] : rs.draw(HOT(slots.task_reset) + 2)) * gait_period;
                 phi = gait_time / gait_period;
             }
             // the reference stores the commanded reset twist verbatim in the body-frame properties
@@ -1697,7 +1709,8 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 }
                 if (HOT(dr_joint_on) && B.joint_armature) {
                     float uj[3];
-                    rs.draw3(HOT(slots.dr_joint), uj[0], uj[1], uj[2]);
+                    if (bundle && EU2) { uj[0] = eu[EU2 ? 16 : 0]; uj[1] = eu[EU2 ? 17 : 0]; uj[2] = eu[EU2 ? 18 : 0]; }
+                    else rs.draw3(HOT(slots.dr_joint), uj[0], uj[1], uj[2]);
                     B.joint_armature[e] = HOT(dr_joint_span[0]) * uj[0] + HOT(dr_joint_lo[0]);
                     B.joint_friction[e] = HOT(dr_joint_span[1]) * uj[1] + HOT(dr_joint_lo[1]);
                     B.joint_damping[e] = HOT(dr_joint_span[2]) * uj[2] + HOT(dr_joint_lo[2]);
