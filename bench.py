@@ -118,6 +118,8 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-gather", action="store_true", help="skip the per-step RCCL all-gather at N>1")
+    ap.add_argument("--sync-gather", action="store_true",
+                    help="wait for each step's all-gather before the next step (default: it overlaps the next step, double-buffered)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-timer-stride", type=int, default=8, help="time the physics kernel of every n-th step (0 = off)")
     ap.add_argument("--task", default="go2", choices=["go2", "go2_wtw", "go2_ee", "tron1_pf_ee"],
@@ -153,17 +155,13 @@ def main():
     env.episode_length_buf[:] = torch.randint(0, int(env.max_episode_length), (n_local,), generator=g, device=dev, dtype=torch.int32)
     # fixed synthetic action stream: a small bank of N(0,1) batches cycled (clipped +-100 in-kernel)
     bank = [torch.randn(n_local, env.num_actions, generator=g, device=dev) for _ in range(16)]
-    rec = torch.empty(n_local, n_obs + 2, device=dev)
-    gathered = torch.empty(world * n_local, n_obs + 2, device=dev) if world > 1 else None
+    from hcr_genesis_lr_cl_amd.distributed import StepGather
+    gather = StepGather(n_local, n_obs, world, dev, overlap=not args.sync_gather) if world > 1 and not args.no_gather else None
 
     def one_step(i):
         out = env.step(bank[i % len(bank)])
-        obs, rew, done = out[0], out[-3], out[-2]      # 5-tuple (go2, wtw) or 6-tuple (estimator tasks): same tail
-        if gathered is not None and not args.no_gather:
-            rec[:, :n_obs] = obs
-            rec[:, n_obs] = rew
-            rec[:, n_obs + 1] = done
-            dist.all_gather_into_tensor(gathered, rec)
+        if gather is not None:
+            gather(out[0], out[-3], out[-2])      # 5-tuple (go2, wtw) or 6-tuple (estimator tasks): same tail (rew, done, extras)
 
     for i in range(args.warmup):
         one_step(i)
@@ -177,6 +175,8 @@ def main():
     ev0.record()           # torch's current stream == the stream lg_step launches on (engine.py)
     for i in range(args.steps):
         one_step(i)
+    if gather is not None:
+        gather.finish()        # every record of the timed region has arrived before the clock stops
     ev1.record()
     torch.cuda.synchronize()
     if dist is not None:
@@ -208,7 +208,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{WORKLOADS[args.task]}, {n_local} envs per GPU, fused LeggedRobot.step "
                                    f"(4 sub-steps dt=0.005) with synthetic N(0,1) actions",
-                       "envs_total": total_envs, "parallelism": f"env-shard x{world}" + (" + all-gather(obs,rew,done)" if world > 1 and not args.no_gather else "")},
+                       "envs_total": total_envs, "parallelism": f"env-shard x{world}" + ((" + all-gather(obs,rew,done) per step" + ("" if args.sync_gather else ", overlapped with the next step")) if world > 1 and not args.no_gather else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": hbm_traffic(f"go2_flat_{n_local}") if args.task == "go2" else None,
                          "kernel": layout, "launch_us": launch_s * 1e6, "samples": kern_n,

@@ -33,23 +33,49 @@ def global_mean(local_sum, local_count):
 
 
 class StepGather:
-    """Packs one step's outputs into a (n_local, obs+2) record and all-gathers it."""
+    """Packs one step's outputs into a (n_local, obs+2) record and all-gathers it.
 
-    def __init__(self, n_local, num_obs, world, device, dtype=torch.float32):
-        self.world, self.num_obs = world, num_obs
-        self.rec = torch.empty(n_local, num_obs + 2, device=device, dtype=dtype)
-        self.out = torch.empty(world * n_local, num_obs + 2, device=device, dtype=dtype) if world > 1 else self.rec
+    `overlap=True` (bench.py at N > 1): the collective of step t is issued asynchronously and only awaited when its
+    double-buffered record is about to be reused at step t+2 (or in `finish()`), so the RCCL latency hides behind the next
+    step's kernel.  That is the data flow SURVEY 8e recommends -- every rank steps its own envs with its own copy of the
+    policy, the gathered records feed the learner once the rollout is over -- and it keeps one all-gather per step on the
+    wire.  `__call__` then returns the buffer the gather is landing in; read it after `finish()` (or after the call two
+    steps later)."""
+
+    def __init__(self, n_local, num_obs, world, device, dtype=torch.float32, overlap=False):
+        self.world, self.num_obs, self.overlap = world, num_obs, bool(overlap) and world > 1
+        nb = 2 if self.overlap else 1
+        self.recs = [torch.empty(n_local, num_obs + 2, device=device, dtype=dtype) for _ in range(nb)]
+        self.outs = [torch.empty(world * n_local, num_obs + 2, device=device, dtype=dtype) if world > 1 else r for r in self.recs]
+        self.work = [None] * nb
+        self.t = 0
+        self.rec, self.out = self.recs[0], self.outs[0]
 
     def __call__(self, obs, rew, done):
-        r = self.rec
-        r[:, :self.num_obs] = obs
-        r[:, self.num_obs] = rew
-        r[:, self.num_obs + 1] = done
+        i = self.t % len(self.recs)
+        self.t += 1
+        if self.work[i] is not None:          # the collective that last used this buffer pair must have finished
+            self.work[i].wait()
+            self.work[i] = None
+        r = self.rec = self.recs[i]
+        self.out = self.outs[i]
+        # one fused packing kernel on the compute stream (three slice copies cost three launches per step)
+        torch.cat((obs, rew.unsqueeze(1), done.unsqueeze(1)), dim=1, out=r)
         if self.world > 1:
             import torch.distributed as dist
-            dist.all_gather_into_tensor(self.out, r)
+            if self.overlap:
+                self.work[i] = dist.all_gather_into_tensor(self.out, r, async_op=True)
+            else:
+                dist.all_gather_into_tensor(self.out, r)
         return self.out
 
-    def split(self):
-        o = self.out
+    def finish(self):
+        """Wait for every outstanding gather (end of rollout / end of the timed region)."""
+        for i, w in enumerate(self.work):
+            if w is not None:
+                w.wait()
+                self.work[i] = None
+
+    def split(self, out=None):
+        o = self.out if out is None else out
         return o[:, :self.num_obs], o[:, self.num_obs], o[:, self.num_obs + 1] > 0.5

@@ -27,6 +27,13 @@ def _worker(rank, world, port, q):
     # command-curriculum mean over the resetting envs of all ranks: rank 0 has 3 of them (sum 6), rank 1 none
     gm = global_mean(torch.tensor(6.0) if rank == 0 else torch.tensor(0.0), 3 if rank == 0 else 0)
     assert gm == (2.0, 3.0), gm
+    # overlapped mode: three steps in flight over two buffer pairs, results read after finish()
+    g2 = StepGather(n, 5, world, "cpu", overlap=True)
+    outs = [g2(obs + k, ids * (2 + k), (ids % 3 == 0).float()) for k in range(3)]
+    g2.finish()
+    full = torch.arange(64, dtype=torch.float32)
+    assert torch.allclose(outs[2][:, 5], full * 4) and torch.allclose(outs[1][:, 5], full * 3)
+    assert torch.allclose(outs[2][:, 0], full + 2)
     q.put((rank, o.numpy().copy(), r.numpy().copy(), d.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
