@@ -86,7 +86,7 @@ def hbm_traffic(workload_key):
         return None
 
 
-def cpu_baseline(n_envs=2048, steps=150):
+def cpu_baseline(n_envs=4096, steps=800):
     """The CPU oracle (C, OpenMP over envs) on a bounded sample of the same workload."""
     import numpy as np
     from hcr_genesis_lr_cl_amd import builders, config as cfgmod
