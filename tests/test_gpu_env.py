@@ -180,3 +180,29 @@ def test_full_size_batch_properties():
     for k, tol, frac in (("dof_pos", 5e-4, 1e-3), ("base_pos", 5e-5, 1e-3), ("base_quat", 1e-4, 1e-3), ("dof_vel", 0.1, 2e-3)):
         bad = (e1.buf[k] - e2.buf[k]).abs() > tol
         assert bad.float().mean() <= frac, (k, int(bad.sum()), float((e1.buf[k] - e2.buf[k]).abs().max()))
+
+
+@pytest.mark.parametrize("task", ["go2", "go2_wtw", "go2_ee", "tron1_pf_ee"])
+def test_long_rollout_stays_sane(task):
+    """1500 control steps of aggressive random actions (sigma 2) on every BASELINE task at 1024 envs: state and outputs
+    stay finite and bounded, resets keep happening (robots fall) and robots never leave the terrain bounds."""
+    import torch
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    env, cfg = make_env(task, 1024, "cuda:0")
+    env.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(7)
+    A = env.num_actions
+    resets = 0
+    for t in range(1500):
+        out = env.step(2.0 * torch.randn(1024, A, generator=g, device="cuda"))
+        if t % 100 == 99:
+            obs, rew, done = out[0], out[-3], out[-2]
+            assert torch.isfinite(obs).all() and torch.isfinite(rew).all(), (task, t)
+            resets += int(done.sum())
+    b = env._engine.buf
+    for k in ("dof_pos", "dof_vel", "base_pos", "base_quat", "base_lin_vel_w", "base_ang_vel_w", "link_contact_forces", "torques"):
+        assert torch.isfinite(b[k]).all(), (task, k)
+    assert (b["base_quat"].norm(dim=1) - 1).abs().max() < 1e-4
+    assert b["base_pos"][:, 2].abs().max() < 20.0 and b["dof_vel"].abs().max() <= 2.0 * 31.0 + 1e-3
+    assert b["base_lin_vel_w"].abs().max() <= 50.0 + 1e-3 and b["base_ang_vel_w"].abs().max() <= 40.0 + 1e-3
+    assert resets > 0
