@@ -195,7 +195,7 @@ def main():
         bytes_env = TASK_BYTES[args.task]
         achieved = bytes_env * n_local / launch_s / 1e9
         legs = 2 if args.task == "tron1_pf_ee" else 4
-        if n_local * legs * 4 > 1024 * 64:
+        if n_local * legs * 4 > 2048 * 64:
             layout = f"env_step_kernel<{legs},ALL> (leg-per-lane)"
         elif legs == 4:
             layout = "quad_sim_kernel<4,PRE,POST|RESET> (component-per-lane physics, MDP phases in its tail)"

@@ -2192,12 +2192,12 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
     }
     // physics layout (lg_quad.h): one vector component per lane while the batch cannot fill the SIMDs with one leg per
     // lane; the MDP phases then follow in a second launch on the same stream
-    // auto: component-per-lane while that needs at most one wave per SIMD (1024 SIMDs); measured go2 crossover: 42 vs 58 us
-    // at 4096 envs, 92 vs 60 us at 16384
+    // auto: component-per-lane while that needs at most two waves per SIMD (1024 SIMDs).  Measured go2, us per step,
+    // component vs leg layout: 4096 envs 34.7 / 56.6, 8192: 50.9 / 55.2, 12288: 69.2 / 55.5, 16384: 92 / 60
     // the component-per-lane kernel is specialised for identity joint frames and hip-x / thigh-y / knee-y axes (lg_quad.h)
     const bool quad_ok = p.jrot_identity && p.k.joint_axis[0] == 0 && p.k.joint_axis[1] == 1 && p.k.joint_axis[2] == 1;
     if (h->opts.sim_layout == 2 && !quad_ok) return fail("lg_step: sim_layout 2 needs identity joint frames and x / y / y joint axes");
-    const int layout = h->opts.sim_layout ? h->opts.sim_layout : ((quad_ok && (long long)threads * 4 <= 1024LL * BLOCK) ? 2 : 1);
+    const int layout = h->opts.sim_layout ? h->opts.sim_layout : ((quad_ok && (long long)threads * 4 <= 2048LL * BLOCK) ? 2 : 1);
     if (layout == 2 && (ph & LG_PHASE_SIM)) {
         dim3 qgrid((threads * 4 + BLOCK - 1) / BLOCK);
         const bool pre = (ph & LG_PHASE_PRE) != 0;

@@ -12,7 +12,7 @@
 //   * sums over legs are two DPP row rotations (row_ror:4, row_ror:8).
 // The serial chain per wave shrinks ~2.7x and the launch has 4x the waves (one per SIMD at 4096 envs).  Total
 // issue slots are ~1.5x those of the leg-per-lane kernel, so that one stays the choice for large batches
-// (`LgSimOptions.sim_layout`; default: this layout while it needs at most one wave per SIMD, i.e. up to 4096 Go2 envs).
+// (`LgSimOptions.sim_layout`; default: this layout while it needs at most two waves per SIMD, i.e. up to 8192 Go2 envs).
 //
 // All control flow is wave-uniform (ballot + scalar branch): a DPP read from a lane switched off by EXEC is
 // undefined, so lanes are never masked off; dead lanes (past the last env) shadow the last env and only their
