@@ -206,3 +206,25 @@ def test_long_rollout_stays_sane(task):
     assert b["base_pos"][:, 2].abs().max() < 20.0 and b["dof_vel"].abs().max() <= 2.0 * 31.0 + 1e-3
     assert b["base_lin_vel_w"].abs().max() <= 50.0 + 1e-3 and b["base_ang_vel_w"].abs().max() <= 40.0 + 1e-3
     assert resets > 0
+
+
+@pytest.mark.parametrize("layout", [1, 2])
+def test_ragged_batch_sizes(layout, monkeypatch):
+    """Env counts that do not fill a wave (7 and 10 envs: dead lanes shadow the last env): the first 7 envs of the 10-env
+    batch evolve bit for bit like the 7-env batch (draws are keyed on the env id), in both physics layouts."""
+    import torch
+    monkeypatch.setenv("LG_SIM_LAYOUT", str(layout))
+    g = torch.Generator(device="cuda"); g.manual_seed(21)
+    acts = [torch.randn(10, 12, generator=g, device="cuda") for _ in range(60)]
+    runs = []
+    for n in (7, 10):
+        env = _mk(n)
+        env.reset()
+        outs = []
+        for a in acts:
+            obs, _, rew, done, _ = env.step(a[:n].contiguous())
+            outs.append((obs[:7].clone(), rew[:7].clone(), done[:7].clone()))
+        assert torch.isfinite(env._engine.buf["dof_pos"]).all()
+        runs.append(outs)
+    for (o1, r1, d1), (o2, r2, d2) in zip(*runs):
+        assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
