@@ -468,48 +468,75 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         QV6 ext[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, extb = {0.f, 0.f};
         {
             const float px = bc<0>(pos), py = bc<1>(pos), pz = bc<2>(pos);
-            auto slot = [&](int k, const QM &R, float P, const QV6 &V, QV6 &acc) {
-                // scalar-form pose of the body in every lane
-                const float zx = bc<2>(R.c0), zy = bc<2>(R.c1), zz = bc<2>(R.c2), Pz = bc<2>(P);
-                float rx = 0.f, ry = 0.f, h = 0.f, nx = 0.f, ny = 0.f, nz = 1.f;
-                const float rz = Pz + zx * sx[k] + zy * sy[k] + zz * sz[k];
+            // broad phase of one slot: this lane's sphere of body (R, P); returns the penetration depth (and centre / terrain)
+            struct Hit { float rx, ry, rz, h, nx, ny, nz, depth; bool on; };
+            auto probe = [&](int k, const QM &R, float P) {
+                Hit t;
+                t.rx = t.ry = 0.f; t.h = 0.f; t.nx = t.ny = 0.f; t.nz = 1.f;
+                t.rz = bc<2>(P) + bc<2>(R.c0) * sx[k] + bc<2>(R.c1) * sy[k] + bc<2>(R.c2) * sz[k];
                 if (hfmode) {
-                    rx = bc<0>(P) + bc<0>(R.c0) * sx[k] + bc<0>(R.c1) * sy[k] + bc<0>(R.c2) * sz[k];
-                    ry = bc<1>(P) + bc<1>(R.c0) * sx[k] + bc<1>(R.c1) * sy[k] + bc<1>(R.c2) * sz[k];
-                    terrain(TR, px + rx, py + ry, h, nx, ny, nz);
+                    t.rx = bc<0>(P) + bc<0>(R.c0) * sx[k] + bc<0>(R.c1) * sy[k] + bc<0>(R.c2) * sz[k];
+                    t.ry = bc<1>(P) + bc<1>(R.c0) * sx[k] + bc<1>(R.c1) * sy[k] + bc<1>(R.c2) * sz[k];
+                    terrain(TR, px + t.rx, py + t.ry, t.h, t.nx, t.ny, t.nz);
                 }
-                const float depth = srad[k] - (pz + rz - h) * nz;
-                const bool on = depth > -margin;
-                if (__builtin_amdgcn_ballot_w64(on) != 0ull) {      // rare: some sphere of this slot, somewhere in the wave
-                    if (!hfmode) {
-                        rx = bc<0>(P) + bc<0>(R.c0) * sx[k] + bc<0>(R.c1) * sy[k] + bc<0>(R.c2) * sz[k];
-                        ry = bc<1>(P) + bc<1>(R.c0) * sx[k] + bc<1>(R.c1) * sy[k] + bc<1>(R.c2) * sz[k];
-                    }
-                    const float wx = bc<0>(V.a), wy = bc<1>(V.a), wz = bc<2>(V.a);
-                    const float vx = bc<0>(V.l) + (wy * rz - wz * ry), vy = bc<1>(V.l) + (wz * rx - wx * rz), vz = bc<2>(V.l) + (wx * ry - wy * rx);
-                    const float vn = vx * nx + vy * ny + vz * nz;
-                    const float fn = (kc * depth - kappa * vn) * sden[k];
-                    float fx = 0.f, fy = 0.f, fz = 0.f;
-                    if (on && fn > 0.f) {
-                        const float tx = vx - nx * vn, ty = vy - ny * vn, tz = vz - nz * vn;
-                        // |f_t| = min(|v_t| / (dt w), mu f_n) along -v_t: one rsq, no sqrt / division
-                        const float s2 = tx * tx + ty * ty + tz * tz;
-                        const float g = s2 > 1e-18f ? fminf(sidw[k], mu * fn * rsqrtf(s2)) : 0.f;
-                        fx = nx * fn - tx * g; fy = ny * fn - ty * g; fz = nz * fn - tz * g;
-                    }
-                    const float cx = rx - nx * srad[k], cy = ry - ny * srad[k], cz = rz - nz * srad[k];
-                    const float mx = sum4(cy * fz - cz * fy), my = sum4(cz * fx - cx * fz), mz = sum4(cx * fy - cy * fx);
-                    fx = sum4(fx); fy = sum4(fy); fz = sum4(fz);
-                    acc.a += L.sel(mx, my, mz);
-                    acc.l += L.sel(fx, fy, fz);
+                t.depth = srad[k] - (pz + t.rz - t.h) * t.nz;
+                t.on = t.depth > -margin;
+                return t;
+            };
+            // force of this lane's sphere (scalar form), accumulated into (m, f) about O; body pose / twist in scalar form
+            struct BodyS { float x0, x1, x2, y0, y1, y2, Px, Py, wx, wy, wz, vx, vy, vz; };
+            auto gather = [&](const QM &R, float P, const QV6 &V) {
+                BodyS g = {bc<0>(R.c0), bc<0>(R.c1), bc<0>(R.c2), bc<1>(R.c0), bc<1>(R.c1), bc<1>(R.c2), bc<0>(P), bc<1>(P),
+                           bc<0>(V.a), bc<1>(V.a), bc<2>(V.a), bc<0>(V.l), bc<1>(V.l), bc<2>(V.l)};
+                return g;
+            };
+            auto force = [&](int k, Hit t, const BodyS &g, float (&m)[3], float (&f)[3]) {
+                if (!hfmode) {
+                    t.rx = g.Px + g.x0 * sx[k] + g.x1 * sy[k] + g.x2 * sz[k];
+                    t.ry = g.Py + g.y0 * sx[k] + g.y1 * sy[k] + g.y2 * sz[k];
+                }
+                const float vx = g.vx + (g.wy * t.rz - g.wz * t.ry), vy = g.vy + (g.wz * t.rx - g.wx * t.rz), vz = g.vz + (g.wx * t.ry - g.wy * t.rx);
+                const float vn = vx * t.nx + vy * t.ny + vz * t.nz;
+                const float fn = (kc * t.depth - kappa * vn) * sden[k];
+                float fx = 0.f, fy = 0.f, fz = 0.f;
+                if (t.on && fn > 0.f) {
+                    const float tx = vx - t.nx * vn, ty = vy - t.ny * vn, tz = vz - t.nz * vn;
+                    // |f_t| = min(|v_t| / (dt w), mu f_n) along -v_t: one rsq, no sqrt / division
+                    const float s2 = tx * tx + ty * ty + tz * tz;
+                    const float gg = s2 > 1e-18f ? fminf(sidw[k], mu * fn * rsqrtf(s2)) : 0.f;
+                    fx = t.nx * fn - tx * gg; fy = t.ny * fn - ty * gg; fz = t.nz * fn - tz * gg;
+                }
+                const float cx = t.rx - t.nx * srad[k], cy = t.ry - t.ny * srad[k], cz = t.rz - t.nz * srad[k];
+                m[0] += cy * fz - cz * fy; m[1] += cz * fx - cx * fz; m[2] += cx * fy - cy * fx;
+                f[0] += fx; f[1] += fy; f[2] += fz;
+            };
+            auto reduce = [&](const float (&m)[3], const float (&f)[3], QV6 &acc) {
+                acc.a += L.sel(sum4(m[0]), sum4(m[1]), sum4(m[2]));
+                acc.l += L.sel(sum4(f[0]), sum4(f[1]), sum4(f[2]));
+            };
+            // one slot of a body; the force branch runs only if some sphere of the slot touches somewhere in the wave
+            auto slot = [&](int k, const QM &R, float P, const QV6 &V, QV6 &acc) {
+                const Hit t = probe(k, R, P);
+                if (__builtin_amdgcn_ballot_w64(t.on) != 0ull) {
+                    float m[3] = {0.f, 0.f, 0.f}, f[3] = {0.f, 0.f, 0.f};
+                    force(k, t, gather(R, P, V), m, f);
+                    reduce(m, f, acc);
                 }
             };
             const QV6 V0 = {ww, vw};
             slot(4, Rb, 0.f, V0, extb);
             slot(0, K[0].R, K[0].P, K[0].V, ext[0]);
             slot(1, K[1].R, K[1].P, K[1].V, ext[1]);
-            slot(2, K[2].R, K[2].P, K[2].V, ext[2]);
-            slot(3, K[2].R, K[2].P, K[2].V, ext[2]);
+            {   // the calf's two slots share one gather and one reduction
+                const Hit t2 = probe(2, K[2].R, K[2].P), t3 = probe(3, K[2].R, K[2].P);
+                if (__builtin_amdgcn_ballot_w64(t2.on || t3.on) != 0ull) {
+                    float m[3] = {0.f, 0.f, 0.f}, f[3] = {0.f, 0.f, 0.f};
+                    const BodyS g = gather(K[2].R, K[2].P, K[2].V);
+                    force(2, t2, g, m, f);
+                    force(3, t3, g, m, f);
+                    reduce(m, f, ext[2]);
+                }
+            }
         }
         f_link[0] = ext[0].l; f_link[1] = ext[1].l; f_link[2] = ext[2].l;
 
