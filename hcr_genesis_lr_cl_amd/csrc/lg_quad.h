@@ -346,6 +346,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     }
     sMraw[threadIdx.x] = stg0; sMraw[threadIdx.x + BLOCK] = stg1; sMraw[threadIdx.x + 2 * BLOCK] = stg2; sMraw[threadIdx.x + 3 * BLOCK] = stg3;
     __syncthreads();
+    STAMP(23);
 
     // ---------------- prologue stores ---------------------------------------------------------------
     if (DO_PRE && st) {
@@ -424,6 +425,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         }
     }
 
+    STAMP(24);
     float torque = 0.f;
     float f_link[4] = {0.f, 0.f, 0.f, 0.f};   // net contact force on hip, thigh, calf, foot links (component)
     float f_base = 0.f;
