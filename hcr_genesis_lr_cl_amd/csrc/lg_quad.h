@@ -54,6 +54,16 @@ template <int LEGS> LG_DEV int env_or(int v) {
     return v;
 }
 
+// 16 bytes of the kernel argument segment per lane (lane i: bytes [16 i, 16 i + 16), clamped to `n16` chunks)
+LG_DEV uint4 kernarg_lane(int n16) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return reinterpret_cast<const uint4 *>(__builtin_amdgcn_kernarg_segment_ptr())[min((int)threadIdx.x, n16 - 1)];
+#else
+    (void)n16;
+    return make_uint4(0u, 0u, 0u, 0u);
+#endif
+}
+
 struct QM { float c0, c1, c2; };       // 3x3: this lane's row
 struct QV6 { float a, l; };            // spatial vector [angular; linear], one component of each
 struct QI6 { QM A, B, Bt, C; };        // [A B; B^T C]: rows c of (A|B) and of (B^T|C)
@@ -235,14 +245,28 @@ template <int LEGS, bool DO_PRE, unsigned MPH>
 __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     using namespace q4;
     constexpr int A = 3 * LEGS;
-    const LgModelDesc *__restrict__ Mg = p.M;
+    // The kernel argument block (KParams, ~800 B of pointers) through ONE vector load: lane i holds bytes [16 i, 16 i + 16).
+    // Fetched with scalar loads it arrives as a dozen dependent dwordx16 chunks (SGPR pressure), each a device-memory round
+    // trip in front of the start-of-kernel burst: ~4 k of the prologue's cycles.  Pointers needed by the burst are rebuilt
+    // from the lanes with v_readlane (right here, full EXEC); everything later uses `p` as usual.
+    static_assert(sizeof(KParams) <= 64 * 16, "kernel argument block must fit one dwordx4 per lane");
+    const uint4 kq = q4::kernarg_lane((int)(sizeof(KParams) + 15) / 16);
+    auto kdw = [&](int dw) {   // dword `dw` of the block (compile-time index after inlining)
+        const unsigned v = (dw & 3) == 0 ? kq.x : ((dw & 3) == 1 ? kq.y : ((dw & 3) == 2 ? kq.z : kq.w));
+        return (unsigned)__builtin_amdgcn_readlane((int)v, dw >> 2);
+    };
+#define KPTR(T, off) (reinterpret_cast<T>(((unsigned long long)kdw((int)((off) / 4) + 1) << 32) | (unsigned long long)kdw((int)((off) / 4))))
+#define KB(T, f) KPTR(T, offsetof(KParams, B) + offsetof(LgBuffers, f))
+#define KINT(member) ((int)kdw((int)(offsetof(KParams, member) / 4)))
+#define KFLT(member) (__int_as_float((int)kdw((int)(offsetof(KParams, member) / 4))))
+    const LgModelDesc *__restrict__ Mg = KPTR(const LgModelDesc *, offsetof(KParams, M));
     __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_STG * BLOCK];
     const LgModelDesc *M = reinterpret_cast<const LgModelDesc *>(sMraw);
     const LgSimOptions *__restrict__ O = p.O;
     __shared__ int sHot[256 + BLOCK];
     int hv0, hv1, hv2, hv3;
     {
-        const int *hp = reinterpret_cast<const int *>(p.H) + (threadIdx.x & 63);
+        const int *hp = KPTR(const int *, offsetof(KParams, H)) + (threadIdx.x & 63);
         hv0 = hp[0]; hv1 = hp[64]; hv2 = hp[128]; hv3 = hp[192];
     }
     uint4 stg0, stg1, stg2, stg3;
@@ -261,43 +285,74 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     const int cj = min(L.c, 2);               // lane 3 shadows lane 2's addresses; it never stores
     const int quad = tid >> 2, leg = quad % LEGS;
     int e = quad / LEGS;
-    const int N = B.n_envs;
+    const int N = KINT(B.n_envs);
     const bool live = e < N;
     if (!live) e = N - 1;
     const bool st = live && !L.is3;           // this lane stores vector components / joint values
     const bool lead = st && leg == 0;         // ... and the per-env ones
-    const int nL = p.k.m_n_links, F = LEGS;
+    const int nL = KINT(k.m_n_links), F = LEGS;
     const int b0 = 1 + 3 * leg, d0 = 3 * leg;
-    const int foot_link = leg == 0 ? p.k.m_foot_link[0] : (leg == 1 ? p.k.m_foot_link[1] : (leg == 2 ? p.k.m_foot_link[2] : p.k.m_foot_link[3]));
+    const int foot_link = leg == 0 ? KINT(k.m_foot_link[0]) : (leg == 1 ? KINT(k.m_foot_link[1]) : (leg == 2 ? KINT(k.m_foot_link[2]) : KINT(k.m_foot_link[3])));
     int foot_slot = 0;
 #pragma unroll
-    for (int k = 0; k < LEGS; k++) foot_slot += (p.k.m_foot_link[k] < foot_link) ? 1 : 0;
+    for (int k = 0; k < LEGS; k++) foot_slot += (KINT(k.m_foot_link[k]) < foot_link) ? 1 : 0;
 
     // ---------------- start-of-kernel loads (one burst, one wait) --------------------------------
+    // pointers of the burst, rebuilt from the lane table
+    const float *const k_actions = KB(const float *, actions);
+    const float *const k_last_actions = KB(const float *, last_actions);
+    const float *const k_base_pos = KB(const float *, base_pos);
+    const float *const k_base_lin_vel_w = KB(const float *, base_lin_vel_w);
+    const float *const k_base_ang_vel_w = KB(const float *, base_ang_vel_w);
+    const float *const k_base_quat = KB(const float *, base_quat);
+    const float *const k_dof_pos = KB(const float *, dof_pos);
+    const float *const k_dof_vel = KB(const float *, dof_vel);
+    const float *const k_feet_vel = KB(const float *, feet_vel);
+    const float *const k_base_lin_vel = KB(const float *, base_lin_vel);
+    const float *const k_base_ang_vel = KB(const float *, base_ang_vel);
+    const float *const k_added_base_mass = KB(const float *, added_base_mass);
+    const float *const k_base_com_bias = KB(const float *, base_com_bias);
+    const float *const k_friction_values = KB(const float *, friction_values);
+    const float *const k_kp_scale = KB(const float *, kp_scale);
+    const float *const k_kd_scale = KB(const float *, kd_scale);
+    const float *const k_joint_armature = KB(const float *, joint_armature);
+    const float *const k_joint_friction = KB(const float *, joint_friction);
+    const float *const k_joint_damping = KB(const float *, joint_damping);
+    const float *const k_env_origins = KB(const float *, env_origins);
+    const float *const k_command_ranges = KB(const float *, command_ranges);
+    const float *const k_episode_sums = KB(const float *, episode_sums);
+    const float *const k_commands = KB(const float *, commands);
+    const float *const k_feet_air_time = KB(const float *, feet_air_time);
+    const int32_t *const k_episode_length_buf = KB(const int32_t *, episode_length_buf);
+    const int64_t *const k_fail_buf = KB(const int64_t *, fail_buf);
+    const uint8_t *const k_last_contacts = KB(const uint8_t *, last_contacts);
+    const float *const k_actions_in = KPTR(const float *, offsetof(KParams, actions));
+    const LgSimOptions *__restrict__ kO = KPTR(const LgSimOptions *, offsetof(KParams, O));
+    const LgTaskCfg *__restrict__ kT = KPTR(const LgTaskCfg *, offsetof(KParams, T));
     const int ja = e * A + d0 + cj;           // this lane's joint
     float act, last_act = 0.f, llast_act = 0.f;
     if (DO_PRE) {
-        const float ca = p.k.clip_actions;
-        last_act = B.actions[ja]; llast_act = B.last_actions[ja];
-        act = clampf(p.actions[ja], -ca, ca);
+        const float ca = KFLT(k.clip_actions);
+        last_act = k_actions[ja]; llast_act = k_last_actions[ja];
+        act = clampf(k_actions_in[ja], -ca, ca);
     } else {
-        act = p.actions ? p.actions[ja] : B.actions[ja];
+        act = k_actions_in ? k_actions_in[ja] : k_actions[ja];
     }
-    float pos = B.base_pos[3 * e + cj], vw = B.base_lin_vel_w[3 * e + cj], ww = B.base_ang_vel_w[3 * e + cj];
-    float quat = B.base_quat[4 * e + L.c];
-    float q = B.dof_pos[ja], qd = B.dof_vel[ja];
-    const float snap_fv = B.feet_vel[(e * F + foot_slot) * 3 + cj];
-    const float snap_blv = B.base_lin_vel[3 * e + cj], snap_bav = B.base_ang_vel[3 * e + cj];
-    const float dr_mass = B.added_base_mass ? B.added_base_mass[e] : 0.f;
-    const float dr_com = B.base_com_bias ? B.base_com_bias[3 * e + cj] : 0.f;
-    const float dr_fric = B.friction_values ? B.friction_values[e] : 1.f;
-    const float dr_kp = B.kp_scale ? B.kp_scale[ja] : 1.f, dr_kd = B.kd_scale ? B.kd_scale[ja] : 1.f;
-    const float gain_p = O->kp[d0 + cj], gain_d = O->kd[d0 + cj], q0 = O->default_dof_pos[d0 + cj];
+    float pos = k_base_pos[3 * e + cj], vw = k_base_lin_vel_w[3 * e + cj], ww = k_base_ang_vel_w[3 * e + cj];
+    float quat = k_base_quat[4 * e + L.c];
+    float q = k_dof_pos[ja], qd = k_dof_vel[ja];
+    const float snap_fv = k_feet_vel[(e * F + foot_slot) * 3 + cj];
+    const float snap_blv = k_base_lin_vel[3 * e + cj], snap_bav = k_base_ang_vel[3 * e + cj];
+    const float dr_mass = k_added_base_mass ? k_added_base_mass[e] : 0.f;
+    const float dr_com = k_base_com_bias ? k_base_com_bias[3 * e + cj] : 0.f;
+    const float dr_fric = k_friction_values ? k_friction_values[e] : 1.f;
+    const float dr_kp = k_kp_scale ? k_kp_scale[ja] : 1.f, dr_kd = k_kd_scale ? k_kd_scale[ja] : 1.f;
+    const float gain_p = kO->kp[d0 + cj], gain_d = kO->kd[d0 + cj], q0 = kO->default_dof_pos[d0 + cj];
     float dr_arm = 0.f, dr_jf = 0.f, dr_jd = 0.f;
-    if (B.joint_armature) { dr_arm = B.joint_armature[e]; dr_jf = B.joint_friction[e]; dr_jd = B.joint_damping[e]; }
-    const float origin = B.env_origins ? B.env_origins[3 * e + cj] : 0.f;
+    if (k_joint_armature) { dr_arm = k_joint_armature[e]; dr_jf = k_joint_friction[e]; dr_jd = k_joint_damping[e]; }
+    const float origin = k_env_origins ? k_env_origins[3 * e + cj] : 0.f;
     int crv = 0;
-    if (MPH != 0) crv = reinterpret_cast<const int *>(B.command_ranges)[min((int)threadIdx.x, LG_CMD_RANGE_FLOATS - 1)];
+    if (MPH != 0) crv = reinterpret_cast<const int *>(k_command_ranges)[min((int)threadIdx.x, LG_CMD_RANGE_FLOATS - 1)];
     // MDP working set of the wave's 16 legs, fetched by lanes 0..15 in this same burst and parked in LDS: the MDP tail
     // (env_step_body<.., FUSED>) reads it back after the physics instead of paying the round trips then.  Layout = the
     // stash of env_step_body (NST values x 16 lanes).
@@ -305,15 +360,15 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     __shared__ float sStF[MPH != 0 ? NST * 16 : 1];
     float wsv[MPH != 0 ? NST : 1];
     if (MPH != 0 && threadIdx.x < 16) {
-        const LgTaskCfg *__restrict__ T = p.T;
+        const LgTaskCfg *__restrict__ T = kT;
         const int lt = blockIdx.x * 16 + (int)threadIdx.x, legL = lt % LEGS, dL = 3 * legL;
         const int eL = min(lt / LEGS, N - 1);
-        const int flL = legL == 0 ? p.k.m_foot_link[0] : (legL == 1 ? p.k.m_foot_link[1] : (legL == 2 ? p.k.m_foot_link[2] : p.k.m_foot_link[3]));
+        const int flL = legL == 0 ? KINT(k.m_foot_link[0]) : (legL == 1 ? KINT(k.m_foot_link[1]) : (legL == 2 ? KINT(k.m_foot_link[2]) : KINT(k.m_foot_link[3])));
         int fsL = 0;
 #pragma unroll
-        for (int k = 0; k < LEGS; k++) fsL += (p.k.m_foot_link[k] < flL) ? 1 : 0;
+        for (int k = 0; k < LEGS; k++) fsL += (KINT(k.m_foot_link[k]) < flL) ? 1 : 0;
 #pragma unroll
-        for (int k = 0; k < LG_R_COUNT; k++) wsv[k] = B.episode_sums[(size_t)k * N + eL];   // unconditional: no branch per term
+        for (int k = 0; k < LG_R_COUNT; k++) wsv[k] = k_episode_sums[(size_t)k * N + eL];   // unconditional: no branch per term
         int c2 = LG_R_COUNT;
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -321,14 +376,14 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             wsv[c2++] = T->reset_dof_lo[dL + j]; wsv[c2++] = T->reset_dof_span[dL + j];
             wsv[c2++] = T->noise_vec[9 + dL + j]; wsv[c2++] = T->noise_vec[9 + A + dL + j]; wsv[c2++] = T->noise_vec[9 + 2 * A + dL + j];
         }
-        const bool clk = p.k.obs_layout == LG_OBS_TRON1_EE;
+        const bool clk = KINT(k.obs_layout) == LG_OBS_TRON1_EE;
         wsv[c2++] = clk ? T->noise_vec[9 + 3 * A + fsL] : 0.f; wsv[c2++] = clk ? T->noise_vec[9 + 3 * A + LEGS + fsL] : 0.f;
-        wsv[c2++] = B.commands[4 * eL]; wsv[c2++] = B.commands[4 * eL + 1]; wsv[c2++] = B.commands[4 * eL + 2]; wsv[c2++] = B.commands[4 * eL + 3];
-        wsv[c2++] = __int_as_float(B.episode_length_buf[eL]);
-        wsv[c2++] = __int_as_float((int)B.fail_buf[eL]);
-        wsv[c2++] = B.feet_air_time[eL * F + fsL];
-        wsv[c2++] = __int_as_float((int)B.last_contacts[eL * F + fsL]);
-        wsv[c2++] = B.env_origins[3 * eL]; wsv[c2++] = B.env_origins[3 * eL + 1]; wsv[c2++] = B.env_origins[3 * eL + 2];
+        wsv[c2++] = k_commands[4 * eL]; wsv[c2++] = k_commands[4 * eL + 1]; wsv[c2++] = k_commands[4 * eL + 2]; wsv[c2++] = k_commands[4 * eL + 3];
+        wsv[c2++] = __int_as_float(k_episode_length_buf[eL]);
+        wsv[c2++] = __int_as_float((int)k_fail_buf[eL]);
+        wsv[c2++] = k_feet_air_time[eL * F + fsL];
+        wsv[c2++] = __int_as_float((int)k_last_contacts[eL * F + fsL]);
+        wsv[c2++] = k_env_origins[3 * eL]; wsv[c2++] = k_env_origins[3 * eL + 1]; wsv[c2++] = k_env_origins[3 * eL + 2];
     }
 
     asm volatile("" ::: "memory");

@@ -3,11 +3,12 @@ import os, sys
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
 import torch
 from hcr_genesis_lr_cl_amd.envs import make_env
-env, cfg = make_env("go2", 4096)
+NE = int(os.environ.get("NE", "4096"))
+env, cfg = make_env("go2", NE)
 env.reset()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
-env.episode_length_buf[:] = torch.randint(0, 1000, (4096,), generator=g, device="cuda", dtype=torch.int32)
-bank = [torch.randn(4096, 12, generator=g, device="cuda") for _ in range(8)]
+env.episode_length_buf[:] = torch.randint(0, 1000, (NE,), generator=g, device="cuda", dtype=torch.int32)
+bank = [torch.randn(NE, 12, generator=g, device="cuda") for _ in range(8)]
 acc = torch.zeros(32); n = 0
 for i in range(800):
     env.step(bank[i % 8])
