@@ -255,24 +255,28 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         const unsigned v = (dw & 3) == 0 ? kq.x : ((dw & 3) == 1 ? kq.y : ((dw & 3) == 2 ? kq.z : kq.w));
         return (unsigned)__builtin_amdgcn_readlane((int)v, dw >> 2);
     };
+#define GAS __attribute__((address_space(1)))
 #define KPTR(T, off) (reinterpret_cast<T>(((unsigned long long)kdw((int)((off) / 4) + 1) << 32) | (unsigned long long)kdw((int)((off) / 4))))
 #define KB(T, f) KPTR(T, offsetof(KParams, B) + offsetof(LgBuffers, f))
 #define KINT(member) ((int)kdw((int)(offsetof(KParams, member) / 4)))
 #define KFLT(member) (__int_as_float((int)kdw((int)(offsetof(KParams, member) / 4))))
-    const LgModelDesc *__restrict__ Mg = KPTR(const LgModelDesc *, offsetof(KParams, M));
+    const LgModelDesc GAS *Mg = KPTR(const LgModelDesc GAS *, offsetof(KParams, M));
     __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_STG * BLOCK];
     const LgModelDesc *M = reinterpret_cast<const LgModelDesc *>(sMraw);
     const LgSimOptions *__restrict__ O = p.O;
     __shared__ int sHot[256 + BLOCK];
     int hv0, hv1, hv2, hv3;
     {
-        const int *hp = KPTR(const int *, offsetof(KParams, H)) + (threadIdx.x & 63);
+        const int GAS *hp = KPTR(const int GAS *, offsetof(KParams, H)) + (threadIdx.x & 63);
         hv0 = hp[0]; hv1 = hp[64]; hv2 = hp[128]; hv3 = hp[192];
     }
     uint4 stg0, stg1, stg2, stg3;
     {
-        const uint4 *src = reinterpret_cast<const uint4 *>(Mg);
-        stg0 = src[threadIdx.x]; stg1 = src[threadIdx.x + BLOCK]; stg2 = src[threadIdx.x + 2 * BLOCK]; stg3 = src[threadIdx.x + 3 * BLOCK];
+        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+        const u4v GAS *src = reinterpret_cast<const u4v GAS *>(Mg);
+        const u4v a0 = src[threadIdx.x], a1 = src[threadIdx.x + BLOCK], a2 = src[threadIdx.x + 2 * BLOCK], a3 = src[threadIdx.x + 3 * BLOCK];
+        stg0 = make_uint4(a0.x, a0.y, a0.z, a0.w); stg1 = make_uint4(a1.x, a1.y, a1.z, a1.w);
+        stg2 = make_uint4(a2.x, a2.y, a2.z, a2.w); stg3 = make_uint4(a3.x, a3.y, a3.z, a3.w);
     }
     const LgBuffers &B = p.B;
     unsigned long long _stamp0 = 0; (void)_stamp0;
@@ -299,36 +303,36 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
 
     // ---------------- start-of-kernel loads (one burst, one wait) --------------------------------
     // pointers of the burst, rebuilt from the lane table
-    const float *const k_actions = KB(const float *, actions);
-    const float *const k_last_actions = KB(const float *, last_actions);
-    const float *const k_base_pos = KB(const float *, base_pos);
-    const float *const k_base_lin_vel_w = KB(const float *, base_lin_vel_w);
-    const float *const k_base_ang_vel_w = KB(const float *, base_ang_vel_w);
-    const float *const k_base_quat = KB(const float *, base_quat);
-    const float *const k_dof_pos = KB(const float *, dof_pos);
-    const float *const k_dof_vel = KB(const float *, dof_vel);
-    const float *const k_feet_vel = KB(const float *, feet_vel);
-    const float *const k_base_lin_vel = KB(const float *, base_lin_vel);
-    const float *const k_base_ang_vel = KB(const float *, base_ang_vel);
-    const float *const k_added_base_mass = KB(const float *, added_base_mass);
-    const float *const k_base_com_bias = KB(const float *, base_com_bias);
-    const float *const k_friction_values = KB(const float *, friction_values);
-    const float *const k_kp_scale = KB(const float *, kp_scale);
-    const float *const k_kd_scale = KB(const float *, kd_scale);
-    const float *const k_joint_armature = KB(const float *, joint_armature);
-    const float *const k_joint_friction = KB(const float *, joint_friction);
-    const float *const k_joint_damping = KB(const float *, joint_damping);
-    const float *const k_env_origins = KB(const float *, env_origins);
-    const float *const k_command_ranges = KB(const float *, command_ranges);
-    const float *const k_episode_sums = KB(const float *, episode_sums);
-    const float *const k_commands = KB(const float *, commands);
-    const float *const k_feet_air_time = KB(const float *, feet_air_time);
-    const int32_t *const k_episode_length_buf = KB(const int32_t *, episode_length_buf);
-    const int64_t *const k_fail_buf = KB(const int64_t *, fail_buf);
-    const uint8_t *const k_last_contacts = KB(const uint8_t *, last_contacts);
-    const float *const k_actions_in = KPTR(const float *, offsetof(KParams, actions));
-    const LgSimOptions *__restrict__ kO = KPTR(const LgSimOptions *, offsetof(KParams, O));
-    const LgTaskCfg *__restrict__ kT = KPTR(const LgTaskCfg *, offsetof(KParams, T));
+    const float GAS *const k_actions = KB(const float GAS *, actions);
+    const float GAS *const k_last_actions = KB(const float GAS *, last_actions);
+    const float GAS *const k_base_pos = KB(const float GAS *, base_pos);
+    const float GAS *const k_base_lin_vel_w = KB(const float GAS *, base_lin_vel_w);
+    const float GAS *const k_base_ang_vel_w = KB(const float GAS *, base_ang_vel_w);
+    const float GAS *const k_base_quat = KB(const float GAS *, base_quat);
+    const float GAS *const k_dof_pos = KB(const float GAS *, dof_pos);
+    const float GAS *const k_dof_vel = KB(const float GAS *, dof_vel);
+    const float GAS *const k_feet_vel = KB(const float GAS *, feet_vel);
+    const float GAS *const k_base_lin_vel = KB(const float GAS *, base_lin_vel);
+    const float GAS *const k_base_ang_vel = KB(const float GAS *, base_ang_vel);
+    const float GAS *const k_added_base_mass = KB(const float GAS *, added_base_mass);
+    const float GAS *const k_base_com_bias = KB(const float GAS *, base_com_bias);
+    const float GAS *const k_friction_values = KB(const float GAS *, friction_values);
+    const float GAS *const k_kp_scale = KB(const float GAS *, kp_scale);
+    const float GAS *const k_kd_scale = KB(const float GAS *, kd_scale);
+    const float GAS *const k_joint_armature = KB(const float GAS *, joint_armature);
+    const float GAS *const k_joint_friction = KB(const float GAS *, joint_friction);
+    const float GAS *const k_joint_damping = KB(const float GAS *, joint_damping);
+    const float GAS *const k_env_origins = KB(const float GAS *, env_origins);
+    const float GAS *const k_command_ranges = KB(const float GAS *, command_ranges);
+    const float GAS *const k_episode_sums = KB(const float GAS *, episode_sums);
+    const float GAS *const k_commands = KB(const float GAS *, commands);
+    const float GAS *const k_feet_air_time = KB(const float GAS *, feet_air_time);
+    const int32_t GAS *const k_episode_length_buf = KB(const int32_t GAS *, episode_length_buf);
+    const int64_t GAS *const k_fail_buf = KB(const int64_t GAS *, fail_buf);
+    const uint8_t GAS *const k_last_contacts = KB(const uint8_t GAS *, last_contacts);
+    const float GAS *const k_actions_in = KPTR(const float GAS *, offsetof(KParams, actions));
+    const LgSimOptions GAS *kO = KPTR(const LgSimOptions GAS *, offsetof(KParams, O));
+    const LgTaskCfg GAS *kT = KPTR(const LgTaskCfg GAS *, offsetof(KParams, T));
     const int ja = e * A + d0 + cj;           // this lane's joint
     float act, last_act = 0.f, llast_act = 0.f;
     if (DO_PRE) {
@@ -352,7 +356,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     if (k_joint_armature) { dr_arm = k_joint_armature[e]; dr_jf = k_joint_friction[e]; dr_jd = k_joint_damping[e]; }
     const float origin = k_env_origins ? k_env_origins[3 * e + cj] : 0.f;
     int crv = 0;
-    if (MPH != 0) crv = reinterpret_cast<const int *>(k_command_ranges)[min((int)threadIdx.x, LG_CMD_RANGE_FLOATS - 1)];
+    if (MPH != 0) crv = reinterpret_cast<const int GAS *>(k_command_ranges)[min((int)threadIdx.x, LG_CMD_RANGE_FLOATS - 1)];
     // MDP working set of the wave's 16 legs, fetched by lanes 0..15 in this same burst and parked in LDS: the MDP tail
     // (env_step_body<.., FUSED>) reads it back after the physics instead of paying the round trips then.  Layout = the
     // stash of env_step_body (NST values x 16 lanes).
@@ -360,7 +364,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     __shared__ float sStF[MPH != 0 ? NST * 16 : 1];
     float wsv[MPH != 0 ? NST : 1];
     if (MPH != 0 && threadIdx.x < 16) {
-        const LgTaskCfg *__restrict__ T = kT;
+        const LgTaskCfg GAS *T = kT;
         const int lt = blockIdx.x * 16 + (int)threadIdx.x, legL = lt % LEGS, dL = 3 * legL;
         const int eL = min(lt / LEGS, N - 1);
         const int flL = legL == 0 ? KINT(k.m_foot_link[0]) : (legL == 1 ? KINT(k.m_foot_link[1]) : (legL == 2 ? KINT(k.m_foot_link[2]) : KINT(k.m_foot_link[3])));
