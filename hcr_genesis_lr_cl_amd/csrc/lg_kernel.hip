@@ -1728,6 +1728,30 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     }
     if (DO_RESET) {
         STAMP(9);
+        // Everything the privileged frames read back from the state arrays (DR parameters, terrain around the feet) is
+        // loaded HERE, in one batch in front of the observation stores.  vmcnt retires loads and stores in order: a load
+        // issued after a run of stores is only usable once those stores have drained, so a load next to each `putp`
+        // cost a store round trip apiece (tron1: 25 of them, 17 k of this section's 24 k cycles).
+        float ld_kp[3] = {1.f, 1.f, 1.f}, ld_kd[3] = {1.f, 1.f, 1.f}, ld_nv3[3] = {0.f, 0.f, 0.f}, ld_haf[9];
+        float ld_fric = 1.f, ld_mass = 0.f, ld_com[3] = {0.f, 0.f, 0.f}, ld_push[2] = {0.f, 0.f}, ld_jnt[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < 9; k++) ld_haf[k] = 0.f;
+        if (hc_obs_layout != LG_OBS_GO2) {
+#pragma unroll
+            for (int j = 0; j < 3; j++) { ld_kp[j] = B.kp_scale[e * A + d0 + j]; ld_kd[j] = B.kd_scale[e * A + d0 + j]; }
+            if (P > 0 && HOT(o_feet_terrain_info)) {
+#pragma unroll
+                for (int k = 0; k < 3; k++) ld_nv3[k] = B.normal_vector_around_feet[((size_t)e * F + foot_slot) * 3 + k];
+#pragma unroll
+                for (int k = 0; k < 9; k++) ld_haf[k] = B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k];
+            }
+            ld_fric = B.friction_values[e]; ld_mass = B.added_base_mass[e];
+#pragma unroll
+            for (int k = 0; k < 3; k++) ld_com[k] = B.base_com_bias[3 * e + k];
+            ld_push[0] = B.rand_push_vels[3 * e]; ld_push[1] = B.rand_push_vels[3 * e + 1];
+            if (B.joint_armature) { ld_jnt[0] = B.joint_armature[e]; ld_jnt[1] = B.joint_friction[e]; ld_jnt[2] = B.joint_damping[e]; }
+            asm volatile("" ::: "memory");
+        }
         // ---- compute_observations + clip (legged_robot.py:48-49).  Layouts: go2.py:40-64 (45),
         //      go2_wtw.py:53-111 (61x5 | 99x5), go2_ee.py:10-75 (45x20 | 174x5 | 24 labels).  Histories are
         //      kept oldest -> newest inside obs_buf / priv_obs_buf themselves and shifted in place.
@@ -1835,8 +1859,8 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 put(57 + foot_slot, theta, 0.5f, 0.f);
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
-                    putp(FR + 10 + d0 + j, B.kp_scale[e * A + d0 + j]);
-                    putp(FR + 10 + A + d0 + j, B.kd_scale[e * A + d0 + j]);
+                    putp(FR + 10 + d0 + j, ld_kp[j]);
+                    putp(FR + 10 + A + d0 + j, ld_kd[j]);
                 }
                 putp(FR + 10 + 2 * A + foot_slot, expC);
                 ts[6 + foot_slot] = theta; ts[10 + foot_slot] = sn; ts[14 + foot_slot] = cs; ts[18 + foot_slot] = expC;
@@ -1844,9 +1868,9 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             if (lead) {
                 put(53, gait_period, 0.5f, 0.f); put(54, bh_tgt, 0.5f, 0.f); put(55, fc_tgt, 0.5f, 0.f); put(56, pitch_tgt, 0.5f, 0.f);
                 putp(FR + 0, blv.x * hc_obs_scale_lin_vel); putp(FR + 1, blv.y * hc_obs_scale_lin_vel); putp(FR + 2, blv.z * hc_obs_scale_lin_vel);
-                putp(FR + 3, B.rand_push_vels[3 * e]); putp(FR + 4, B.rand_push_vels[3 * e + 1]);
-                putp(FR + 5, B.added_base_mass[e]); putp(FR + 6, B.friction_values[e]);
-                putp(FR + 7, B.base_com_bias[3 * e]); putp(FR + 8, B.base_com_bias[3 * e + 1]); putp(FR + 9, B.base_com_bias[3 * e + 2]);
+                putp(FR + 3, ld_push[0]); putp(FR + 4, ld_push[1]);
+                putp(FR + 5, ld_mass); putp(FR + 6, ld_fric);
+                putp(FR + 7, ld_com[0]); putp(FR + 8, ld_com[1]); putp(FR + 9, ld_com[2]);
             }
         } else if (hc_obs_layout == LG_OBS_GO2_EE) {
             // critic frame (go2_ee.py:21-48): obs 45 | DR 31 | contact states K | heights P
@@ -1856,8 +1880,8 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             if (live) {
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
-                    putp(FR + 7 + d0 + j, B.kp_scale[e * A + d0 + j] - HOT(kp_offset));
-                    putp(FR + 7 + A + d0 + j, B.kd_scale[e * A + d0 + j] - HOT(kd_offset));
+                    putp(FR + 7 + d0 + j, ld_kp[j] - HOT(kp_offset));
+                    putp(FR + 7 + A + d0 + j, ld_kd[j] - HOT(kd_offset));
                 }
                 // contact states are those of the physics read-back (stale for a just-reset env, as in the reference)
 #pragma unroll
@@ -1889,9 +1913,9 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmean - hc_foot_height_offset, -1.f, 1.f);
             }
             if (lead) {
-                putp(FR + 0, B.friction_values[e] - HOT(friction_offset)); putp(FR + 1, B.added_base_mass[e]);
-                putp(FR + 2, B.base_com_bias[3 * e]); putp(FR + 3, B.base_com_bias[3 * e + 1]); putp(FR + 4, B.base_com_bias[3 * e + 2]);
-                putp(FR + 5, B.rand_push_vels[3 * e]); putp(FR + 6, B.rand_push_vels[3 * e + 1]);
+                putp(FR + 0, ld_fric - HOT(friction_offset)); putp(FR + 1, ld_mass);
+                putp(FR + 2, ld_com[0]); putp(FR + 3, ld_com[1]); putp(FR + 4, ld_com[2]);
+                putp(FR + 5, ld_push[0]); putp(FR + 6, ld_push[1]);
                 if (M->state_link_mask & 1u) { const float cs = norm(f_base) > 1.f ? 1.f : 0.f; putp(FR + 7 + 2 * A, cs); lab[3] = cs; }
                 lab[0] = blv.x * hc_obs_scale_lin_vel; lab[1] = blv.y * hc_obs_scale_lin_vel; lab[2] = blv.z * hc_obs_scale_lin_vel;
             }
@@ -1910,8 +1934,8 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 ts[4 + foot_slot] = theta; ts[6 + foot_slot] = sn; ts[6 + F + foot_slot] = cs; ts[10 + foot_slot] = expC;
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
-                    putp(oDR + 7 + d0 + j, B.kp_scale[e * A + d0 + j] - HOT(kp_offset));
-                    putp(oDR + 7 + A + d0 + j, B.kd_scale[e * A + d0 + j] - HOT(kd_offset));
+                    putp(oDR + 7 + d0 + j, ld_kp[j] - HOT(kp_offset));
+                    putp(oDR + 7 + A + d0 + j, ld_kd[j] - HOT(kd_offset));
                 }
                 putp(oG + foot_slot, expC);
 #pragma unroll
@@ -1939,21 +1963,21 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                         putp(oH + k, hv);
                     }
                 }
-                const float *nv3 = B.normal_vector_around_feet + ((size_t)e * F + foot_slot) * 3;
+                const float (&nv3)[3] = ld_nv3;
 #pragma unroll
                 for (int k = 0; k < 3; k++) { putp(oN + 3 * foot_slot + k, nv3[k]); lab[3 + K + F + 3 * foot_slot + k] = nv3[k]; }
 #pragma unroll
                 for (int k = 0; k < 9; k++)
-                    putp(oR + 9 * foot_slot + k, clampf(foot_p.z - B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k], -1.f, 1.f));
+                    putp(oR + 9 * foot_slot + k, clampf(foot_p.z - ld_haf[k], -1.f, 1.f));
                 lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmax - hc_foot_height_offset, -1.f, 1.f);
             }
             if (lead) {
-                putp(oDR + 0, B.friction_values[e] - HOT(friction_offset)); putp(oDR + 1, B.added_base_mass[e]);
-                putp(oDR + 2, B.base_com_bias[3 * e]); putp(oDR + 3, B.base_com_bias[3 * e + 1]); putp(oDR + 4, B.base_com_bias[3 * e + 2]);
-                putp(oDR + 5, B.rand_push_vels[3 * e]); putp(oDR + 6, B.rand_push_vels[3 * e + 1]);
-                putp(oDR + 7 + 2 * A, B.joint_armature ? B.joint_armature[e] : 0.f);
-                putp(oDR + 8 + 2 * A, B.joint_friction ? B.joint_friction[e] : 0.f);
-                putp(oDR + 9 + 2 * A, B.joint_damping ? B.joint_damping[e] : 0.f);
+                putp(oDR + 0, ld_fric - HOT(friction_offset)); putp(oDR + 1, ld_mass);
+                putp(oDR + 2, ld_com[0]); putp(oDR + 3, ld_com[1]); putp(oDR + 4, ld_com[2]);
+                putp(oDR + 5, ld_push[0]); putp(oDR + 6, ld_push[1]);
+                putp(oDR + 7 + 2 * A, ld_jnt[0]);
+                putp(oDR + 8 + 2 * A, ld_jnt[1]);
+                putp(oDR + 9 + 2 * A, ld_jnt[2]);
                 if (M->state_link_mask & 1u) { const float cst = norm(f_base) > 1.f ? 1.f : 0.f; putp(oK, cst); lab[3] = cst; }
                 lab[0] = blv.x * hc_obs_scale_lin_vel; lab[1] = blv.y * hc_obs_scale_lin_vel; lab[2] = blv.z * hc_obs_scale_lin_vel;
             }

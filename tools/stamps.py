@@ -9,13 +9,13 @@ g = torch.Generator(device="cuda"); g.manual_seed(1)
 env.episode_length_buf[:] = torch.randint(0, 1000, (4096,), generator=g, device="cuda", dtype=torch.int32)
 bank = [torch.randn(4096, env.num_actions, generator=g, device="cuda") for _ in range(8)]
 names = ["start", "lds staged", "prologue loads", "lane consts", "sub-steps", "sim epilogue", "callback", "rewards", "post end", "reset blk", "obs", "end"]
-acc = torch.zeros(12)
+acc = torch.zeros(32)
 n = 0
 for i in range(700):
     env.step(bank[i % 8])
     if i >= 500:
         torch.cuda.synchronize()
-        acc += env._engine.buf["episode_done_sums"].flatten()[:12].cpu()
+        acc += env._engine.buf["episode_done_sums"].flatten()[:32].cpu()
         n += 1
 acc /= n
 prev = 0.0
