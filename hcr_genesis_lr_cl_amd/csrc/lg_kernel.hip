@@ -470,11 +470,16 @@ __global__ __launch_bounds__(256) void obs_compact_kernel(float *buf, int n_rows
     }
 }
 
+// Hand-off of the physics results from quad_sim_kernel to its MDP tail through LDS: value k of leg-lane l sits at
+// sX[k * 16 + l] (per-env values are written once per leg).  Indices:
+enum { XA = 0, XLA = 3, XLLA = 6, XQ = 9, XQD = 12, XLQD = 15, XTQ = 18, XFL = 21, XFP = 33, XFV = 36, XLFV = 39, XPOS = 42, XQUAT = 45,
+       XVW = 49, XWW = 52, XBLV = 55, XBAV = 58, XPG = 61, XEUL = 64, XFB = 67, NX = 70 };
+
 // The body of the leg-per-lane step.  FUSED = called from the tail of quad_sim_kernel (lg_quad.h) by the first 16 lanes of
 // the wave, one per leg of the wave's envs: the model table, the hot constants and the command ranges are already in
 // LDS, `vtid` is the leg-lane index and nothing is staged here.
 template <int LEGS, unsigned PH, bool FUSED>
-LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF, const int vtid, const int vlane) {
+LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF, const float *sX, const int vtid, const int vlane) {
     constexpr bool DO_PRE = (PH & LG_PHASE_PRE) != 0, DO_SIM = (PH & LG_PHASE_SIM) != 0;
     constexpr bool DO_POST = (PH & LG_PHASE_POST) != 0, DO_RESET = (PH & LG_PHASE_RESET) != 0;
     constexpr int A = LEGS * 3;
@@ -528,6 +533,9 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     } else if (DO_SIM && !DO_POST) {  // Simulator.step(actions): actions come pre-clipped from the env
 #pragma unroll
         for (int j = 0; j < 3; j++) { act[j] = p.actions[e * A + d0 + j]; last_act[j] = llast_act[j] = 0.f; }
+    } else if (FUSED) {   // handed over by the physics phase of the same launch through LDS
+#pragma unroll
+        for (int j = 0; j < 3; j++) { act[j] = sX[(XA + j) * 16 + vlane]; last_act[j] = sX[(XLA + j) * 16 + vlane]; llast_act[j] = sX[(XLLA + j) * 16 + vlane]; }
     } else {
 #pragma unroll
         for (int j = 0; j < 3; j++) {
@@ -538,11 +546,20 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     }
 
     // ---------------- state ----------------------------------------------------------------
-    V3 pos = ld3(B.base_pos + 3 * e), vw = ld3(B.base_lin_vel_w + 3 * e), ww = ld3(B.base_ang_vel_w + 3 * e);
-    float qx = B.base_quat[4 * e], qy = B.base_quat[4 * e + 1], qz = B.base_quat[4 * e + 2], qw = B.base_quat[4 * e + 3];
-    float q[3], qd[3];
+    V3 pos, vw, ww;
+    float qx, qy, qz, qw, q[3], qd[3];
+    if (FUSED) {
+        auto X3 = [&](int k) { return v3(sX[k * 16 + vlane], sX[(k + 1) * 16 + vlane], sX[(k + 2) * 16 + vlane]); };
+        pos = X3(XPOS); vw = X3(XVW); ww = X3(XWW);
+        qx = sX[XQUAT * 16 + vlane]; qy = sX[(XQUAT + 1) * 16 + vlane]; qz = sX[(XQUAT + 2) * 16 + vlane]; qw = sX[(XQUAT + 3) * 16 + vlane];
 #pragma unroll
-    for (int j = 0; j < 3; j++) { q[j] = B.dof_pos[e * A + d0 + j]; qd[j] = B.dof_vel[e * A + d0 + j]; }
+        for (int j = 0; j < 3; j++) { q[j] = sX[(XQ + j) * 16 + vlane]; qd[j] = sX[(XQD + j) * 16 + vlane]; }
+    } else {
+        pos = ld3(B.base_pos + 3 * e); vw = ld3(B.base_lin_vel_w + 3 * e); ww = ld3(B.base_ang_vel_w + 3 * e);
+        qx = B.base_quat[4 * e]; qy = B.base_quat[4 * e + 1]; qz = B.base_quat[4 * e + 2]; qw = B.base_quat[4 * e + 3];
+#pragma unroll
+        for (int j = 0; j < 3; j++) { q[j] = B.dof_pos[e * A + d0 + j]; qd[j] = B.dof_vel[e * A + d0 + j]; }
+    }
 
     // ---- MDP working set, fetched NOW so that the round trips overlap the physics below instead of being
     //      exposed one by one behind it (a lone wave per SIMD has nothing else to switch to) -----------------
@@ -1181,18 +1198,28 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             if (lead && (M->state_link_mask & 1u)) B.link_contact_states[(size_t)e * __popc(M->state_link_mask)] = norm(f_base) > 1.f ? 1.f : 0.f;
         }
     } else {
-        // SIM not in this launch: pick the read-back up from HBM
-        blv = ld3(B.base_lin_vel + 3 * e); bav = ld3(B.base_ang_vel + 3 * e);
-        pg = ld3(B.projected_gravity + 3 * e); eul = ld3(B.base_euler + 3 * e);
+        // SIM not in this launch: pick the read-back up from LDS (fused behind the physics) or from HBM
         const int l0 = foot_link - 3;
+        if (FUSED) {
+            auto X3 = [&](int k) { return v3(sX[k * 16 + vlane], sX[(k + 1) * 16 + vlane], sX[(k + 2) * 16 + vlane]); };
+            blv = X3(XBLV); bav = X3(XBAV); pg = X3(XPG); eul = X3(XEUL);
 #pragma unroll
-        for (int k = 0; k < 4; k++) f_link[k] = ld3(B.link_contact_forces + (e * L + l0 + k) * 3);
-        f_base = ld3(B.link_contact_forces + (e * L) * 3);
-        foot_p = ld3(B.feet_pos + (e * F + foot_slot) * 3);
-        foot_v = ld3(B.feet_vel + (e * F + foot_slot) * 3);
-        last_foot_v = ld3(B.last_feet_vel + (e * F + foot_slot) * 3);
+            for (int k = 0; k < 4; k++) f_link[k] = X3(XFL + 3 * k);
+            f_base = X3(XFB); foot_p = X3(XFP); foot_v = X3(XFV); last_foot_v = X3(XLFV);
 #pragma unroll
-        for (int j = 0; j < 3; j++) { last_qd[j] = B.last_dof_vel[e * A + d0 + j]; torque[j] = B.torques[e * A + d0 + j]; }
+            for (int j = 0; j < 3; j++) { last_qd[j] = sX[(XLQD + j) * 16 + vlane]; torque[j] = sX[(XTQ + j) * 16 + vlane]; }
+        } else {
+            blv = ld3(B.base_lin_vel + 3 * e); bav = ld3(B.base_ang_vel + 3 * e);
+            pg = ld3(B.projected_gravity + 3 * e); eul = ld3(B.base_euler + 3 * e);
+#pragma unroll
+            for (int k = 0; k < 4; k++) f_link[k] = ld3(B.link_contact_forces + (e * L + l0 + k) * 3);
+            f_base = ld3(B.link_contact_forces + (e * L) * 3);
+            foot_p = ld3(B.feet_pos + (e * F + foot_slot) * 3);
+            foot_v = ld3(B.feet_vel + (e * F + foot_slot) * 3);
+            last_foot_v = ld3(B.last_feet_vel + (e * F + foot_slot) * 3);
+#pragma unroll
+            for (int j = 0; j < 3; j++) { last_qd[j] = B.last_dof_vel[e * A + d0 + j]; torque[j] = B.torques[e * A + d0 + j]; }
+        }
         if (P > 0) {
             float acc = 0.f;
             if (hreg) {
@@ -2024,7 +2051,7 @@ template <int LEGS, unsigned PH>
 __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_STG * BLOCK];
     __shared__ int sHot[256 + BLOCK];
-    env_step_body<LEGS, PH, false>(p, sMraw, sHot, nullptr, blockIdx.x * BLOCK + threadIdx.x, threadIdx.x & 63);
+    env_step_body<LEGS, PH, false>(p, sMraw, sHot, nullptr, nullptr, blockIdx.x * BLOCK + threadIdx.x, threadIdx.x & 63);
 }
 
 #include "lg_quad.h"

@@ -413,13 +413,13 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         B.last_actions[ja] = last_act;
         B.actions[ja] = act;
     }
-    const float last_foot_v = snap_fv;
+    const float last_foot_v = snap_fv, qd_start = qd;   // kept for the MDP tail (dof_acc, foot_acc)
     if (st) {   // "last" snapshots (genesis_simulator.py:21-24)
         B.last_dof_vel[ja] = qd;
         B.last_feet_vel[(e * F + foot_slot) * 3 + cj] = snap_fv;
         if (leg == 0) { B.last_base_lin_vel[3 * e + cj] = snap_blv; B.last_base_ang_vel[3 * e + cj] = snap_bav; }
     }
-    (void)last_foot_v;
+    (void)last_foot_v; (void)qd_start;
 
     // ---------------- constants ---------------------------------------------------------------------
     const float dt = HOT(o_dt), kc = HOT(o_contact_k), kappa = kc * dt + HOT(o_contact_b), margin = HOT(o_contact_margin);
@@ -923,13 +923,26 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     STAMPB(8192);
     // ---------------- MDP phases in the same launch -------------------------------------------------
     if (MPH != 0) {
-        // everything the MDP reads was stored above by this very wave (workgroup = one wave): a workgroup-scope fence
-        // (wait for the stores; the CU's L1 is coherent with its own stores) is all it takes.  An agent-scope fence
-        // here writes back the XCD's L2 from every wave: measured +29 us per launch.
-        __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+        // hand the results to the MDP phases through LDS (layout: lg_kernel.hip, XA .. XFB): leg-lane l of the tail is quad l
+        // of this wave; a quad lane writes its own component.  Nothing the tail reads then comes from the arrays stored
+        // above, so those stores drain in the background instead of being waited for.
+        __shared__ float sX[NX * 16];
+        {
+            const int qi = (int)threadIdx.x >> 2;
+            auto XW = [&](int k, float v) { if (!L.is3) sX[(k + L.c) * 16 + qi] = v; };
+            XW(XA, act); XW(XLA, last_act); XW(XLLA, llast_act); XW(XQ, q); XW(XQD, qd); XW(XLQD, qd_start); XW(XTQ, torque);
+            XW(XFL, f_link[0]); XW(XFL + 3, f_link[1]); XW(XFL + 6, f_link[2]); XW(XFL + 9, f_link[3]);
+            XW(XFP, foot_p); XW(XFV, foot_v); XW(XLFV, last_foot_v);
+            XW(XPOS, pos); XW(XVW, vw); XW(XWW, ww); XW(XBLV, blv); XW(XBAV, bav); XW(XPG, pg); XW(XEUL, eul); XW(XFB, f_base);
+            sX[(XQUAT + L.c) * 16 + qi] = quat;
+        }
+        // terrain samples (heightfield only) still travel through measured_heights / height_around_feet: a workgroup-scope
+        // fence (the workgroup is this wave; the CU's L1 is coherent with its own stores) makes them visible.  An
+        // agent-scope fence here writes back the XCD's L2 from every wave: measured +29 us per launch.
+        if (P > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __syncthreads();
         if (threadIdx.x < 16)
-            env_step_body<LEGS, MPH, true>(p, sMraw, sHot, sStF, blockIdx.x * 16 + (int)threadIdx.x, (int)threadIdx.x);
+            env_step_body<LEGS, MPH, true>(p, sMraw, sHot, sStF, sX, blockIdx.x * 16 + (int)threadIdx.x, (int)threadIdx.x);
     }
     STAMPB(12288);
 }
