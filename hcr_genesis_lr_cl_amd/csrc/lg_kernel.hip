@@ -1595,6 +1595,31 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     }
 
     STAMP(8);
+    // Everything the privileged frames (observation section below) read back from the state arrays -- DR parameters, terrain
+    // around the feet -- is loaded HERE, in one batch, ahead of the reset block's and the observation section's stores; a
+    // reset updates these copies when it redraws the parameters.  vmcnt retires loads and stores in order: a load issued
+    // after a run of stores is only usable once those stores have drained, so a load next to each `putp` cost a store
+    // round trip apiece (tron1: 25 of them, 17 k of the observation section's 24 k cycles).
+    float ld_kp[3] = {1.f, 1.f, 1.f}, ld_kd[3] = {1.f, 1.f, 1.f}, ld_nv3[3] = {0.f, 0.f, 0.f}, ld_haf[9];
+    float ld_fric = 1.f, ld_mass = 0.f, ld_com[3] = {0.f, 0.f, 0.f}, ld_push[2] = {0.f, 0.f}, ld_jnt[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 9; k++) ld_haf[k] = 0.f;
+    if (DO_RESET && hc_obs_layout != LG_OBS_GO2) {   // ahead of the reset block's stores too; a reset updates these copies
+#pragma unroll
+        for (int j = 0; j < 3; j++) { ld_kp[j] = B.kp_scale[e * A + d0 + j]; ld_kd[j] = B.kd_scale[e * A + d0 + j]; }
+        if (P > 0 && HOT(o_feet_terrain_info)) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) ld_nv3[k] = B.normal_vector_around_feet[((size_t)e * F + foot_slot) * 3 + k];
+#pragma unroll
+            for (int k = 0; k < 9; k++) ld_haf[k] = B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k];
+        }
+        ld_fric = B.friction_values[e]; ld_mass = B.added_base_mass[e];
+#pragma unroll
+        for (int k = 0; k < 3; k++) ld_com[k] = B.base_com_bias[3 * e + k];
+        ld_push[0] = B.rand_push_vels[3 * e]; ld_push[1] = B.rand_push_vels[3 * e + 1];
+        if (B.joint_armature) { ld_jnt[0] = B.joint_armature[e]; ld_jnt[1] = B.joint_friction[e]; ld_jnt[2] = B.joint_damping[e]; }
+        asm volatile("" ::: "memory");
+    }
     // ---- reset_idx (legged_robot.py:94-148) + simulator.reset_idx (genesis_simulator.py:62-82) ----
     if (DO_RESET) {
         V3 pos_origin_override = v3(0, 0, 0);
@@ -1712,8 +1737,8 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     rs.draw3(HOT(slots.dr_kd) + d0, ud2[0], ud2[1], ud2[2]);
 #pragma unroll
                     for (int j = 0; j < 3; j++) {
-                        B.kp_scale[e * A + d0 + j] = HOT(dr_kp_span) * up[j] + HOT(dr_kp_lo);
-                        B.kd_scale[e * A + d0 + j] = HOT(dr_kd_span) * ud2[j] + HOT(dr_kd_lo);
+                        ld_kp[j] = HOT(dr_kp_span) * up[j] + HOT(dr_kp_lo); B.kp_scale[e * A + d0 + j] = ld_kp[j];
+                        ld_kd[j] = HOT(dr_kd_span) * ud2[j] + HOT(dr_kd_lo); B.kd_scale[e * A + d0 + j] = ld_kd[j];
                     }
                 }
             }
@@ -1725,22 +1750,22 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 st3(B.projected_gravity + 3 * e, pg);
                 st3(B.last_base_lin_vel + 3 * e, v3(0, 0, 0)); st3(B.last_base_ang_vel + 3 * e, v3(0, 0, 0));
                 // domain randomisation (genesis_simulator.py:62-77, 665-739)
-                if (HOT(dr_friction_on)) B.friction_values[e] = HOT(dr_friction_span) * (bundle ? eu[3] : rs.draw(HOT(slots.dr_friction))) + HOT(dr_friction_lo);
-                if (HOT(dr_mass_on)) B.added_base_mass[e] = HOT(dr_mass_span) * (bundle ? eu[7] : rs.draw(HOT(slots.dr_mass))) + HOT(dr_mass_lo);
+                if (HOT(dr_friction_on)) { ld_fric = HOT(dr_friction_span) * (bundle ? eu[3] : rs.draw(HOT(slots.dr_friction))) + HOT(dr_friction_lo); B.friction_values[e] = ld_fric; }
+                if (HOT(dr_mass_on)) { ld_mass = HOT(dr_mass_span) * (bundle ? eu[7] : rs.draw(HOT(slots.dr_mass))) + HOT(dr_mass_lo); B.added_base_mass[e] = ld_mass; }
                 if (HOT(dr_com_on)) {
                     float uc[3];
                     if (bundle) { uc[0] = eu[4]; uc[1] = eu[5]; uc[2] = eu[6]; }
                     else rs.draw3(HOT(slots.dr_com), uc[0], uc[1], uc[2]);
 #pragma unroll
-                    for (int k = 0; k < 3; k++) B.base_com_bias[3 * e + k] = HOT(dr_com_span[k]) * uc[k] + HOT(dr_com_lo[k]);
+                    for (int k = 0; k < 3; k++) { ld_com[k] = HOT(dr_com_span[k]) * uc[k] + HOT(dr_com_lo[k]); B.base_com_bias[3 * e + k] = ld_com[k]; }
                 }
                 if (HOT(dr_joint_on) && B.joint_armature) {
                     float uj[3];
                     if (bundle && EU2) { uj[0] = eu[EU2 ? 16 : 0]; uj[1] = eu[EU2 ? 17 : 0]; uj[2] = eu[EU2 ? 18 : 0]; }
                     else rs.draw3(HOT(slots.dr_joint), uj[0], uj[1], uj[2]);
-                    B.joint_armature[e] = HOT(dr_joint_span[0]) * uj[0] + HOT(dr_joint_lo[0]);
-                    B.joint_friction[e] = HOT(dr_joint_span[1]) * uj[1] + HOT(dr_joint_lo[1]);
-                    B.joint_damping[e] = HOT(dr_joint_span[2]) * uj[2] + HOT(dr_joint_lo[2]);
+                    ld_jnt[0] = HOT(dr_joint_span[0]) * uj[0] + HOT(dr_joint_lo[0]); B.joint_armature[e] = ld_jnt[0];
+                    ld_jnt[1] = HOT(dr_joint_span[1]) * uj[1] + HOT(dr_joint_lo[1]); B.joint_friction[e] = ld_jnt[1];
+                    ld_jnt[2] = HOT(dr_joint_span[2]) * uj[2] + HOT(dr_joint_lo[2]); B.joint_damping[e] = ld_jnt[2];
                 }
                 // extras["episode"] (legged_robot.py:128-132): snapshot this env's sums + the step it reset at; the
                 // host forms the per-step means lazily from these.  (A first version used one float atomic per term
@@ -1755,30 +1780,6 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     }
     if (DO_RESET) {
         STAMP(9);
-        // Everything the privileged frames read back from the state arrays (DR parameters, terrain around the feet) is
-        // loaded HERE, in one batch in front of the observation stores.  vmcnt retires loads and stores in order: a load
-        // issued after a run of stores is only usable once those stores have drained, so a load next to each `putp`
-        // cost a store round trip apiece (tron1: 25 of them, 17 k of this section's 24 k cycles).
-        float ld_kp[3] = {1.f, 1.f, 1.f}, ld_kd[3] = {1.f, 1.f, 1.f}, ld_nv3[3] = {0.f, 0.f, 0.f}, ld_haf[9];
-        float ld_fric = 1.f, ld_mass = 0.f, ld_com[3] = {0.f, 0.f, 0.f}, ld_push[2] = {0.f, 0.f}, ld_jnt[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-        for (int k = 0; k < 9; k++) ld_haf[k] = 0.f;
-        if (hc_obs_layout != LG_OBS_GO2) {
-#pragma unroll
-            for (int j = 0; j < 3; j++) { ld_kp[j] = B.kp_scale[e * A + d0 + j]; ld_kd[j] = B.kd_scale[e * A + d0 + j]; }
-            if (P > 0 && HOT(o_feet_terrain_info)) {
-#pragma unroll
-                for (int k = 0; k < 3; k++) ld_nv3[k] = B.normal_vector_around_feet[((size_t)e * F + foot_slot) * 3 + k];
-#pragma unroll
-                for (int k = 0; k < 9; k++) ld_haf[k] = B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k];
-            }
-            ld_fric = B.friction_values[e]; ld_mass = B.added_base_mass[e];
-#pragma unroll
-            for (int k = 0; k < 3; k++) ld_com[k] = B.base_com_bias[3 * e + k];
-            ld_push[0] = B.rand_push_vels[3 * e]; ld_push[1] = B.rand_push_vels[3 * e + 1];
-            if (B.joint_armature) { ld_jnt[0] = B.joint_armature[e]; ld_jnt[1] = B.joint_friction[e]; ld_jnt[2] = B.joint_damping[e]; }
-            asm volatile("" ::: "memory");
-        }
         // ---- compute_observations + clip (legged_robot.py:48-49).  Layouts: go2.py:40-64 (45),
         //      go2_wtw.py:53-111 (61x5 | 99x5), go2_ee.py:10-75 (45x20 | 174x5 | 24 labels).  Histories are
         //      kept oldest -> newest inside obs_buf / priv_obs_buf themselves and shifted in place.
