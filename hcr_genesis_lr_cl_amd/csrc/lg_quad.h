@@ -880,12 +880,41 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         const float yn = rcp(fmaxf(fsqrt(qz * qz + qw * qw), 1e-9f));
         const float yz = qz * yn, yw = qw * yn;
         const float px = bc<0>(pos), py = bc<1>(pos);
-        for (int k = leg * 4 + L.c; k < P; k += 4 * LEGS) {
-            const float vx = B.height_points[2 * k], vy = B.height_points[2 * k + 1];
-            const float tx = -2.f * yz * vy, ty = 2.f * yz * vx;
-            const float rx = vx + yw * tx - yz * ty, ry = vy + yw * ty + yz * tx;
-            const float h = sample_min3(O, p.hf, rx + px, ry + py);
-            if (live) B.measured_heights[(size_t)e * P + k] = h;
+        constexpr int HQ = 7;                    // samples per lane held in flight (go2: 81 / 16 lanes, tron1: 49 / 8)
+        const int kstride = 4 * LEGS, k0 = leg * 4 + L.c;
+        if (P <= HQ * kstride) {
+            // all of this lane's samples at once: points, then the 3 x HQ height loads, then the minima -- instead of one
+            // exposed load round trip per sample
+            const float brd = HOT(o_border), hs = HOT(o_hscale), vs = HOT(o_vscale);
+            const int TRr = HOT(o_terrain_rows), TCc = HOT(o_terrain_cols);
+            float vx[HQ], vy[HQ];
+#pragma unroll
+            for (int i = 0; i < HQ; i++) { const int kc = min(k0 + i * kstride, P - 1); vx[i] = B.height_points[2 * kc]; vy[i] = B.height_points[2 * kc + 1]; }
+            int h1[HQ], h2[HQ], h3[HQ];
+#pragma unroll
+            for (int i = 0; i < HQ; i++) {
+                const float tx = -2.f * yz * vy[i], ty = 2.f * yz * vx[i];
+                const float rx = vx[i] + yw * tx - yz * ty, ry = vy[i] + yw * ty + yz * tx;
+                // genesis_simulator.py:565-575: cell index by truncation, clipped, min over three neighbours
+                int cx = (int)((rx + px + brd) / hs), cy = (int)((ry + py + brd) / hs);
+                cx = min(max(cx, 0), TRr - 2);
+                cy = min(max(cy, 0), TCc - 2);
+                const int16_t *c = p.hf + cx * TCc + cy;
+                h1[i] = c[0]; h2[i] = c[TCc]; h3[i] = c[1];
+            }
+#pragma unroll
+            for (int i = 0; i < HQ; i++) {
+                const int k = k0 + i * kstride;
+                if (live && k < P) B.measured_heights[(size_t)e * P + k] = (float)min(min(h1[i], h2[i]), h3[i]) * vs;
+            }
+        } else {
+            for (int k = k0; k < P; k += kstride) {
+                const float vx = B.height_points[2 * k], vy = B.height_points[2 * k + 1];
+                const float tx = -2.f * yz * vy, ty = 2.f * yz * vx;
+                const float rx = vx + yw * tx - yz * ty, ry = vy + yw * ty + yz * tx;
+                const float h = sample_min3(O, p.hf, rx + px, ry + py);
+                if (live) B.measured_heights[(size_t)e * P + k] = h;
+            }
         }
         if (HOT(o_feet_terrain_info)) {
             const float fx = bc<0>(foot_p), fy = bc<1>(foot_p);
