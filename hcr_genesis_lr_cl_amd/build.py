@@ -35,6 +35,9 @@ def build(force=False, verbose=False):
                "-o", OUT] + [os.path.join(CSRC, s) for s in SRC]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode == 0:
+            if flags is not attempts[0]:
+                import sys
+                print("build.py: compiled with fallback flags " + " ".join(flags), file=sys.stderr)
             break
         err = r.stderr
     if r.returncode != 0:
