@@ -175,3 +175,27 @@ def test_one_control_step_matches_oracle_other_configs(robot, rough, layout):
         else:
             bad = ~np.isclose(got[k], ref, atol=TOL[k] * (3 if rough else 1), rtol=1e-4)
             assert bad.mean() <= (5e-3 if rough else 0.0), (k, bad.sum(), np.abs(got[k] - ref).max())
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("iters", [1, 3])
+def test_other_sweep_counts_match_oracle(go2, layout, iters):
+    """The contact / limit sweep count is an option (cfg.hip.contact_iters): both kernels follow the CPU restatement at
+    1 and 3 sweeps as well as at the default 2."""
+    import copy, torch
+    from hcr_genesis_lr_cl_amd import abi, builders
+    from hcr_genesis_lr_cl_amd.engine import Engine
+    from oracle import oracle as orc
+    from tests.util import random_sim_state, load_state_into_engine, engine_arrays
+    opts = copy.copy(go2["opts"])
+    opts.sim_layout, opts.contact_iters = layout, iters
+    eng = Engine(go2["model"], go2["desc"], opts, builders.make_task_cfg(go2["model"], go2["cfg"]), 256, "cuda:0")
+    st, actions = random_sim_state(go2["model"], go2["cfg"], 256, 13)
+    load_state_into_engine(eng, st)
+    eng.step(abi.PHASE_SIM, torch.from_numpy(actions).cuda(), 0)
+    orc.sim_step(go2["desc"], opts, st, actions, "f64", threads=8)
+    got = engine_arrays(eng, ["dof_pos", "dof_vel", "base_pos", "base_quat", "link_contact_forces"])
+    for k in ("dof_pos", "dof_vel", "base_pos", "base_quat"):
+        np.testing.assert_allclose(got[k], st.arr[k].reshape(256, -1), atol=TOL[k], rtol=1e-4, err_msg=k)
+    err = np.abs(got["link_contact_forces"] - st.arr["link_contact_forces"].reshape(256, -1))
+    assert np.all(err <= 0.3 + 0.01 * np.abs(st.arr["link_contact_forces"].reshape(256, -1))), err.max()
