@@ -20,10 +20,30 @@ sys.path.insert(0, ROOT)
 
 ENVS_PER_GPU = 4096
 BYTES_PER_ENV_STEP = 988          # go2 flat, f32, state read once + written once
-# the other configs: SURVEY 8(d) "roofline env-steps/s at 8 TB/s" column (1.1e9 / 5.4e8 / 5.9e8) turned back into bytes; they
-# assume the whole observation history is rewritten every step, which the sliding window no longer does
-TASK_BYTES = {"go2": BYTES_PER_ENV_STEP, "go2_wtw": 7273, "go2_ee": 14815, "tron1_pf_ee": 13559}
+# SURVEY 8(d) persistent-state floats (read once + written once per control step) of the history-stacked tasks; the
+# observation part of their traffic is derived from the task constants in algorithmic_bytes() below (DESIGN.md "Roofline
+# bookkeeping"): the sliding window writes ONE new frame per stack per step instead of re-materialising the whole history
+STATE_FLOATS = {"go2_wtw": 300, "go2_ee": 320, "tron1_pf_ee": 260}
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
+VALU_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9   # 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz = 39.3e12 non-packed f32 lane-ops/s
+
+
+def algorithmic_bytes(task_name, t):
+    """Bytes one env-step has to move (f32), DESIGN.md "Roofline bookkeeping".  go2: SURVEY 8(d)'s 988 B.  History tasks:
+    SURVEY's state figure + what the sliding-window design writes per step: one new frame per stack into each of the
+    `obs_sets` copies, the labels, and the compaction (read + write of stack-1 frames once every `obs_slack` steps)."""
+    if task_name == "go2":
+        return BYTES_PER_ENV_STEP
+    sets = 2 if int(t.obs_sets) > 1 else 1
+    fl = STATE_FLOATS[task_name]
+    for frame, stack in ((int(t.obs_frame), int(t.obs_stack)), (int(t.priv_frame), int(t.priv_stack))):
+        if frame == 0:
+            continue
+        fl += frame * (sets if stack > 1 else 1)
+        if stack > 1 and int(t.obs_slack) > 0:
+            fl += 2.0 * (stack - 1) * frame * sets / int(t.obs_slack)
+    fl += int(t.num_labels)
+    return 4.0 * fl
 
 
 WORKLOADS = {"go2": "go2_flat, flat-plane contact", "go2_wtw": "go2_wtw, periodic-gait rewards + domain rand, flat plane",
@@ -76,14 +96,48 @@ def host_threads():
     return max(1, min(16, n))
 
 
-def hbm_traffic(workload_key):
-    """HBM bytes per launch from the committed PMC pass (profiles/hbm_traffic.json, written by tools/pmc_traffic.py
-    from separate rocprofv3 --pmc runs with the gfx950 FETCH_SIZE correction applied); None when not collected."""
+def _profile_json(name, workload_key, field):
     try:
-        with open(os.path.join(ROOT, "profiles", "hbm_traffic.json")) as f:
-            return json.load(f).get(workload_key, {}).get("bytes_per_launch")
+        with open(os.path.join(ROOT, "profiles", name)) as f:
+            return json.load(f).get(workload_key, {}).get(field)
     except (OSError, ValueError):
         return None
+
+
+def hbm_traffic(workload_key):
+    """HBM bytes per control step from the committed PMC passes (profiles/hbm_traffic.json, written by tools/pmc_traffic.py
+    from separate rocprofv3 --pmc runs with the gfx950 FETCH_SIZE correction applied); None when not collected."""
+    return _profile_json("hbm_traffic.json", workload_key, "bytes_per_launch")
+
+
+def valu_roofline(workload_key, launch_s):
+    """Second roofline figure (the go2 step sits on the VALU-issue side): SQ_INSTS_VALU per control step from the
+    committed SQ counter pass (profiles/sq_counters.json, tools/pmc_sq.py) x 64 lanes / the live kernel time, against the
+    non-packed f32 issue rate of the chip."""
+    insts = _profile_json("sq_counters.json", workload_key, "SQ_INSTS_VALU")
+    if not insts or launch_s <= 0:
+        return None
+    ach = insts * 64.0 / launch_s
+    return {"bound": "valu-issue", "achieved": ach / 1e12, "peak": VALU_PEAK_LANEOPS / 1e12, "unit": "T lane-ops/s",
+            "frac": ach / VALU_PEAK_LANEOPS, "valu_insts_per_step": insts,
+            "valu_busy_frac": _profile_json("sq_counters.json", workload_key, "valu_active_share"),
+            "wait_frac": _profile_json("sq_counters.json", workload_key, "wait_share")}
+
+
+def spawn_ranks(n):
+    """`python bench.py --gpus N` from a plain shell: start N ranks (one per GPU) with torch.distributed.run as a CHILD process
+    -- this process has not touched the GPU (torch is not even imported yet) -- and pass its exit code on.  Rank 0 of the
+    children prints the JSON line."""
+    import socket
+    import subprocess
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
 
 
 def cpu_baseline(n_envs=4096, steps=800):
@@ -111,6 +165,56 @@ def cpu_baseline(n_envs=4096, steps=800):
                       f"OpenMP {cores} threads; the numpy MDP stack is not included)"}
 
 
+def build_flags():
+    """hipcc flags the loaded liblgsim.so was built with (sidecar written by hcr_genesis_lr_cl_amd/build.py)."""
+    try:
+        with open(os.path.join(ROOT, "hcr_genesis_lr_cl_amd", "csrc", "liblgsim.build.json")) as f:
+            return json.load(f).get("flags")
+    except (OSError, ValueError):
+        return None
+
+
+def launcher_dry_run(args, world, rank):
+    """N > 1 plumbing of this file without a GPU: gloo process group, the same StepGather, barrier + max-over-ranks clock,
+    ONE JSON line on rank 0.  The env step is replaced by writing the rank id into a fake observation."""
+    import torch
+    import torch.distributed as dist
+    from hcr_genesis_lr_cl_amd.distributed import StepGather
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("gloo")
+    n_local, widths = 32, [5, 3]
+    gather = StepGather(n_local, widths, world, "cpu", overlap=not args.sync_gather) if world > 1 else None
+    obs = [torch.full((n_local, w), float(rank)) for w in widths]
+    rew, done = torch.full((n_local,), 0.5 + rank), torch.zeros(n_local, dtype=torch.bool)
+    done[rank] = True
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        out = gather(obs, rew, done) if gather is not None else None
+    if gather is not None:
+        gather.finish()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    ok = True
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        parts, r, d = gather.split(out)
+        for k in range(world):
+            sl = slice(k * n_local, (k + 1) * n_local)
+            ok &= all(bool((p_[sl] == k).all()) for p_ in parts) and bool((r[sl] == 0.5 + k).all()) and int(d[sl].sum()) == 1 and bool(d[k * n_local + k])
+    if rank == 0:
+        print(json.dumps({"metric": "launcher dry run", "value": n_local * world * args.steps / max(elapsed, 1e-9), "unit": "records/s",
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "gather_ok": bool(ok), "data": "synthetic"}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+    return 0 if ok else 1
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -128,12 +232,23 @@ def main():
     ap.add_argument("--ppo-rollout", type=int, default=0, metavar="ITERS",
                     help="also time ITERS rollouts of 24 steps with the go2 actor/critic MLPs (45-512-256-128-12 / -1, ELU) "
                          "run between the steps (SURVEY 8d ii); reported under 'ppo_rollout', never as 'value'")
+    ap.add_argument("--launcher-dry-run", action="store_true",
+                    help="rank plumbing only (spawn, rendezvous, gather, max-over-ranks timing, one JSON line) on the CPU with the "
+                         "gloo backend and a stand-in for the env step: the world-2 test of this file's N > 1 path")
     args = ap.parse_args()
 
-    import torch
+    if "WORLD_SIZE" not in os.environ and args.gpus > 1:
+        sys.exit(spawn_ranks(args.gpus))          # before anything here touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); pass --gpus {world} or run "
+                         f"`python bench.py --gpus {args.gpus}` from a plain shell (it spawns the ranks itself)")
+    if args.launcher_dry_run:
+        return launcher_dry_run(args, world, rank)
+
+    import torch
     dist = None
     if world > 1:
         import torch.distributed as dist
@@ -156,12 +271,16 @@ def main():
     # fixed synthetic action stream: a small bank of N(0,1) batches cycled (clipped +-100 in-kernel)
     bank = [torch.randn(n_local, env.num_actions, generator=g, device=dev) for _ in range(16)]
     from hcr_genesis_lr_cl_amd.distributed import StepGather
-    gather = StepGather(n_local, n_obs, world, dev, overlap=not args.sync_gather) if world > 1 and not args.no_gather else None
+
+    def obs_outputs(out):      # every observation tensor step() returns: 5-tuple (obs, priv) or 6-tuple (features, labels, critic)
+        return [o for o in out[:-3] if o is not None]
+    widths = [int(o.shape[1]) for o in obs_outputs(env.step(bank[0]))]
+    gather = StepGather(n_local, widths, world, dev, overlap=not args.sync_gather) if world > 1 and not args.no_gather else None
 
     def one_step(i):
         out = env.step(bank[i % len(bank)])
         if gather is not None:
-            gather(out[0], out[-3], out[-2])      # 5-tuple (go2, wtw) or 6-tuple (estimator tasks): same tail (rew, done, extras)
+            gather(obs_outputs(out), out[-3], out[-2])      # same tail in both arities: (rew, done, extras)
 
     for i in range(args.warmup):
         one_step(i)
@@ -192,15 +311,16 @@ def main():
         value = total_envs * args.steps / elapsed
         kern_us, kern_n = env._engine.profile_read()
         launch_s = kern_us * 1e-6 if kern_n else dev_ms / 1e3 / args.steps
-        bytes_env = TASK_BYTES[args.task]
+        bytes_env = algorithmic_bytes(args.task, env._engine.task)
         achieved = bytes_env * n_local / launch_s / 1e9
+        wkey = f"{'go2_flat' if args.task == 'go2' else args.task}_{n_local}"
         legs = 2 if args.task == "tron1_pf_ee" else 4
         if n_local * legs * 4 > 2048 * 64:
             layout = f"env_step_kernel<{legs},ALL> (leg-per-lane)"
         elif legs == 4:
             layout = "quad_sim_kernel<4,PRE,POST|RESET> (component-per-lane physics, MDP phases in its tail)"
         else:
-            layout = "quad_sim_kernel<2,PRE,0> (component-per-lane physics; MDP phases follow in env_step_kernel<2,POST|RESET>)"
+            layout = "quad_sim_kernel<2,PRE,0> + env_step_kernel<2,POST|RESET> (component-per-lane physics, then the MDP phases; timed together)"
         out = {
             "metric": "env-steps/sec, Go2 flat 12-DOF, 4096 envs @1/2/4/8 MI355X" if args.task == "go2" else f"env-steps/sec, {args.task}",
             "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
@@ -210,10 +330,12 @@ def main():
                                    f"(4 sub-steps dt=0.005) with synthetic N(0,1) actions",
                        "envs_total": total_envs, "parallelism": f"env-shard x{world}" + ((" + all-gather(obs,rew,done) per step" + ("" if args.sync_gather else ", overlapped with the next step")) if world > 1 and not args.no_gather else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": hbm_traffic(f"go2_flat_{n_local}") if args.task == "go2" else None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": hbm_traffic(wkey),
                          "kernel": layout, "launch_us": launch_s * 1e6, "samples": kern_n,
                          "step_device_us": dev_ms * 1e3 / args.steps,
-                         "algorithmic_bytes_per_launch": bytes_env * n_local},
+                         "algorithmic_bytes_per_launch": bytes_env * n_local,
+                         "valu": valu_roofline(wkey, launch_s)},
+            "build_flags": build_flags(),
         }
         if world == 1 and args.ppo_rollout > 0:
             out["ppo_rollout"] = ppo_rollout(env, args.ppo_rollout, dev)
@@ -225,4 +347,4 @@ def main():
 
 
 if __name__ == "__main__":
-    main()
+    sys.exit(main() or 0)

@@ -80,7 +80,7 @@ class LgRandSlots(C.Structure):
 class LgTaskCfg(C.Structure):
     _fields_ = [
         ("obs_layout", i32), ("num_obs", i32), ("num_priv_obs", i32), ("obs_frame", i32), ("priv_frame", i32),
-        ("obs_stack", i32), ("priv_stack", i32), ("obs_slack", i32),
+        ("obs_stack", i32), ("priv_stack", i32), ("obs_slack", i32), ("obs_sets", i32),
         ("control_dt", f32), ("clip_actions", f32), ("clip_obs", f32), ("max_episode_length", f32),
         ("fail_threshold", f32), ("max_projected_gravity", f32),
         ("resample_steps", i32), ("push_interval", i32), ("max_push_vel_xy", f32), ("heading_command", i32),
@@ -129,7 +129,7 @@ _BUF_FIELDS = [
         "actions", "last_actions", "llast_actions", "commands",
         "feet_air_time", "last_contacts", "episode_length_buf", "fail_buf",
         "reset_buf", "time_out_buf",
-        "rew_buf", "obs_buf", "priv_obs_buf", "labels_buf", "obs_hist", "priv_hist",
+        "rew_buf", "obs_buf", "priv_obs_buf", "labels_buf", "obs_dirty",
         "episode_sums", "episode_done_sums", "episode_done_step", "command_ranges", "task_state", "rand_in")],
 ]
 
@@ -208,13 +208,14 @@ def load_lib():
     lib.lg_step.argtypes = [H, u32, C.c_void_p, i64, C.c_void_p]
     lib.lg_time_steps.argtypes = [H, C.c_void_p, i64, i32, C.c_void_p, C.POINTER(C.c_float)]
     lib.lg_obs_window.argtypes = [H, C.POINTER(i32)]
+    lib.lg_obs_set.argtypes = [H, C.POINTER(i32)]
     lib.lg_profile.argtypes = [H, i32]
     lib.lg_profile_read.argtypes = [H, C.POINTER(C.c_float), C.POINTER(i32)]
     lib.lg_philox.argtypes = [C.POINTER(u32 * 4), C.POINTER(u32 * 2), C.POINTER(u32 * 4)]
     lib.lg_philox.restype = C.c_int
     lib.lg_last_error.restype = C.c_char_p
     lib.lg_abi_version.restype = C.c_int
-    for f in ("lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step", "lg_time_steps", "lg_obs_window", "lg_profile",
+    for f in ("lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step", "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_profile",
               "lg_profile_read"):
         getattr(lib, f).restype = C.c_int
     _LIB = lib
@@ -222,7 +223,7 @@ def load_lib():
 
 
 EXPORTS = ["lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step",
-           "lg_time_steps", "lg_obs_window", "lg_profile", "lg_profile_read", "lg_philox", "lg_last_error", "lg_abi_version"]
+           "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_profile", "lg_profile_read", "lg_philox", "lg_last_error", "lg_abi_version"]
 
 
 def check(rc, lib=None):

@@ -219,7 +219,10 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
     t.env_id_offset = int(env_id_offset)
     # history stacks: slide a window over rows with slack instead of moving the history every step (288 GB of HBM
     # buys bandwidth: one new frame written per step, one compaction every `obs_history_slack` steps)
+    # two copies of the observation outputs, written alternately: the tensors one step() hands out survive the next step()
+    # (rsl_rl holds them across env.step(), ppo.py:103-104; the reference's step() returns fresh tensors, legged_robot.py:48-49)
+    t.obs_sets = int(os.environ.get("LG_OBS_SETS", getattr(cfg.hip, "obs_sets", 2)))              # env: tests only
     if t.obs_stack > 1 or t.priv_stack > 1:
         slack = int(os.environ.get("LG_OBS_SLACK", getattr(cfg.hip, "obs_history_slack", 64)))   # env: tests / timing only
-        t.obs_slack = max(slack, int(t.obs_stack), int(t.priv_stack)) if slack > 0 else 0
+        t.obs_slack = max(slack, int(t.obs_stack) + (t.obs_sets > 1), int(t.priv_stack) + (t.obs_sets > 1)) if slack > 0 else 0
     return t

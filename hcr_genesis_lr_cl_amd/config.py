@@ -51,6 +51,7 @@ def section(*bases, **fields):
 # ---------------------------------------------------------------------------------------------
 # legged_robot_config.py:3-262 (defaults) -- only fields the hot path reads
 class LeggedRobotCfg(Section):
+    seed = 1                       # legged_robot_config.py:275
     env = section(
         num_envs=4096, num_observations=48, num_privileged_obs=None, num_actions=12,
         send_timeouts=True, episode_length_s=20, env_spacing=1.0, fail_to_terminal_time_s=0.1, debug=False)
@@ -107,7 +108,7 @@ class LeggedRobotCfg(Section):
     # engine constants of this backend (no counterpart in the reference: Genesis' soft-constraint
     # parameters are internal to genesis-world).  See DESIGN.md "Contact model".
     hip = section(contact_stiffness=4.0e4, contact_damping=4.0e2, joint_limit_stiffness=5.0e3,
-                  joint_limit_damping=5.0e1, contact_iters=2, sim_layout=0, obs_history_slack=64, contact_margin=0.02, limit_margin=0.2,
+                  joint_limit_damping=5.0e1, contact_iters=2, sim_layout=0, obs_history_slack=64, obs_sets=2, contact_margin=0.02, limit_margin=0.2,
                   max_base_lin_vel=50.0, max_base_ang_vel=40.0, joint_vel_clamp=2.0, seed=1)
 
 

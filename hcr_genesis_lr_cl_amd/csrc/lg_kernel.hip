@@ -29,7 +29,7 @@
 #include <vector>
 #include <hip/hip_ext.h>
 
-#define LG_ABI_VERSION 1
+#define LG_ABI_VERSION 2
 #define BLOCK 64
 #define MODEL_STG 4   /* uint4 per thread to stage the model table: 4 * 64 * 16 B = 4 KiB >= sizeof(LgModelDesc) */
 static_assert(sizeof(LgModelDesc) <= MODEL_STG * BLOCK * 16, "model table does not fit the staging image");
@@ -46,6 +46,7 @@ struct LgHot {
     int32_t obs_stack;
     int32_t priv_stack;
     int32_t obs_slack;
+    int32_t obs_sets;
     int32_t reward_mask;   // bit k: reward term k has a non-zero scale (one scalar test per term instead of an LDS round trip)
     float control_dt;
     float clip_actions;
@@ -164,6 +165,7 @@ static void fill_hot(LgHot &H, const LgTaskCfg &t, const LgSimOptions &o, const 
     H.obs_stack = t.obs_stack;
     H.priv_stack = t.priv_stack;
     H.obs_slack = t.obs_slack;
+    H.obs_sets = t.obs_sets > 1 ? 2 : 1;
     H.reward_mask = 0;
     for (int i = 0; i < LG_R_COUNT; i++) if (t.reward_scales[i] != 0.f) H.reward_mask |= (int32_t)(1u << i);
     H.control_dt = t.control_dt;
@@ -315,6 +317,7 @@ struct KParams {
              int joint_axis[3];   // per joint index: 0/1/2 if that joint's axis is +-e_x/e_y/e_z on every leg, else -1 (lg_quad.h joint_rot)
     } k;
     int obs_win;         // first frame of the observation window this launch writes (sliding history, LgTaskCfg.obs_slack)
+    int obs_set;         // copy of obs_buf / priv_obs_buf / labels_buf this launch writes (LgTaskCfg.obs_sets)
 };
 
 #ifdef LG_DBG_STAMPS
@@ -571,7 +574,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
 #pragma unroll
     for (int j = 0; j < 3; j++) q0l[j] = O->default_dof_pos[d0 + j];
     float cmd0 = 0.f, cmd1 = 0.f, cmd2 = 0.f, cmd3 = 0.f, air = 0.f;
-    int ep_len = 0, last_contact = 0;
+    int ep_len = 0, last_contact = 0, dirty_prev = 0;
     long long fail_buf = 0;
     float es[LG_R_COUNT];
 #pragma unroll
@@ -608,6 +611,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         fail_buf = B.fail_buf[e];
         air = B.feet_air_time[e * F + foot_slot];
         last_contact = B.last_contacts[e * F + foot_slot];
+        if (DO_RESET && B.obs_dirty) dirty_prev = B.obs_dirty[e];
         origin_pre = ld3(B.env_origins + 3 * e);
         if (!FUSED) crv = reinterpret_cast<const int *>(B.command_ranges)[min(vlane, LG_CMD_RANGE_FLOATS - 1)];
         if (lead) {
@@ -661,6 +665,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         sSt[c++][t] = __int_as_float(ep_len); sSt[c++][t] = __int_as_float((int)fail_buf); sSt[c++][t] = air;
         sSt[c++][t] = __int_as_float(last_contact);
         sSt[c++][t] = origin_pre.x; sSt[c++][t] = origin_pre.y; sSt[c++][t] = origin_pre.z;
+        sSt[c++][t] = __int_as_float(dirty_prev);
     }
     __syncthreads();
     STAMP(2);
@@ -1271,6 +1276,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     const auto hc_obs_frame = HOT(obs_frame);
     const auto hc_obs_stack = HOT(obs_stack);
     const auto hc_obs_slack = HOT(obs_slack);
+    const auto hc_obs_sets = HOT(obs_sets);
     const auto hc_priv_frame = HOT(priv_frame);
     const auto hc_priv_stack = HOT(priv_stack);
     const auto hc_num_obs = HOT(num_obs);
@@ -1306,6 +1312,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         ep_len = __float_as_int(SS(c++)); fail_buf = (long long)__float_as_int(SS(c++)); air = SS(c++);
         last_contact = __float_as_int(SS(c++));
         origin_pre.x = SS(c++); origin_pre.y = SS(c++); origin_pre.z = SS(c++);
+        dirty_prev = __float_as_int(SS(c++));
     }
 
     // ======================= MDP: legged_robot.py:55-168, 300-334 ============================
@@ -1785,34 +1792,55 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         //      kept oldest -> newest inside obs_buf / priv_obs_buf themselves and shifted in place.
         const int FR = hc_obs_frame, PF = hc_priv_frame, ST = hc_obs_stack, PST = hc_priv_stack;
         const int SL = hc_obs_slack;
-        float *o = B.obs_buf + (size_t)e * (hc_num_obs + SL * FR) + (size_t)p.obs_win * FR;
-        float *pv = hc_num_priv_obs > 0 ? B.priv_obs_buf + (size_t)e * (hc_num_priv_obs + SL * PF) + (size_t)p.obs_win * PF : nullptr;
+        // Two copies ("sets") of the observation buffers, written alternately (LgTaskCfg.obs_sets): what the previous
+        // launch handed to the caller is not touched by this one.  `cs` = this launch's set, `xs` = the other one.
+        const size_t orow = (size_t)(hc_num_obs + SL * FR), prow = (size_t)(hc_num_priv_obs + SL * PF);
+        const bool two = hc_obs_sets > 1;
+        const int cs = two ? p.obs_set : 0, xs = two ? 1 - cs : 0;
+        float *const oset_c = B.obs_buf + (size_t)cs * N * orow, *const oset_x = B.obs_buf + (size_t)xs * N * orow;
+        float *const pset_c = hc_num_priv_obs > 0 ? B.priv_obs_buf + (size_t)cs * N * prow : nullptr;
+        float *const pset_x = hc_num_priv_obs > 0 ? B.priv_obs_buf + (size_t)xs * N * prow : nullptr;
+        float *o = oset_c + (size_t)e * orow + (size_t)p.obs_win * FR;
+        float *pv = pset_c ? pset_c + (size_t)e * prow + (size_t)p.obs_win * PF : nullptr;
         const float co = hc_clip_obs;
         if (SL > 0) {
             // sliding window: the previous frames are already where this window expects them; only an env that was just
             // reset blanks its history (go2_wtw.py:174-178).  All active lanes of the wave blank each such env together:
             // left to the env's own 2-4 lanes that is up to 750 stores per lane (tron1: 9 x 31 + 9 x 134 floats), and the
-            // biped resets often
-            unsigned long long rm = __builtin_amdgcn_ballot_w64(live && reset && leg == 0);
+            // biped resets often.  With two sets an env reset at the PREVIOUS observation launch still carries its old
+            // history in this set (that launch blanked the other one): everything older than the frame that launch
+            // wrote goes now (`dirty`).
             const int nl = FUSED ? 16 : BLOCK;
-            while (rm) {
-                const int bit = __builtin_ctzll(rm);
-                rm &= rm - 1;
-                const int er = (vtid - vlane + bit) / LEGS;
-                float *orow = B.obs_buf + (size_t)er * (hc_num_obs + SL * FR) + (size_t)p.obs_win * FR;
-                for (int i = vlane; i < (ST - 1) * FR; i += nl) orow[i] = 0.f;
-                if (hc_num_priv_obs > 0) {
-                    float *prow = B.priv_obs_buf + (size_t)er * (hc_num_priv_obs + SL * PF) + (size_t)p.obs_win * PF;
-                    for (int i = vlane; i < (PST - 1) * PF; i += nl) prow[i] = 0.f;
+            auto blank = [&](unsigned long long rm, int keep) {   // zero all but the newest `keep` frames of the window
+                while (rm) {
+                    const int bit = __builtin_ctzll(rm);
+                    rm &= rm - 1;
+                    const int er = (vtid - vlane + bit) / LEGS;
+                    float *orw = oset_c + (size_t)er * orow + (size_t)p.obs_win * FR;
+                    for (int i = vlane; i < (ST - keep) * FR; i += nl) orw[i] = 0.f;
+                    if (pset_c) {
+                        float *prw = pset_c + (size_t)er * prow + (size_t)p.obs_win * PF;
+                        for (int i = vlane; i < (PST - keep) * PF; i += nl) prw[i] = 0.f;
+                    }
                 }
-            }
-        } else if (live) {   // this lane's columns move one frame towards the past (zeros after a reset)
+            };
+            blank(__builtin_amdgcn_ballot_w64(live && reset && leg == 0), 1);
+            if (two) blank(__builtin_amdgcn_ballot_w64(live && !reset && dirty_prev != 0 && leg == 0), 2);
+        } else if (live) {   // this lane's columns move one frame towards the past (zeros after a reset); with two sets the
+                             // previous observation is read from the other one
+            const float *so = oset_x + (size_t)e * orow;
             for (int f = 0; f + 1 < ST; f++)
-                for (int i = leg; i < FR; i += LEGS) o[f * FR + i] = reset ? 0.f : o[(f + 1) * FR + i];
-            if (pv)
+                for (int i = leg; i < FR; i += LEGS) o[f * FR + i] = reset ? 0.f : so[(f + 1) * FR + i];
+            if (pv) {
+                const float *sp = pset_x + (size_t)e * prow;
                 for (int f = 0; f + 1 < PST; f++)
-                    for (int i = leg; i < PF; i += LEGS) pv[f * PF + i] = reset ? 0.f : pv[(f + 1) * PF + i];
+                    for (int i = leg; i < PF; i += LEGS) pv[f * PF + i] = reset ? 0.f : sp[(f + 1) * PF + i];
+            }
         }
+        // the frame written now also goes into the other set's row (same frame index): that set's window covers it at the
+        // next launch
+        float *on2 = (two && SL > 0 && ST > 1) ? oset_x + (size_t)e * orow + (size_t)p.obs_win * FR + (size_t)(ST - 1) * FR : nullptr;
+        float *pn2 = (two && SL > 0 && PST > 1 && pset_x) ? pset_x + (size_t)e * prow + (size_t)p.obs_win * PF + (size_t)(PST - 1) * PF : nullptr;
         float *on = o + (ST - 1) * FR, *pn = pv ? pv + (PST - 1) * PF : nullptr;
         const bool nz = hc_add_noise != 0;
         const int ns = HOT(slots.noise);
@@ -1860,11 +1888,13 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             }
         }
         auto put = [&](int idx, float v, float u, float nscale) {   // critic copy of the frame is noise-free
-            if (pn) pn[idx] = clampf(v, -co, co);
+            if (pn) { const float c = clampf(v, -co, co); pn[idx] = c; if (pn2) pn2[idx] = c; }
             if (nz) v += (2.f * u - 1.f) * nscale;
-            on[idx] = clampf(v, -co, co);
+            const float c = clampf(v, -co, co);
+            on[idx] = c;
+            if (on2) on2[idx] = c;
         };
-        auto putp = [&](int idx, float v) { pn[idx] = clampf(v, -co, co); };
+        auto putp = [&](int idx, float v) { const float c = clampf(v, -co, co); pn[idx] = c; if (pn2) pn2[idx] = c; };
         if (live) {
 #pragma unroll
             for (int j = 0; j < 3; j++) {
@@ -1904,7 +1934,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             // critic frame (go2_ee.py:21-48): obs 45 | DR 31 | contact states K | heights P
             const int K = __popc(M->state_link_mask);
             const int l0 = foot_link - 3;
-            float *lab = B.labels_buf + (size_t)e * hc_num_labels;
+            float *lab = B.labels_buf + ((size_t)cs * N + e) * hc_num_labels;
             if (live) {
 #pragma unroll
                 for (int j = 0; j < 3; j++) {
@@ -1952,7 +1982,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             // gait F | contact states K | heights P | normals 3F | clip(foot_z - h9) 9F.  labels: v_b 3 | K | F | 3F
             const int K = __popc(M->state_link_mask);
             const int l0 = foot_link - 3;
-            float *lab = B.labels_buf + (size_t)e * hc_num_labels;
+            float *lab = B.labels_buf + ((size_t)cs * N + e) * hc_num_labels;
             const float ang = 6.283185307179586f * (phi + theta);
             const int oDR = FR, oG = FR + 7 + 2 * A + 3, oK = oG + F, oH = oK + K, oN = oH + P, oR = oN + 3 * F;
             if (live) {
@@ -2037,6 +2067,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         B.episode_length_buf[e] = ep_len;
         B.fail_buf[e] = fail_buf;
         B.reset_buf[e] = reset ? 1 : 0;
+        if (DO_RESET && B.obs_dirty) B.obs_dirty[e] = reset ? 1 : 0;
         B.time_out_buf[e] = time_out ? 1 : 0;
         B.rew_buf[e] = total;
         if (DO_POST || (DO_RESET && reset)) {
@@ -2070,6 +2101,7 @@ struct LgEngine {
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     LgHot hot;           // host copy of the hot block (upload_hot)
     int obs_win = 0;     // window of the latest stacked observation (obs_slack > 0)
+    int obs_set = 0;     // copy of the observation buffers the latest observation launch wrote (obs_sets == 2)
     // bounded run-ahead: the host never gets more than ~128 lg_step calls ahead of the device (see lg_step)
     hipEvent_t ra_ev[4] = {nullptr, nullptr, nullptr, nullptr}; long long ra_calls = 0;
     // sampling timer of the physics kernel (lg_profile)
@@ -2125,6 +2157,8 @@ extern "C" int lg_create(const LgModelDesc *model, const LgSimOptions *opts, con
     if (opts->contact_iters < 1 || opts->contact_iters > 16) return fail("lg_create: contact_iters must be in [1,16]");
     if (task->obs_slack < 0 || (task->obs_slack > 0 && (task->obs_slack < task->obs_stack || task->obs_slack < task->priv_stack)))
         return fail("lg_create: obs_slack must be 0 or at least as large as the history stacks");
+    if (task->obs_sets > 1 && task->obs_slack > 0 && (task->obs_slack <= task->obs_stack || task->obs_slack <= task->priv_stack))
+        return fail("lg_create: with two observation sets obs_slack must exceed the history stacks");
     LgEngine *h = new LgEngine();
     h->model = *model; h->opts = *opts; h->task = *task;
     memset(&h->bufs, 0, sizeof(h->bufs));
@@ -2199,6 +2233,14 @@ static int prof_begin(LgEngine *h, hipStream_t st) {
 #define LG_LAUNCH(pi, kern, grid_) do { \
         if ((pi) >= 0) hipExtLaunchKernelGGL(kern, grid_, block, 0, st, h->prof_ev[2 * (pi)], h->prof_ev[2 * (pi) + 1], 0, p); \
         else hipLaunchKernelGGL(kern, grid_, block, 0, st, p); } while (0)
+// a control step made of two launches (biped: physics, then the MDP phases): begin timestamp of the first, end timestamp of
+// the second, so that the sample is the whole step including the gap between the two
+#define LG_LAUNCH_FIRST(pi, kern, grid_) do { \
+        if ((pi) >= 0) hipExtLaunchKernelGGL(kern, grid_, block, 0, st, h->prof_ev[2 * (pi)], nullptr, 0, p); \
+        else hipLaunchKernelGGL(kern, grid_, block, 0, st, p); } while (0)
+#define LG_LAUNCH_LAST(pi, kern, grid_) do { \
+        if ((pi) >= 0) hipExtLaunchKernelGGL(kern, grid_, block, 0, st, nullptr, h->prof_ev[2 * (pi) + 1], 0, p); \
+        else hipLaunchKernelGGL(kern, grid_, block, 0, st, p); } while (0)
 
 template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *actions, int64_t counter, hipStream_t st) {
     KParams p;
@@ -2228,19 +2270,26 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
     const int threads = h->bufs.n_envs * LEGS;
     dim3 grid((threads + BLOCK - 1) / BLOCK), block(BLOCK);
     p.obs_win = 0;
-    if ((ph & LG_PHASE_RESET) && h->task.obs_slack > 0) {
-        // the observation written by this launch lives one frame further; out of slack -> compact first (source and
-        // destination ranges are disjoint because lg_create enforces slack >= stack)
+    p.obs_set = h->obs_set;
+    if (ph & LG_PHASE_RESET) {
         const LgTaskCfg &t = h->task;
-        if (h->obs_win >= t.obs_slack) {
-            const int n = h->bufs.n_envs;
-            if (t.obs_stack > 1)
-                hipLaunchKernelGGL(obs_compact_kernel, dim3(1024), dim3(256), 0, st, h->bufs.obs_buf, n, (t.obs_stack + t.obs_slack) * t.obs_frame, t.obs_frame, t.obs_stack, h->obs_win);
-            if (t.num_priv_obs > 0 && t.priv_stack > 1)
-                hipLaunchKernelGGL(obs_compact_kernel, dim3(1024), dim3(256), 0, st, h->bufs.priv_obs_buf, n, (t.priv_stack + t.obs_slack) * t.priv_frame, t.priv_frame, t.priv_stack, h->obs_win);
-            h->obs_win = 0;
+        const int sets = t.obs_sets > 1 ? 2 : 1;
+        if (sets == 2) p.obs_set = (h->obs_set ^= 1);      // this launch writes the copy the caller is NOT holding
+        if (t.obs_slack > 0) {
+            // the observation written by this launch lives one frame further; out of slack -> compact first (source and
+            // destination ranges are disjoint because lg_create enforces slack >= stack, and with two sets the window the
+            // caller still holds, [slack, slack + stack), is clear of everything written here because slack >= stack + 1).
+            // Both sets are compacted together: they are one allocation of sets * n rows
+            if (h->obs_win >= t.obs_slack) {
+                const int n = h->bufs.n_envs * sets;
+                if (t.obs_stack > 1)
+                    hipLaunchKernelGGL(obs_compact_kernel, dim3(1024), dim3(256), 0, st, h->bufs.obs_buf, n, (t.obs_stack + t.obs_slack) * t.obs_frame, t.obs_frame, t.obs_stack, h->obs_win);
+                if (t.num_priv_obs > 0 && t.priv_stack > 1)
+                    hipLaunchKernelGGL(obs_compact_kernel, dim3(1024), dim3(256), 0, st, h->bufs.priv_obs_buf, n, (t.priv_stack + t.obs_slack) * t.priv_frame, t.priv_frame, t.priv_stack, h->obs_win);
+                h->obs_win = 0;
+            }
+            p.obs_win = ++h->obs_win;
         }
-        p.obs_win = ++h->obs_win;
     }
     // physics layout (lg_quad.h): one vector component per lane while the batch cannot fill the SIMDs with one leg per
     // lane; the MDP phases then follow in a second launch on the same stream
@@ -2261,12 +2310,14 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
         const bool fuse = LEGS == 4 && pre && rest != 0;
         if (fuse && rest == (LG_PHASE_POST | LG_PHASE_RESET)) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET>), qgrid);
         else if (fuse && rest == LG_PHASE_POST) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST>), qgrid);
+        else if (pre && rest) LG_LAUNCH_FIRST(pi, (quad_sim_kernel<LEGS, true, 0u>), qgrid);
         else if (pre) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, 0u>), qgrid);
+        else if (rest) LG_LAUNCH_FIRST(pi, (quad_sim_kernel<LEGS, false, 0u>), qgrid);
         else LG_LAUNCH(pi, (quad_sim_kernel<LEGS, false, 0u>), qgrid);
         HIPCHK(hipGetLastError());
         if (!fuse && rest) {
-            if (rest == (LG_PHASE_POST | LG_PHASE_RESET)) hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET>), grid, block, 0, st, p);
-            else if (rest == LG_PHASE_POST) hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST>), grid, block, 0, st, p);
+            if (rest == (LG_PHASE_POST | LG_PHASE_RESET)) LG_LAUNCH_LAST(pi, (env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET>), grid);
+            else if (rest == LG_PHASE_POST) LG_LAUNCH_LAST(pi, (env_step_kernel<LEGS, LG_PHASE_POST>), grid);
             else return fail("lg_step: unsupported phase combination");
         }
         HIPCHK(hipGetLastError());
@@ -2301,6 +2352,7 @@ static int check_mdp_bufs(const LgEngine *h, uint32_t ph) {
         REQ(episode_sums); REQ(episode_done_sums); REQ(episode_done_step); REQ(command_ranges); REQ(rand_push_vels);
         REQ(friction_values); REQ(added_base_mass); REQ(base_com_bias); REQ(kp_scale); REQ(kd_scale);
 #undef REQ
+        if (h->task.obs_sets > 1 && h->task.obs_slack > 0 && !b.obs_dirty) return fail("lg_step: two observation sets with history stacks need buffer obs_dirty");
     }
     return 0;
 }
@@ -2346,6 +2398,12 @@ extern "C" int lg_philox(const uint32_t counter[4], const uint32_t key[2], uint3
 extern "C" int lg_obs_window(LgHandle h, int32_t *first_frame) {
     if (!h || !first_frame) return fail("lg_obs_window: null argument");
     *first_frame = h->task.obs_slack > 0 ? h->obs_win : 0;
+    return 0;
+}
+
+extern "C" int lg_obs_set(LgHandle h, int32_t *set) {
+    if (!h || !set) return fail("lg_obs_set: null argument");
+    *set = h->task.obs_sets > 1 ? h->obs_set : 0;
     return 0;
 }
 

@@ -330,6 +330,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     const int32_t GAS *const k_episode_length_buf = KB(const int32_t GAS *, episode_length_buf);
     const int64_t GAS *const k_fail_buf = KB(const int64_t GAS *, fail_buf);
     const uint8_t GAS *const k_last_contacts = KB(const uint8_t GAS *, last_contacts);
+    const uint8_t GAS *const k_obs_dirty = KB(const uint8_t GAS *, obs_dirty);
     const float GAS *const k_actions_in = KPTR(const float GAS *, offsetof(KParams, actions));
     const LgSimOptions GAS *kO = KPTR(const LgSimOptions GAS *, offsetof(KParams, O));
     const LgTaskCfg GAS *kT = KPTR(const LgTaskCfg GAS *, offsetof(KParams, T));
@@ -388,6 +389,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         wsv[c2++] = k_feet_air_time[eL * F + fsL];
         wsv[c2++] = __int_as_float((int)k_last_contacts[eL * F + fsL]);
         wsv[c2++] = k_env_origins[3 * eL]; wsv[c2++] = k_env_origins[3 * eL + 1]; wsv[c2++] = k_env_origins[3 * eL + 2];
+        wsv[c2++] = __int_as_float(((MPH & LG_PHASE_RESET) && k_obs_dirty) ? (int)k_obs_dirty[eL] : 0);
     }
 
     asm volatile("" ::: "memory");
@@ -400,7 +402,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
 #pragma unroll
             for (int k = 0; k < LG_R_COUNT; k++) sStF[k * 16 + threadIdx.x] = (leadL && ((rm >> k) & 1u)) ? wsv[k] : 0.f;
 #pragma unroll
-            for (int k = LG_R_COUNT; k < NST - 2; k++) sStF[k * 16 + threadIdx.x] = wsv[k];
+            for (int k = LG_R_COUNT; k < NST - 1; k++) sStF[k * 16 + threadIdx.x] = wsv[k];
         }
     }
     sMraw[threadIdx.x] = stg0; sMraw[threadIdx.x + BLOCK] = stg1; sMraw[threadIdx.x + 2 * BLOCK] = stg2; sMraw[threadIdx.x + 3 * BLOCK] = stg3;

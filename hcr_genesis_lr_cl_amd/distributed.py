@@ -33,20 +33,27 @@ def global_mean(local_sum, local_count):
 
 
 class StepGather:
-    """Packs one step's outputs into a (n_local, obs+2) record and all-gathers it.
+    """Packs one step's outputs -- every observation tensor step() returned (actor obs; privileged / critic obs and
+    estimator labels where the task has them), reward and done -- into one (n_local, sum(widths) + 2) float record and
+    all-gathers it.
 
     `overlap=True` (bench.py at N > 1): the collective of step t is issued asynchronously and only awaited when its
     double-buffered record is about to be reused at step t+2 (or in `finish()`), so the RCCL latency hides behind the next
     step's kernel.  That is the data flow SURVEY 8e recommends -- every rank steps its own envs with its own copy of the
     policy, the gathered records feed the learner once the rollout is over -- and it keeps one all-gather per step on the
     wire.  `__call__` then returns the buffer the gather is landing in; read it after `finish()` (or after the call two
-    steps later)."""
+    steps later).
 
-    def __init__(self, n_local, num_obs, world, device, dtype=torch.float32, overlap=False):
-        self.world, self.num_obs, self.overlap = world, num_obs, bool(overlap) and world > 1
+    The inputs may be strided views (sliding history windows) and `done` a bool tensor: the packing is one `torch.cat`
+    into the float record."""
+
+    def __init__(self, n_local, widths, world, device, dtype=torch.float32, overlap=False):
+        self.widths = [int(widths)] if isinstance(widths, int) else [int(w) for w in widths]
+        self.num_obs = sum(self.widths)
+        self.world, self.overlap = world, bool(overlap) and world > 1
         nb = 2 if self.overlap else 1
-        self.recs = [torch.empty(n_local, num_obs + 2, device=device, dtype=dtype) for _ in range(nb)]
-        self.outs = [torch.empty(world * n_local, num_obs + 2, device=device, dtype=dtype) if world > 1 else r for r in self.recs]
+        self.recs = [torch.empty(n_local, self.num_obs + 2, device=device, dtype=dtype) for _ in range(nb)]
+        self.outs = [torch.empty(world * n_local, self.num_obs + 2, device=device, dtype=dtype) if world > 1 else r for r in self.recs]
         self.work = [None] * nb
         self.t = 0
         self.rec, self.out = self.recs[0], self.outs[0]
@@ -59,8 +66,9 @@ class StepGather:
             self.work[i] = None
         r = self.rec = self.recs[i]
         self.out = self.outs[i]
-        # one fused packing kernel on the compute stream (three slice copies cost three launches per step)
-        torch.cat((obs, rew.unsqueeze(1), done.unsqueeze(1)), dim=1, out=r)
+        parts = [obs] if torch.is_tensor(obs) else list(obs)
+        # one fused packing kernel on the compute stream (slice copies cost a launch each per step)
+        torch.cat((*parts, rew.unsqueeze(1), done.unsqueeze(1).to(r.dtype)), dim=1, out=r)
         if self.world > 1:
             import torch.distributed as dist
             if self.overlap:
@@ -77,5 +85,10 @@ class StepGather:
                 self.work[i] = None
 
     def split(self, out=None):
+        """-> ([obs tensors in the order given], rew, done) views of a gathered record."""
         o = self.out if out is None else out
-        return o[:, :self.num_obs], o[:, self.num_obs], o[:, self.num_obs + 1] > 0.5
+        parts, c = [], 0
+        for w in self.widths:
+            parts.append(o[:, c:c + w])
+            c += w
+        return parts, o[:, self.num_obs], o[:, self.num_obs + 1] > 0.5

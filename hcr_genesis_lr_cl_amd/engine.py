@@ -55,20 +55,26 @@ def buffer_specs(A, L, F, K, P, num_obs, num_priv, num_labels, n_slots, hist, pr
 
 
 class _Buffers(dict):
-    """name -> device tensor.  History-stacked observations live in rows with slack frames and are exposed as the
-    window of the most recent step (LgTaskCfg.obs_slack, lg_obs_window): `buf["obs_buf"]` is that (N, stack*frame)
-    strided view, `buf.raw("obs_buf")` the whole allocation the C ABI is bound to."""
+    """name -> device tensor.  The observation outputs (obs_buf, priv_obs_buf, labels_buf) exist in
+    `LgTaskCfg.obs_sets` copies written alternately, and history-stacked ones live in rows with slack frames
+    (LgTaskCfg.obs_slack): `buf["obs_buf"]` is the (N, stack*frame) view of the copy and window the most recent
+    observation launch wrote (lg_obs_set, lg_obs_window), `buf.raw("obs_buf")` the whole (sets, N, row) allocation
+    the C ABI is bound to."""
 
     def __init__(self, *a, **k):
         super().__init__(*a, **k)
         self.windows = {}     # name -> (frame width, stack)
+        self.sets = set()     # names allocated as (obs_sets, N, ...)
         self.first_frame = lambda: 0
+        self.current_set = lambda: 0
 
     def raw(self, k):
         return dict.__getitem__(self, k)
 
     def __getitem__(self, k):
         t = dict.__getitem__(self, k)
+        if k in self.sets:
+            t = t[self.current_set()]
         w = self.windows.get(k)
         if w is None:
             return t
@@ -94,6 +100,7 @@ class Engine:
         torch.cuda.set_device(self.device)
         self.model, self.desc, self.opts, self.task = model, desc, opts, task
         self.n = int(n_envs)
+        self._obs_slot = (0, 0)
         A, L, F = model.n_dof, model.n_links, model.n_legs
         K = bin(desc.state_link_mask).count("1")
         P = int(opts.n_height_points)
@@ -106,8 +113,14 @@ class Engine:
             specs["obs_buf"] = (((task.obs_stack + SL) * task.obs_frame,), torch.float32)
             if task.num_priv_obs:
                 specs["priv_obs_buf"] = (((task.priv_stack + SL) * task.priv_frame,), torch.float32)
-        self.buf = _Buffers({k: torch.zeros((self.n,) + tuple(shape), dtype=dt, device=self.device)
+        sets = 2 if int(task.obs_sets) > 1 else 1
+        outs = [k for k in ("obs_buf", "priv_obs_buf", "labels_buf") if k in specs]
+        if sets == 2 and SL:
+            specs["obs_dirty"] = ((), torch.uint8)
+        self.buf = _Buffers({k: torch.zeros(((sets,) if k in outs else ()) + (self.n,) + tuple(shape), dtype=dt, device=self.device)
                              for k, (shape, dt) in specs.items()})
+        self.buf.sets = set(outs)
+        self.buf.current_set = self.obs_set
         if SL:
             self.buf.windows["obs_buf"] = (int(task.obs_frame), int(task.obs_stack))
             if task.num_priv_obs:
@@ -165,19 +178,32 @@ class Engine:
             a = actions.data_ptr()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         abi.check(self.lib.lg_step(self.handle, phases, a, int(counter), stream), self.lib)
+        if phases & abi.PHASE_RESET:
+            self._refresh_obs_slot()
 
     def time_steps(self, actions, first_counter, count):
         ms = C.c_float()
         stream = torch.cuda.current_stream(self.device).cuda_stream
         abi.check(self.lib.lg_time_steps(self.handle, actions.data_ptr(), int(first_counter), int(count), stream,
                                          C.byref(ms)), self.lib)
+        self._refresh_obs_slot()
         return ms.value
+
+    def _refresh_obs_slot(self):
+        """Which copy / window of the observation buffers the latest observation launch wrote (cached: the views are
+        looked up on every step)."""
+        w, s_ = C.c_int32(), C.c_int32()
+        abi.check(self.lib.lg_obs_window(self.handle, C.byref(w)), self.lib)
+        abi.check(self.lib.lg_obs_set(self.handle, C.byref(s_)), self.lib)
+        self._obs_slot = (s_.value, w.value)
 
     def obs_window(self):
         """First frame of the window holding the latest stacked observation (0 without history slack)."""
-        w = C.c_int32()
-        abi.check(self.lib.lg_obs_window(self.handle, C.byref(w)), self.lib)
-        return w.value
+        return self._obs_slot[1]
+
+    def obs_set(self):
+        """Copy of the observation buffers the latest observation launch wrote (0 with a single set)."""
+        return self._obs_slot[0]
 
     def profile(self, stride):
         """Time the physics kernel of every `stride`-th step with HIP events (0 = off)."""

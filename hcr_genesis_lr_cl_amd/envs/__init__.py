@@ -11,10 +11,23 @@ TASKS = {"go2": (GO2, GO2Cfg), "go2_wtw": (GO2WTW, GO2WTWCfg), "go2_ee": (Go2EE,
          "tron1_pf_ee": (TRON1PF_EE, TRON1PFEECfg)}
 
 
+def set_seed(seed):
+    """helpers.py:36-46 (the heightfield generator draws from np.random, like the reference's)."""
+    import os
+    import random
+    import numpy as np
+    import torch
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    os.environ["PYTHONHASHSEED"] = str(seed)
+
+
 def make_env(name, num_envs=None, device="cuda:0", **kw):
-    """task_registry.make_env equivalent (task_registry.py:35-72) for this backend."""
+    """task_registry.make_env equivalent (task_registry.py:35-72) for this backend, including its set_seed(cfg.seed)."""
     cls, cfg_cls = TASKS[name]
     cfg = cfg_cls()
     if num_envs is not None:
         cfg.env.num_envs = int(num_envs)
+    set_seed(int(cfg.seed))
     return cls(cfg, None, device, True, **kw), cfg

@@ -15,10 +15,10 @@ class LeggedRobotEE(LeggedRobot):
         self.num_estimator_features = cfg.env.num_estimator_features
         self.num_estimator_labels = cfg.env.num_estimator_labels
 
-    def _init_buffers(self):
-        super()._init_buffers()
-        b = self._engine.buf
-        self.estimator_labels_buf = b["labels_buf"]
+    # the observation outputs alternate between two copies (engine._Buffers): look them up per access
+    @property
+    def estimator_labels_buf(self):
+        return self._engine.buf["labels_buf"]
 
     @property
     def estimator_features_buf(self):

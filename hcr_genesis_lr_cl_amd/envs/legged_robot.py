@@ -16,7 +16,7 @@ counter-based Philox stream keyed on (seed, global env id, step, slot).
 """
 from __future__ import annotations
 
-from collections.abc import Mapping
+from collections.abc import MutableMapping
 
 import numpy as np
 import torch
@@ -26,17 +26,30 @@ from .. import config as cfgmod
 from ..simulator import HipSimulator
 
 
-class _EpisodeExtras(Mapping):
+class _EpisodeExtras(MutableMapping):
     """Lazy ``extras["episode"]`` (legged_robot.py:128-138): per-term mean of the episode sums over the envs
     reset at one step, divided by episode_length_s.  The kernel snapshots every resetting env's sums and the
     step index; the means are formed on access, so the hot loop issues no extra launches and no atomics.
     When a step had no reset the reference leaves the previous dict in place: the same happens here by
     falling back to the most recent step (<= this one) that had resets.  (An env that resets twice before
-    the dict is read contributes only its latest episode -- logging only.)"""
+    the dict is read contributes only its latest episode -- logging only.)
+    The reference's dict is a plain one and its runner writes into it (on_policy_runner.py:182-185 rebinds
+    ``ep_info[key]`` while logging): writes land in a local overlay, deletes hide a key."""
 
     def __init__(self, env, step):
         self._env, self._step = env, step
         self._mask = None
+        self._over, self._gone = {}, set()
+
+    def __setitem__(self, key, value):
+        self._over[key] = value
+        self._gone.discard(key)
+
+    def __delitem__(self, key):
+        if key not in self:
+            raise KeyError(key)
+        self._over.pop(key, None)
+        self._gone.add(key)
 
     def _ids(self):
         if self._mask is None:
@@ -49,6 +62,10 @@ class _EpisodeExtras(Mapping):
         return self._mask
 
     def __getitem__(self, key):
+        if key in self._gone:
+            raise KeyError(key)
+        if key in self._over:
+            return self._over[key]
         env = self._env
         if key == "max_command_x":
             return env.command_ranges["lin_vel_x"][1]
@@ -62,7 +79,7 @@ class _EpisodeExtras(Mapping):
             return torch.zeros((), device=env.device)
         return torch.mean(env._engine.buf["episode_done_sums"][abi.REWARD_ID[name]][m]) / env.max_episode_length_s
 
-    def __iter__(self):
+    def _lazy_keys(self):
         env = self._env
         for k in env.episode_sums:
             yield "rew_" + k
@@ -70,6 +87,16 @@ class _EpisodeExtras(Mapping):
             yield "terrain_level"
         if env.cfg.commands.curriculum:
             yield "max_command_x"
+
+    def __iter__(self):
+        seen = set()
+        for k in self._lazy_keys():
+            seen.add(k)
+            if k not in self._gone:
+                yield k
+        for k in self._over:
+            if k not in seen:
+                yield k
 
     def __len__(self):
         return sum(1 for _ in self)
@@ -97,7 +124,7 @@ class LeggedRobot:
         self.rew_buf = b["rew_buf"]
         self.reset_buf = b["reset_buf"].view(torch.bool)
         self.time_out_buf = b["time_out_buf"].view(torch.bool)
-        self.episode_length_buf = b["episode_length_buf"]
+        self._episode_length_buf = b["episode_length_buf"]
         self.reset_buf.fill_(True)
         self.extras = {}
         self._init_buffers()
@@ -105,7 +132,19 @@ class LeggedRobot:
         self._warm_rare_paths()
         self.init_done = True
 
-    # history-stacked observations are windows that move one frame per step (engine._Buffers): look them up per access
+    @property
+    def episode_length_buf(self):
+        """The kernel's per-env step counter.  rsl_rl REBINDS this attribute (`env.episode_length_buf = torch.randint_like(...)`,
+        on_policy_runner.py:105-106 init_at_random_ep_len): the setter copies into the device buffer the kernel reads."""
+        return self._episode_length_buf
+
+    @episode_length_buf.setter
+    def episode_length_buf(self, value):
+        self._episode_length_buf.copy_(torch.as_tensor(value, device=self._episode_length_buf.device).to(self._episode_length_buf.dtype))
+
+    # The observation outputs alternate between two copies and history-stacked ones are windows that move one frame per step
+    # (engine._Buffers): look them up per access.  The tensors step() returns stay intact while the NEXT step() runs
+    # (rsl_rl keeps them across env.step(), ppo.py:103-104 / rollout_storage.py:92) and are overwritten by the one after.
     @property
     def obs_buf(self):
         return self._engine.buf["obs_buf"]

@@ -261,7 +261,11 @@ class HipSimulator:
                 max_init_level = cfg.terrain.num_rows - 1
             b = self._engine.buf
             self._terrain_levels, self._terrain_types = b["terrain_levels"], b["terrain_types"]
-            self._terrain_levels[:] = torch.randint(0, max_init_level + 1, (N,), device=dev)
+            # genesis_simulator.py:521 draws these from torch's global stream; here from a stream keyed on the task seed and drawn
+            # for the GLOBAL env range, so that construction is repeatable and a rank's slice equals the single-process run
+            gen = torch.Generator().manual_seed(int(cfg.hip.seed))
+            lv = torch.randint(0, max_init_level + 1, (self._global_num_envs,), generator=gen)
+            self._terrain_levels[:] = lv[self._env_id_offset:self._env_id_offset + N].to(dev)
             gid = torch.arange(N, device=dev) + self._env_id_offset
             self._terrain_types[:] = torch.div(gid, (self._global_num_envs / cfg.terrain.num_cols), rounding_mode="floor").to(torch.long)
             self._max_terrain_level = cfg.terrain.num_rows

@@ -157,6 +157,11 @@ typedef struct LgTaskCfg {
     int32_t obs_slack;               /* history stacks only: extra frames per row; the stacked observation is a window that
                                       * slides one frame per step over rows of (stack + slack) frames (lg_obs_window), so a
                                       * step writes one frame instead of moving the whole history; 0 = shift in place */
+    int32_t obs_sets;                /* 1 or 2 copies of obs_buf / priv_obs_buf / labels_buf.  With 2, consecutive launches
+                                      * alternate between the copies, so the observation tensors handed out by one step stay
+                                      * intact while the next step runs (the reference's step() returns a fresh tensor,
+                                      * legged_robot.py:48-49, and rsl_rl keeps it across env.step(), ppo.py:103-104);
+                                      * needs obs_slack >= stack + 1 when obs_slack > 0 */
     float control_dt;                /* dt * decimation */
     float clip_actions, clip_obs;
     float max_episode_length;        /* ceil(episode_length_s / dt) as float (legged_robot.py:446) */
@@ -238,8 +243,10 @@ typedef struct LgBuffers {
     float *feet_air_time; uint8_t *last_contacts;
     int32_t *episode_length_buf; int64_t *fail_buf;
     uint8_t *reset_buf, *time_out_buf;
-    float *rew_buf, *obs_buf, *priv_obs_buf, *labels_buf; /* priv/labels may be NULL */
-    float *obs_hist, *priv_hist;      /* (N, stack, frame) ring-free history, may be NULL */
+    float *rew_buf;
+    float *obs_buf, *priv_obs_buf, *labels_buf; /* (obs_sets, N, row); priv/labels may be NULL */
+    uint8_t *obs_dirty;               /* (N) with obs_sets == 2 and history stacks: env was reset at the previous observation
+                                         launch, so its history in the other copy still has to be blanked; may be NULL */
     float *episode_sums;              /* (LG_R_COUNT, N) */
     float *episode_done_sums;         /* (LG_R_COUNT, N): each env's episode sums as they stood at its latest reset */
     int32_t *episode_done_step;       /* (N): common_step_counter of that reset; together they back the lazy
@@ -277,13 +284,17 @@ int lg_step(LgHandle h, uint32_t phases, const float *actions, int64_t common_st
  * HIP events on `stream`; returns mean kernel-to-kernel milliseconds per step in *ms. */
 int lg_time_steps(LgHandle h, const float *actions, int64_t first_counter, int32_t count, void *stream, float *ms);
 /* Sampling timer for the roofline line of bench.py: with stride N > 0 every N-th lg_step that contains LG_PHASE_SIM
- * brackets its physics kernel (the dominant launch) with a pair of HIP events on the caller's stream (at most 1024
+ * brackets the control step's kernel(s) -- begin of the first launch to end of the last when a step takes two (biped:
+ * physics, then the MDP phases) -- with a pair of HIP events on the caller's stream (at most 1024
  * samples are kept); stride 0 switches it off.  lg_profile_read waits for the recorded events and returns the
  * mean kernel duration in microseconds and the sample count, then clears the samples. */
 /* First frame of the window that holds the most recent stacked observation: row e of obs_buf starts at
  * obs_buf + e * (obs_stack + obs_slack) * obs_frame + *first_frame * obs_frame (same frame index for priv_obs_buf
  * with its own stack / frame widths).  Always 0 when obs_slack == 0. */
 int lg_obs_window(LgHandle h, int32_t *first_frame);
+/* Copy (0 or 1; always 0 with obs_sets == 1) of obs_buf / priv_obs_buf / labels_buf that holds the most recent
+ * observation: copy s starts s * n_envs * row floats into the allocation. */
+int lg_obs_set(LgHandle h, int32_t *set);
 int lg_profile(LgHandle h, int32_t stride);
 int lg_profile_read(LgHandle h, float *mean_us, int32_t *samples);
 /* Diagnostic: one Philox4x32-10 block computed on the device by the kernel's own generator (known-answer tests). */

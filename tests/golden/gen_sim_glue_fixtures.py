@@ -1,0 +1,386 @@
+"""Golden vectors for the reference's SIMULATOR GLUE: the in-tree arithmetic of
+legged_gym/simulator/genesis_simulator.py that surrounds the (absent) Genesis engine, produced by
+RUNNING THE REFERENCE'S OWN METHODS UNBOUND on a stand-in object whose `_robot` / `_scene` are recording stubs.
+
+Build-container only:   PYTHONDONTWRITEBYTECODE=1 python tests/golden/gen_sim_glue_fixtures.py
+Output: tests/golden/sim_glue_<task>.npz and tests/golden/math_utils_kat.npz (data only).
+
+What is pinned (reference file:line):
+  * GenesisSimulator.step            genesis_simulator.py:20-33   "last" snapshots, one _compute_torques per sub-step
+  * GenesisSimulator._compute_torques  :630-642                   PD law with per-env kp / kd scales, unclipped
+  * GenesisSimulator.post_physics_step :35-60                     wxyz -> xyzw, euler, body-frame twist, projected gravity,
+                                                                  link contact states
+  * GenesisSimulator._check_base_pos_out_of_bound  :612-628       teleport to base_init_pos + env_origins, velocity kept
+  * GenesisSimulator.reset_idx + _randomize_*      :62-82, 665-739  draw order, formulas, what reaches the engine setters
+  * GenesisSimulator.reset_dofs / reset_root_states / push_robots / update_terrain_curriculum   :84-158
+  * math_utils.py:34-112 known-answer vectors (quat_apply, quat_apply_yaw, wrap_to_pi, quat_rotate_inverse,
+    get_euler_xyz, quat_from_euler_xyz, torch_rand_float's affine map)
+Every uniform draw (gs.rand, torch.rand, torch_rand_float, torch.randint_like) is served by a recorder and stored
+in call order, so a test can feed the very same numbers to the code under test.
+"""
+import os
+import sys
+import types
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, HERE)
+sys.path.insert(0, ROOT)
+import ref_harness as rh  # noqa: E402
+
+rh.load_reference()
+import torch  # noqa: E402
+
+from hcr_genesis_lr_cl_amd.model_compiler import load_model  # noqa: E402
+
+torch.set_num_threads(2)
+
+
+class Draws:
+    """Serves uniforms from one numpy stream and keeps them in call order as (tag, array)."""
+
+    def __init__(self, seed):
+        self.rng = np.random.default_rng(seed)
+        self.log = []
+
+    def u(self, tag, shape):
+        v = self.rng.random(size=tuple(shape), dtype=np.float32)
+        self.log.append((tag, v.copy()))
+        return torch.from_numpy(v)
+
+    def take(self):
+        out, self.log = self.log, []
+        return out
+
+
+class RobotStub:
+    """Stands in for the Genesis RigidEntity behind `self._robot`: getters serve a scripted state, setters are recorded
+    (and applied where a later getter of the same reference method reads the value back)."""
+
+    def __init__(self, n_envs, n_dof, n_links, feet):
+        self.N, self.A, self.n_links, self.feet = n_envs, n_dof, n_links, feet
+        self.calls = []
+        self.s = {}
+
+    def load(self, s):
+        self.s = {k: torch.from_numpy(np.ascontiguousarray(v)).clone() for k, v in s.items()}
+
+    def rec(self, name, **kw):
+        self.calls.append((name, {k: (v.detach().clone().numpy() if torch.is_tensor(v) else (np.asarray(v) if isinstance(v, (list, range, np.ndarray)) else v))
+                                  for k, v in kw.items()}))
+
+    def take(self):
+        out, self.calls = self.calls, []
+        return out
+
+    # getters (genesis_simulator.py:27-51, 153)
+    def get_pos(self): return self.s["base_pos"].clone()
+    def get_quat(self): return self.s["base_quat_wxyz"].clone()
+    def get_vel(self): return self.s["base_lin_vel_w"].clone()
+    def get_ang(self): return self.s["base_ang_vel_w"].clone()
+
+    def get_dofs_position(self, idx=None):
+        return self.s["dof_pos"].clone()
+
+    def get_dofs_velocity(self, idx=None):
+        if idx is None:   # push_robots: all 6 + A dofs, base twist first
+            return torch.cat([self.s["base_lin_vel_w"], self.s["base_ang_vel_w"], self.s["dof_vel"]], 1)
+        return self.s["dof_vel"].clone()
+
+    def get_links_net_contact_force(self): return self.s["link_contact_forces"].clone()
+    def get_links_pos(self): return self.s["links_pos"].clone()
+    def get_links_vel(self): return self.s["links_vel"].clone()
+
+    # setters
+    def control_dofs_force(self, t, idx): self.rec("control_dofs_force", t=t, idx=idx)
+
+    def set_pos(self, pos, zero_velocity=True, envs_idx=None):
+        self.rec("set_pos", pos=pos, zero_velocity=zero_velocity, envs_idx=envs_idx)
+        self.s["base_pos"][envs_idx] = pos
+
+    def set_quat(self, q, zero_velocity=True, envs_idx=None): self.rec("set_quat", quat=q, zero_velocity=zero_velocity, envs_idx=envs_idx)
+    def set_dofs_position(self, position, dofs_idx_local, zero_velocity, envs_idx): self.rec("set_dofs_position", position=position, idx=dofs_idx_local, zero_velocity=zero_velocity, envs_idx=envs_idx)
+    def zero_all_dofs_velocity(self, envs_idx): self.rec("zero_all_dofs_velocity", envs_idx=envs_idx)
+    def set_dofs_velocity(self, velocity, dofs_idx_local=None, envs_idx=None): self.rec("set_dofs_velocity", velocity=velocity, idx=-1 if dofs_idx_local is None else dofs_idx_local, envs_idx=-1 if envs_idx is None else envs_idx)
+    def set_friction_ratio(self, ratios, links, envs_idx): self.rec("set_friction_ratio", ratios=ratios, links=links, envs_idx=envs_idx)
+    def set_mass_shift(self, m, link, envs_idx): self.rec("set_mass_shift", mass=m, link=link, envs_idx=envs_idx)
+    def set_COM_shift(self, c, link, envs_idx): self.rec("set_COM_shift", com=c, link=link, envs_idx=envs_idx)
+    def set_dofs_armature(self, a, idx, envs_idx): self.rec("set_dofs_armature", v=a, idx=idx, envs_idx=envs_idx)
+    def set_dofs_frictionloss(self, a, idx, envs_idx): self.rec("set_dofs_frictionloss", v=a, idx=idx, envs_idx=envs_idx)
+    def set_dofs_damping(self, a, idx, envs_idx): self.rec("set_dofs_damping", v=a, idx=idx, envs_idx=envs_idx)
+    def set_dofs_kp(self, *a, **k): pass
+    def set_dofs_kv(self, *a, **k): pass
+
+
+class SceneStub:
+    """`self._scene.step()`: moves the robot stub on to the next scripted sub-step state."""
+
+    def __init__(self, robot):
+        self.robot, self.sub = robot, None
+
+    def step(self):
+        q, qd = next(self.sub)
+        self.robot.s["dof_pos"], self.robot.s["dof_vel"] = q, qd
+
+
+def make_glue(GS, cfg, N, draws):
+    """An object on which the reference's GenesisSimulator methods run unbound: attributes are created by the reference's
+    own _init_buffers / _init_domain_params / _init_height_points; every other method or property resolves to GS's."""
+
+    class Glue:
+        def __getattr__(self, name):           # only reached when normal lookup fails
+            f = GS.__dict__.get(name)
+            if f is None:
+                from legged_gym.simulator.simulator import Simulator
+                f = Simulator.__dict__.get(name)
+            if isinstance(f, property):
+                return f.fget(self)
+            if callable(f):
+                return types.MethodType(f, self)
+            raise AttributeError(name)
+
+    g = Glue()
+    model = load_model(cfg.asset.name)
+    g.model = model
+    g._cfg, g._device, g._num_envs, g._num_actions = cfg, "cpu", N, cfg.env.num_actions
+    g._num_dof = cfg.env.num_actions
+    g._dof_indices = list(range(6, 6 + g._num_actions))
+    d = cfg.domain_rand
+    g._batch_dofs_links_info = d.randomize_joint_armature or d.randomize_joint_friction or d.randomize_joint_damping
+    g._feet_indices = model.find_link_indices([n for n in model.link_names if cfg.asset.foot_name in n])
+    if cfg.asset.obtain_link_contact_states:
+        g._contact_state_link_indices = model.find_link_indices(cfg.asset.contact_state_link_names)
+    g._base_link_index = 0
+    g._robot = RobotStub(N, g._num_actions, model.n_links, g._feet_indices)
+    g._scene = SceneStub(g._robot)
+    # genesis_simulator.py:278-294 (the statements themselves need the Genesis scene: restated, and cross-checked by the tests
+    # against hcr_genesis_lr_cl_amd.config.terrain_bounds)
+    t = cfg.terrain
+    if t.mesh_type in ("heightfield", "trimesh"):
+        g._terrain_x_range = torch.tensor([-t.border_size + 1.0, t.border_size + t.num_rows * t.terrain_length - 1.0])
+        g._terrain_y_range = torch.tensor([-t.border_size + 1.0, t.border_size + t.num_cols * t.terrain_width - 1.0])
+    else:
+        g._terrain_x_range = torch.tensor([-t.plane_length / 2 + 1, t.plane_length / 2 - 1])
+        g._terrain_y_range = torch.tensor([-t.plane_length / 2 + 1, t.plane_length / 2 - 1])
+    GS._init_buffers(g)
+    GS._init_domain_params(g)
+    g._env_origins = torch.from_numpy(np.random.default_rng(5).uniform(-5, 5, (N, 3)).astype(np.float32))
+    g._env_origins[:, 2] = torch.from_numpy(np.random.default_rng(6).uniform(0, 0.4, N).astype(np.float32))
+    return g
+
+
+def gen_task(name, ref_cfg_cls, N=16, T=6, seed=101):
+    import legged_gym.simulator.genesis_simulator as gsm
+    GS = gsm.GenesisSimulator
+    draws = Draws(seed)
+    # every source of randomness the glue uses (genesis_simulator.py:150-158, 665-739)
+    gsm.gs.rand = lambda shape, dtype=float: draws.u("gs.rand", shape)
+    gsm.torch_rand_float = lambda lo, hi, shape, device: (hi - lo) * draws.u("torch_rand_float", shape) + lo
+    orig_rand, orig_randint_like = torch.rand, torch.randint_like
+    cfg = ref_cfg_cls()
+    cfg.env.num_envs = N
+    try:
+        g = make_glue(GS, cfg, N, draws)
+        model, A, L, F = g.model, g._num_actions, g.model.n_links, g.model.n_legs
+        dec = cfg.control.decimation
+        rng = np.random.default_rng(seed + 1)
+        q0 = g._default_dof_pos.numpy()[0]
+        out = {k: [] for k in ("actions", "kp_scale", "kd_scale", "dof_pos0", "dof_vel0", "dof_pos_sub", "dof_vel_sub", "torques_sub",
+                               "torques", "last_dof_vel", "last_feet_vel", "last_base_lin_vel", "last_base_ang_vel",
+                               "rb_base_pos_in", "rb_base_quat_wxyz", "rb_base_lin_vel_w", "rb_base_ang_vel_w", "rb_link_contact_forces",
+                               "rb_links_pos", "rb_links_vel",
+                               "base_pos", "base_quat", "base_euler", "base_lin_vel", "base_ang_vel", "projected_gravity",
+                               "feet_pos", "feet_vel", "oob_ids", "link_contact_states")}
+        xr, yr = g._terrain_x_range.numpy(), g._terrain_y_range.numpy()
+        # per-env PD scales as the DR would leave them
+        g._kp_scale[:] = torch.from_numpy(rng.uniform(0.8, 1.2, (N, A)).astype(np.float32))
+        g._kd_scale[:] = torch.from_numpy(rng.uniform(0.8, 1.2, (N, A)).astype(np.float32))
+        for t in range(T):
+            act = (rng.normal(size=(N, A)) * (1.0 if t % 3 else 40.0)).astype(np.float32)
+            qs = (q0 + rng.normal(size=(dec + 1, N, A)) * 0.4).astype(np.float32)
+            qds = (rng.normal(size=(dec + 1, N, A)) * 4.0).astype(np.float32)
+            # state before the step (what the previous post_physics_step left in the buffers)
+            g._dof_pos[:] = torch.from_numpy(qs[0]); g._dof_vel[:] = torch.from_numpy(qds[0])
+            g._feet_vel[:] = torch.from_numpy((rng.normal(size=(N, F, 3))).astype(np.float32))
+            g._base_lin_vel[:] = torch.from_numpy(rng.normal(size=(N, 3)).astype(np.float32))
+            g._base_ang_vel[:] = torch.from_numpy(rng.normal(size=(N, 3)).astype(np.float32))
+            snap = dict(last_dof_vel=g._dof_vel.numpy().copy(), last_feet_vel=g._feet_vel.numpy().copy(),
+                        last_base_lin_vel=g._base_lin_vel.numpy().copy(), last_base_ang_vel=g._base_ang_vel.numpy().copy())
+            g._scene.sub = iter([(torch.from_numpy(qs[k + 1]), torch.from_numpy(qds[k + 1])) for k in range(dec)])
+            g._robot.load(dict(dof_pos=qs[0], dof_vel=qds[0]))
+            GS.step(g, torch.from_numpy(act))
+            calls = g._robot.take()
+            tq = np.stack([c[1]["t"] for c in calls if c[0] == "control_dofs_force"])
+            assert tq.shape == (dec, N, A)
+            for k, v in snap.items():
+                np.testing.assert_array_equal(getattr(g, "_" + k).numpy(), v)   # genesis_simulator.py:21-24
+                out[k].append(v)
+            out["actions"].append(act); out["kp_scale"].append(g._kp_scale.numpy().copy()); out["kd_scale"].append(g._kd_scale.numpy().copy())
+            out["dof_pos0"].append(qs[0]); out["dof_vel0"].append(qds[0]); out["dof_pos_sub"].append(qs[1:]); out["dof_vel_sub"].append(qds[1:])
+            out["torques_sub"].append(tq); out["torques"].append(g._torques.numpy().copy())
+            # read-back (post_physics_step): a scripted final pose, a third of the envs outside the terrain box
+            pos = (rng.normal(size=(N, 3)) * [3, 3, 0.05] + [0, 0, 0.4]).astype(np.float32)
+            oob = rng.random(N) < 0.35
+            side = rng.integers(0, 4, N)
+            pos[oob & (side == 0), 0] = xr[1] + rng.uniform(0, 2)
+            pos[oob & (side == 1), 0] = xr[0] - rng.uniform(0, 2)
+            pos[oob & (side == 2), 1] = yr[1] + rng.uniform(0, 2)
+            pos[oob & (side == 3), 1] = yr[0]                                    # exactly on the bound counts as outside (<=)
+            quat = rng.normal(size=(N, 4)).astype(np.float32)
+            quat /= np.linalg.norm(quat, axis=1, keepdims=True)
+            if t == 0:
+                quat[0] = [0.7071069, 0, 0.7071069, 0]                         # wxyz: pitch +90 deg, 2 w y = 1.0000002 -> |sinp| >= 1 branch of get_euler_xyz
+                quat[1] = [0.7071069, 0, -0.7071069, 0]
+            f = (rng.normal(size=(N, L, 3)) * 2.0 * (rng.random((N, L, 1)) < 0.5)).astype(np.float32)
+            rb = dict(base_pos=pos.copy(), base_quat_wxyz=quat, base_lin_vel_w=rng.normal(size=(N, 3)).astype(np.float32),
+                      base_ang_vel_w=rng.normal(size=(N, 3)).astype(np.float32), dof_pos=qs[dec], dof_vel=qds[dec],
+                      link_contact_forces=f, links_pos=rng.normal(size=(N, L, 3)).astype(np.float32),
+                      links_vel=rng.normal(size=(N, L, 3)).astype(np.float32))
+            g._robot.load(rb)
+            cfg.terrain.measure_heights = False       # heights / feet info are pinned by the MDP fixtures (gen_mdp_fixtures.py)
+            GS.post_physics_step(g)
+            calls = g._robot.take()
+            sp = [c for c in calls if c[0] == "set_pos"]
+            ids = sp[0][1]["envs_idx"] if sp else np.zeros(0, np.int64)
+            if sp:
+                assert sp[0][1]["zero_velocity"] is False
+            mask = np.zeros(N, np.uint8); mask[ids] = 1
+            out["oob_ids"].append(mask)
+            for k in ("base_pos", "base_quat_wxyz", "base_lin_vel_w", "base_ang_vel_w", "link_contact_forces", "links_pos", "links_vel"):
+                out["rb_" + (k if k != "base_pos" else "base_pos_in")].append(rb[k] if k != "base_pos" else pos)
+            for k in ("base_pos", "base_quat", "base_euler", "base_lin_vel", "base_ang_vel", "projected_gravity", "feet_pos", "feet_vel"):
+                out[k].append(getattr(g, "_" + k).numpy().copy())
+            out["link_contact_states"].append(g._link_contact_states.numpy().copy() if cfg.asset.obtain_link_contact_states else np.zeros((N, 0), np.float32))
+        arrays = {k: np.stack(v) for k, v in out.items()}
+        arrays["env_origins"] = g._env_origins.numpy().copy()
+        arrays["base_init_pos"] = g._base_init_pos.numpy().copy()
+        arrays["terrain_x_range"], arrays["terrain_y_range"] = xr.copy(), yr.copy()
+        arrays["p_gains"] = g._p_gains.numpy().reshape(-1, A)[0].copy(); arrays["d_gains"] = g._d_gains.numpy().reshape(-1, A)[0].copy()
+        arrays["default_dof_pos"] = q0.copy()
+        arrays["action_scale"] = np.float32(cfg.control.action_scale)
+
+        # ---- reset_idx: the reference's DR draws (genesis_simulator.py:62-82, 665-739) ----
+        torch.rand = lambda *shape, **kw: draws.u("torch.rand", shape[0] if len(shape) == 1 and isinstance(shape[0], (tuple, list)) else shape)
+        draws.take(); g._robot.take()
+        ids = torch.from_numpy(np.sort(rng.choice(N, N // 2, replace=False)))
+        for k in ("_last_dof_vel", "_last_feet_vel", "_last_base_lin_vel", "_last_base_ang_vel"):
+            getattr(g, k)[:] = 7.0
+        before = {k: getattr(g, k).numpy().copy() for k in ("_friction_values", "_added_base_mass", "_base_com_bias", "_kp_scale", "_kd_scale",
+                                                           "_joint_armature", "_joint_friction", "_joint_damping")}
+        GS.reset_idx(g, ids)
+        log, calls = draws.take(), g._robot.take()
+        arrays["reset_ids"] = ids.numpy()
+        arrays["reset_draw_tags"] = np.array([t_ for t_, _ in log])
+        for i, (_, v) in enumerate(log):
+            arrays[f"reset_draw_{i}"] = v
+        for k in before:
+            arrays["reset_before" + k] = before[k]
+            arrays["reset_after" + k] = getattr(g, k).numpy().copy()
+        for k in ("_last_dof_vel", "_last_feet_vel", "_last_base_lin_vel", "_last_base_ang_vel"):
+            arrays["reset_after" + k] = getattr(g, k).numpy().copy()
+        arrays["reset_setter_names"] = np.array([c[0] for c in calls])
+        for i, (nm, kw) in enumerate(calls):
+            for k, v in kw.items():
+                arrays[f"reset_setter_{i}_{k}"] = np.asarray(v)
+
+        # ---- reset_dofs / reset_root_states / push_robots (genesis_simulator.py:84-133, 150-158) ----
+        dof_pos = (q0 + rng.normal(size=(len(ids), A)) * 0.2).astype(np.float32)
+        g._dof_vel[:] = 3.0
+        GS.reset_dofs(g, ids, torch.from_numpy(dof_pos), torch.zeros(len(ids), A))
+        calls = g._robot.take()
+        arrays["rd_dof_pos_in"] = dof_pos
+        arrays["rd_dof_pos"], arrays["rd_dof_vel"] = g._dof_pos.numpy().copy(), g._dof_vel.numpy().copy()
+        arrays["rd_setter_names"] = np.array([c[0] for c in calls])
+        assert [c[0] for c in calls] == ["set_dofs_position", "zero_all_dofs_velocity"] and calls[0][1]["zero_velocity"] is True
+        bp = (rng.normal(size=(len(ids), 3))).astype(np.float32)
+        bq = rng.normal(size=(len(ids), 4)).astype(np.float32); bq /= np.linalg.norm(bq, axis=1, keepdims=True)
+        blv, bav = rng.normal(size=(len(ids), 3)).astype(np.float32), rng.normal(size=(len(ids), 3)).astype(np.float32)
+        g._base_quat[:] = torch.from_numpy(np.tile(np.array([0, 0, 0, 1], np.float32), (N, 1)))
+        g._robot.load(dict(base_pos=g._base_pos.numpy().copy()))
+        GS.reset_root_states(g, ids, torch.from_numpy(bp), torch.from_numpy(bq), torch.from_numpy(blv), torch.from_numpy(bav))
+        calls = g._robot.take()
+        arrays.update(rr_base_pos_in=bp, rr_base_quat_in=bq, rr_lin_vel_in=blv, rr_ang_vel_in=bav,
+                      rr_base_pos=g._base_pos.numpy().copy(), rr_base_quat=g._base_quat.numpy().copy(),
+                      rr_projected_gravity=g._projected_gravity.numpy().copy(), rr_base_lin_vel=g._base_lin_vel.numpy().copy(),
+                      rr_base_ang_vel=g._base_ang_vel.numpy().copy())
+        arrays["rr_setter_names"] = np.array([c[0] for c in calls])
+        sv = [c for c in calls if c[0] == "set_dofs_velocity"][0][1]
+        arrays["rr_engine_velocity"] = sv["velocity"]          # what the engine's dofs 0-5 receive: [lin (world), ang (world)]
+        arrays["rr_engine_quat_wxyz"] = [c for c in calls if c[0] == "set_quat"][0][1]["quat"]
+        # push
+        base_w = rng.normal(size=(N, 3)).astype(np.float32)
+        g._robot.load(dict(base_lin_vel_w=base_w, base_ang_vel_w=np.zeros((N, 3), np.float32), dof_vel=np.zeros((N, A), np.float32)))
+        draws.take()
+        GS.push_robots(g)
+        log, calls = draws.take(), g._robot.take()
+        arrays["push_u"] = log[0][1]
+        arrays["push_base_lin_vel_w_in"] = base_w
+        arrays["push_rand_push_vels"] = g._rand_push_vels.numpy().copy()
+        arrays["push_engine_velocity"] = calls[0][1]["velocity"]
+        arrays["push_max"] = np.float32(cfg.domain_rand.max_push_vel_xy)
+
+        # ---- update_terrain_curriculum (genesis_simulator.py:140-148) ----
+        if cfg.terrain.mesh_type == "heightfield":
+            rows, cols = cfg.terrain.num_rows, cfg.terrain.num_cols
+            g._max_terrain_level = rows
+            g._terrain_levels = torch.from_numpy(rng.integers(0, rows, N))
+            g._terrain_levels[ids[:3]] = rows - 1
+            g._terrain_types = torch.from_numpy(rng.integers(0, cols, N))
+            g._terrain_origins = torch.from_numpy(rng.normal(size=(rows, cols, 3)).astype(np.float32))
+            up = torch.from_numpy(rng.random(len(ids)) < 0.5); up[:3] = True
+            down = torch.from_numpy(rng.random(len(ids)) < 0.4) & ~up
+            arrays.update(tc_levels_in=g._terrain_levels.numpy().copy(), tc_types=g._terrain_types.numpy().copy(),
+                          tc_origins=g._terrain_origins.numpy().copy(), tc_up=up.numpy(), tc_down=down.numpy())
+
+            def ril(t_, high):
+                idx = rng.integers(0, high, size=tuple(t_.shape))
+                arrays["tc_randint"] = idx.copy()
+                return torch.from_numpy(idx).to(t_.dtype)
+            torch.randint_like = ril
+            GS.update_terrain_curriculum(g, ids, up, down)
+            arrays["tc_levels"] = g._terrain_levels.numpy().copy()
+            arrays["tc_env_origins"] = g._env_origins.numpy().copy()
+        path = os.path.join(HERE, f"sim_glue_{name}.npz")
+        np.savez_compressed(path, **arrays)
+        print("wrote", path, os.path.getsize(path), "oob/step", arrays["oob_ids"].sum(1), "reset draws", list(arrays["reset_draw_tags"]),
+              "setters", list(arrays["reset_setter_names"]))
+    finally:
+        torch.rand, torch.randint_like = orig_rand, orig_randint_like
+
+
+def gen_math_kat(seed=301, n=64):
+    """math_utils.py:34-112 known-answer vectors, from the reference's own TorchScript functions."""
+    from legged_gym.utils import math_utils as mu
+    rng = np.random.default_rng(seed)
+    q = rng.normal(size=(n, 4)).astype(np.float32); q /= np.linalg.norm(q, axis=1, keepdims=True)
+    q[0] = [0, 0.7071069, 0, 0.7071069]; q[1] = [0, -0.7071069, 0, 0.7071069]; q[2] = [0, 0, 0, 1]
+    v = rng.normal(size=(n, 3)).astype(np.float32)
+    ang = np.concatenate([rng.uniform(-12, 12, n - 6), [0.0, np.pi, -np.pi, 2 * np.pi, -2 * np.pi, 3.5]]).astype(np.float32)
+    rpy = rng.uniform(-3, 3, (n, 3)).astype(np.float32)
+    tq, tv = torch.from_numpy(q), torch.from_numpy(v)
+    arrays = dict(q=q, v=v, angles=ang, rpy=rpy,
+                  quat_rotate_inverse=mu.quat_rotate_inverse(tq, tv).numpy(),
+                  quat_apply=mu.quat_apply(tq, tv).numpy(),
+                  quat_apply_yaw=mu.quat_apply_yaw(tq, tv).numpy(),
+                  get_euler_xyz=mu.get_euler_xyz(tq).numpy(),
+                  wrap_to_pi=mu.wrap_to_pi(torch.from_numpy(ang.copy())).numpy(),
+                  quat_from_euler_xyz=mu.quat_from_euler_xyz(torch.from_numpy(rpy[:, 0]), torch.from_numpy(rpy[:, 1]), torch.from_numpy(rpy[:, 2])).numpy(),
+                  quat_mul=mu.quat_mul(tq, torch.from_numpy(np.roll(q, 1, 0).copy())).numpy(),
+                  normalize=mu.normalize(tv).numpy())
+    path = os.path.join(HERE, "math_utils_kat.npz")
+    np.savez_compressed(path, **arrays)
+    print("wrote", path, os.path.getsize(path))
+
+
+if __name__ == "__main__":
+    from legged_gym.envs.go2.go2_config import GO2Cfg
+    from legged_gym.envs.go2.go2_wtw.go2_wtw_config import GO2WTWCfg
+    from legged_gym.envs.go2.go2_ee.go2_ee_config import Go2EECfg
+    from legged_gym.envs.tron1_pf.tron1_pf_ee.tron1_pf_ee_config import TRON1PF_EECfg
+    gen_math_kat()
+    gen_task("go2", GO2Cfg, seed=101)
+    gen_task("go2_wtw", GO2WTWCfg, seed=111)
+    gen_task("go2_ee", Go2EECfg, seed=121)
+    gen_task("tron1_pf_ee", TRON1PF_EECfg, seed=131)

@@ -78,3 +78,15 @@ def test_product_never_imports_the_oracle():
             if f.endswith((".py", ".hip", ".h")):
                 txt = open(os.path.join(dp, f)).read()
                 assert "oracle" not in txt.replace("oracle/lg_oracle.c", "").replace("CPU oracle", "").replace("(see oracle", "").replace("The CPU oracle", ""), f
+
+
+def test_build_used_primary_flags():
+    """The in-tree library was compiled with the scheduler flags the measurements are quoted for: a silent fallback after a
+    compiler crash (build.py) would show up here and in bench.py's `build_flags`."""
+    import json
+    from hcr_genesis_lr_cl_amd import build
+    if not os.path.exists(build.SIDECAR):
+        build.build(force=True)
+    info = json.load(open(build.SIDECAR))
+    assert info["fallback"] is False, info.get("primary_error", "")[-500:]
+    assert all(f in info["flags"] for f in build.EXTRA_FLAGS)

@@ -23,7 +23,7 @@ def _worker(rank, world, port, q):
     ids = torch.arange(off, off + n, dtype=torch.float32)
     obs = ids[:, None] * torch.ones(1, 5) + torch.arange(5) * 0.1
     out = g(obs, ids * 2, (ids % 3 == 0).float())
-    o, r, d = g.split()
+    (o,), r, d = g.split()
     # command-curriculum mean over the resetting envs of all ranks: rank 0 has 3 of them (sum 6), rank 1 none
     gm = global_mean(torch.tensor(6.0) if rank == 0 else torch.tensor(0.0), 3 if rank == 0 else 0)
     assert gm == (2.0, 3.0), gm
@@ -64,3 +64,39 @@ def test_shard_is_contiguous_and_even():
 def test_global_mean_without_process_group_is_local():
     assert global_mean(torch.tensor(9.0), 3) == (3.0, 3.0)
     assert global_mean(torch.tensor(0.0), 0) == (0.0, 0.0)
+
+
+def test_gather_packs_strided_windows_bool_done_and_several_outputs():
+    """What bench.py hands it for the history tasks: the actor stack is a strided window of a wider row, `done` is bool,
+    and the critic stack and labels ride in the same record."""
+    g = StepGather(6, [4, 3, 2], 1, "cpu")
+    rows = torch.arange(6 * 10, dtype=torch.float32).reshape(6, 10)
+    obs, crit, lab = rows[:, 3:7], rows[:, 1:4] * 2, rows[:, 8:] + 0.5
+    assert not obs.is_contiguous()
+    done = torch.tensor([True, False, False, True, False, False])
+    g(obs=[obs, crit, lab], rew=torch.arange(6.0), done=done)
+    (o, c, l), r, d = g.split()
+    assert torch.equal(o, obs) and torch.equal(c, crit) and torch.equal(l, lab)
+    assert torch.equal(r, torch.arange(6.0)) and torch.equal(d, done) and d.dtype == torch.bool
+
+
+def test_bench_launcher_spawns_the_ranks_it_was_asked_for():
+    """`python bench.py --gpus 2` from a plain shell (no WORLD_SIZE): the file itself starts two ranks through
+    torch.distributed.run and rank 0 prints ONE JSON line saying n_gpus = 2 (dry run: gloo, no GPU, stand-in step)."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--launcher-dry-run"],
+                       capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["steps"] == 5 and out["gather_ok"] is True
+    # a launcher that started a different number of ranks than --gpus says is refused, not silently accepted
+    env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-dry-run"], capture_output=True, text=True,
+                        timeout=120, env=env2)
+    assert r2.returncode != 0 and "--gpus 2" in (r2.stderr + r2.stdout)

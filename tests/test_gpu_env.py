@@ -29,7 +29,7 @@ def test_vecenv_surface():
     assert (env.num_envs, env.num_obs, env.num_privileged_obs, env.num_actions) == (128, 45, None, 12)
     assert env.max_episode_length == 1000 and abs(env.dt - 0.02) < 1e-12
     obs, priv = env.reset()
-    assert obs.shape == (128, 45) and priv is None and obs is env.get_observations()
+    assert obs.shape == (128, 45) and priv is None and obs.data_ptr() == env.get_observations().data_ptr()
     obs, priv, rew, done, extras = env.step(torch.zeros(128, 12, device="cuda"))
     assert rew.shape == (128,) and done.dtype == torch.bool and done.shape == (128,)
     assert extras["time_outs"].dtype == torch.bool and "episode" in extras
@@ -60,32 +60,52 @@ def test_deterministic_and_shard_invariant():
         assert torch.equal(obs, a[t][0][128:]) and torch.equal(rew, a[t][1][128:]) and torch.equal(done, a[t][2][128:])
 
 
-def test_fused_launch_equals_split_launches():
-    """Same state in, one control step through (a) the fused launch and (b) PRE|SIM|POST + RESET:
-    identical integers, floats to 1e-5 (the two template instantiations may contract FMAs
-    differently; contact dynamics would amplify that over many steps, so states are re-synced
-    every step)."""
+@pytest.mark.parametrize("task", ["go2", "go2_wtw", "go2_ee"])
+def test_fused_launch_equals_split_launches(task):
+    """Same state in, one control step through (a) the fused launch -- the instantiation bench.py times,
+    quad_sim_kernel<4, true, POST|RESET> with the MDP phases in its tail -- and (b) SIM, then PRE|POST|RESET in
+    env_step_kernel<4, PRE|POST|RESET>, the very instantiation the golden replays of tests/test_gpu_mdp.py go through:
+    identical integers, floats to 1e-5 (the template instantiations may contract FMAs differently; contact dynamics
+    would amplify that over many steps, so states are re-synced every step).  Every quadruped task that uses the fused
+    tail is covered: go2 (45-wide frame), go2_wtw (gait state, 5-frame stacks, PD-gain DR), go2_ee (heightfield
+    sampling handed over through measured_heights, 20 / 5-frame stacks, labels)."""
     import torch
     from hcr_genesis_lr_cl_amd import abi
-    e1, e2 = _mk(256), _mk(256)
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    N = 256
+    e1, e2 = make_env(task, N, "cuda:0")[0], make_env(task, N, "cuda:0")[0]
     e1.reset(); e2.reset()
     g = torch.Generator(device="cuda"); g.manual_seed(5)
+    # spread the episode clocks so that time-outs, command and behaviour resampling fall inside the window
+    e1.episode_length_buf[:] = torch.randint(0, 1000, (N,), generator=g, device="cuda", dtype=torch.int32)
+    e1.common_step_counter = e2.common_step_counter = 480          # crosses the push step (500 / 750) for go2_ee
+    loose = {"obs_buf": 2e-4, "priv_obs_buf": 2e-4, "labels_buf": 2e-4, "dof_vel": 2e-3, "last_dof_vel": 2e-3, "feet_vel": 2e-3,
+             "last_feet_vel": 2e-3, "base_lin_vel": 2e-4, "base_ang_vel": 1e-3, "base_lin_vel_w": 2e-4, "base_ang_vel_w": 1e-3,
+             "torques": 2e-3, "link_contact_forces": 0.05, "last_base_lin_vel": 2e-4, "last_base_ang_vel": 1e-3}
+    n_reset = 0
     for t in range(40):
-        for k, v in e1._engine.buf.items():
-            e2._engine.buf[k].copy_(v)
+        for k in e1._engine.buf.keys():
+            e2._engine.buf.raw(k).copy_(e1._engine.buf.raw(k))
         e2.common_step_counter = e1.common_step_counter
-        act = torch.randn(256, 12, generator=g, device="cuda")
+        act = torch.randn(N, 12, generator=g, device="cuda") * (1.0 if t % 5 else 4.0)
         e1.step(act)
         e2.common_step_counter += 1
-        e2._engine.step(abi.PHASE_PRE | abi.PHASE_SIM | abi.PHASE_POST, act, e2.common_step_counter)
-        e2._engine.step(abi.PHASE_RESET, None, e2.common_step_counter)
+        ca = float(e2.cfg.normalization.clip_actions)
+        e2._engine.step(abi.PHASE_SIM, torch.clip(act, -ca, ca), e2.common_step_counter)       # Simulator.step: pre-clipped actions
+        e2._engine.step(abi.PHASE_PRE | abi.PHASE_POST | abi.PHASE_RESET, act, e2.common_step_counter)
         torch.cuda.synchronize()
+        assert e1._engine.obs_window() == e2._engine.obs_window()
         # velocities through a stiff contact solve carry ~1e-4 of instantiation-dependent round-off
-        for k, tol in (("obs_buf", 2e-4), ("rew_buf", 1e-5), ("dof_pos", 1e-5), ("dof_vel", 2e-3), ("base_pos", 1e-5),
-                       ("commands", 1e-6), ("episode_sums", 1e-5), ("feet_air_time", 0)):
-            np.testing.assert_allclose(e1._engine.buf[k].cpu().numpy(), e2._engine.buf[k].cpu().numpy(), rtol=1e-5, atol=tol, err_msg=f"{k} @ {t}")
-        assert torch.equal(e1._engine.buf["reset_buf"], e2._engine.buf["reset_buf"])
-        assert torch.equal(e1._engine.buf["episode_length_buf"], e2._engine.buf["episode_length_buf"])
+        for k in e1._engine.buf.keys():
+            a, b = e1._engine.buf[k], e2._engine.buf[k]
+            if a.dtype in (torch.float32,):
+                if k in ("episode_done_sums",):
+                    continue
+                np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=loose.get(k, 1e-5), err_msg=f"{k} @ {t}")
+            elif k != "episode_done_step":
+                assert torch.equal(a, b), f"{k} @ {t}"
+        n_reset += int(e1.reset_buf.sum())
+    assert n_reset > 0
 
 
 def test_long_random_rollout_is_sane():
@@ -228,3 +248,91 @@ def test_ragged_batch_sizes(layout, monkeypatch):
         runs.append(outs)
     for (o1, r1, d1), (o2, r2, d2) in zip(*runs):
         assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
+
+
+def _obs_tensors(out):
+    """(actor obs, critic obs / labels ...) of a step()/reset() result: every tensor-valued observation output."""
+    import torch
+    return [o for o in out[:3] if torch.is_tensor(o) and o.dtype == torch.float32 and o.dim() == 2]
+
+
+@pytest.mark.parametrize("slack", ["64", "1"], ids=["default-slack", "min-slack"])
+@pytest.mark.parametrize("task", ["go2", "go2_wtw", "go2_ee", "tron1_pf_ee"])
+def test_returned_observations_survive_the_next_step(task, slack, monkeypatch):
+    """The ordering of the reference's rollout loop (rsl_rl/algorithms/ppo.py:103-104 keeps `obs`,
+    on_policy_runner.py:118-124 calls env.step, rollout_storage.py:92 copies `obs` only afterwards): what a step
+    handed out must still be the PRE-step observation after the next step has run -- including for envs that reset in
+    that step (their history is blanked) and on steps where the sliding history window is compacted."""
+    import torch
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    monkeypatch.setenv("LG_OBS_SLACK", slack)
+    N = 128
+    env, cfg = make_env(task, N, "cuda:0")
+    held = _obs_tensors(env.reset())
+    g = torch.Generator(device="cuda"); g.manual_seed(2)
+    env.episode_length_buf = torch.randint(900, 1001, (N,), generator=g, device="cuda", dtype=torch.int32)   # time-outs inside the window
+    n_reset = 0
+    for t in range(90):
+        snap = [h.clone() for h in held]
+        out = env.step(torch.randn(N, env.num_actions, generator=g, device="cuda") * 2.0)
+        torch.cuda.synchronize()
+        for h, s in zip(held, snap):
+            assert torch.equal(h, s), f"observation of step {t - 1} changed under step {t}"
+        new = _obs_tensors(out)
+        assert all(a.data_ptr() != b.data_ptr() for a, b in zip(new, held))
+        held = new
+        n_reset += int(out[-2].sum())
+    assert n_reset > N // 2
+
+
+@pytest.mark.parametrize("slack", ["64", "1", "0"], ids=["window", "window-min-slack", "shift"])
+@pytest.mark.parametrize("task", ["go2_wtw", "tron1_pf_ee"])
+def test_two_observation_sets_equal_a_single_one(task, slack, monkeypatch):
+    """Same seeded rollout with LgTaskCfg.obs_sets = 2 (default) and = 1: every returned observation bit-identical.  Covers
+    the hand-over between the two copies: the frame written into the other copy, the deferred blanking of an env reset at
+    the previous launch, compaction of both copies."""
+    import torch
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    monkeypatch.setenv("LG_OBS_SLACK", slack)
+    N = 96
+
+    def run(sets):
+        monkeypatch.setenv("LG_OBS_SETS", str(sets))
+        env, _ = make_env(task, N, "cuda:0")
+        assert int(env._engine.task.obs_sets) == sets
+        env.reset()
+        g = torch.Generator(device="cuda"); g.manual_seed(4)
+        env.episode_length_buf = torch.randint(930, 1001, (N,), generator=g, device="cuda", dtype=torch.int32)
+        outs = []
+        for t in range(75):
+            out = env.step(torch.randn(N, env.num_actions, generator=g, device="cuda") * 2.0)
+            outs.append([o.clone() for o in _obs_tensors(out)] + [out[-2].clone()])
+        return outs
+    a, b = run(2), run(1)
+    for t, (x, y) in enumerate(zip(a, b)):
+        for u, v in zip(x, y):
+            assert torch.equal(u, v), f"step {t}"
+    assert sum(int(x[-1].sum()) for x in a) > N // 2
+
+
+def test_runner_statements_on_the_env():
+    """The statements the reference's unmodified runner executes on the env object (on_policy_runner.py:105-106, 182-185)."""
+    import torch
+    env = _mk(64)
+    env.reset()
+    # init_at_random_ep_len REBINDS the attribute: the kernel's buffer has to follow
+    env.episode_length_buf = torch.randint_like(env.episode_length_buf, high=int(env.max_episode_length))
+    assert env.episode_length_buf.data_ptr() == env._engine.buf["episode_length_buf"].data_ptr()
+    before = env.episode_length_buf.clone()
+    assert int(before.max()) > 10
+    _, _, _, done, infos = env.step(torch.zeros(64, 12, device="cuda"))
+    assert torch.equal(env.episode_length_buf[~done], before[~done] + 1)
+    # log(): scalars and 0-dim tensors are rewritten in place
+    ep_info = infos["episode"]
+    for key in ep_info:
+        if not isinstance(ep_info[key], torch.Tensor):
+            ep_info[key] = torch.Tensor([ep_info[key]])
+        if len(ep_info[key].shape) == 0:
+            ep_info[key] = ep_info[key].unsqueeze(0)
+        assert ep_info[key].shape == (1,)
+    assert len(list(ep_info)) == 16
