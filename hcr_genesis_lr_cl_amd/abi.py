@@ -36,7 +36,7 @@ REWARD_NAMES = [
 ]
 R_COUNT = len(REWARD_NAMES)
 REWARD_ID = {n: i for i, n in enumerate(REWARD_NAMES)}
-OBS_GO2, OBS_GO2_WTW, OBS_GO2_EE, OBS_TRON1_EE = 0, 1, 2, 3
+OBS_GO2, OBS_GO2_WTW, OBS_GO2_EE, OBS_TRON1_EE, OBS_PROGRAM = 0, 1, 2, 3, 4
 
 f32, i32, u32, i64, u64 = C.c_float, C.c_int32, C.c_uint32, C.c_int64, C.c_uint64
 fp = C.POINTER(C.c_float)
@@ -77,6 +77,15 @@ class LgRandSlots(C.Structure):
         "terrain_level", "task_cb", "task_reset", "noise")]
 
 
+MAX_SEGS = 8
+(SEG_END, SEG_FRAME, SEG_DR, SEG_DR_JOINT, SEG_BASE_LIN_VEL, SEG_CONTACT_STATES, SEG_HEIGHTS, SEG_FEET_REL_HEIGHTS,
+ SEG_FEET_HEIGHTS, SEG_FEET_NORMALS, SEG_FOOT_CLEARANCE, SEG_NEXT_STATE) = range(12)
+
+
+class LgObsProgram(C.Structure):
+    _fields_ = [("n_segs", i32), ("clip", i32), ("kind", i32 * MAX_SEGS), ("offset", i32 * MAX_SEGS), ("scale", f32 * MAX_SEGS)]
+
+
 class LgTaskCfg(C.Structure):
     _fields_ = [
         ("obs_layout", i32), ("num_obs", i32), ("num_priv_obs", i32), ("obs_frame", i32), ("priv_frame", i32),
@@ -90,7 +99,7 @@ class LgTaskCfg(C.Structure):
         ("tracking_sigma", f32), ("base_height_target", f32), ("foot_clearance_target", f32),
         ("foot_height_offset", f32), ("foot_clearance_sigma", f32), ("about_landing_threshold", f32),
         ("feet_air_time_threshold", f32), ("base_height_sigma", f32), ("euler_sigma", f32),
-        ("foot_distance_threshold", f32),
+        ("foot_distance_threshold", f32), ("foot_clearance_ref", i32),
         ("obs_scale_lin_vel", f32), ("obs_scale_ang_vel", f32), ("obs_scale_dof_pos", f32),
         ("obs_scale_dof_vel", f32), ("obs_scale_height", f32),
         ("add_noise", i32), ("noise_vec", f32 * MAX_OBS),
@@ -111,6 +120,7 @@ class LgTaskCfg(C.Structure):
         ("b_swing", f32), ("gait_period_fixed", f32), ("theta_table", f32 * 4 * 4),
         ("sit_percent", f32), ("sit_pos", f32 * 3), ("sit_quat", f32 * 4), ("sit_dof_pos", f32 * MAX_DOF),
         ("task_state_width", i32),
+        ("priv_prog", LgObsProgram), ("labels_prog", LgObsProgram),
         ("slots", LgRandSlots), ("seed", u64), ("env_id_offset", i64),
     ]
 

@@ -88,7 +88,7 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
     layout = cfg.reset.obs_layout
     A = model.n_dof
     t.obs_layout = {"go2": abi.OBS_GO2, "go2_wtw": abi.OBS_GO2_WTW, "go2_ee": abi.OBS_GO2_EE,
-                    "tron1_ee": abi.OBS_TRON1_EE}[layout]
+                    "tron1_ee": abi.OBS_TRON1_EE, "program": abi.OBS_PROGRAM}[layout]
     if layout == "go2":
         t.num_obs, t.obs_frame, t.obs_stack = 45, 45, 1
         t.num_priv_obs = t.priv_frame = t.priv_stack = 0
@@ -119,6 +119,36 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
         abi.fill_array(t.noise_vec, go2_noise_vec(cfg))            # go2_ee.py:100-122
         t.slots = go2_slots(A, e.num_single_obs)
         t.heights_offset, t.heights_clip_scale = 0.5, 1             # go2_ee.py:45-46
+    elif layout == "program":
+        # go2_ts / go2_cts / go2_dreamwaq / go2_cat: go2's actor frame, stacked `frame_stack` deep; critic frame and the
+        # auxiliary per-step output assembled from blocks (config.py GO2TSCfg ...)
+        e = cfg.env
+        K = len(model.find_link_indices(cfg.asset.contact_state_link_names)) if cfg.asset.obtain_link_contact_states else 0
+        P = len(cfg.terrain.measured_points_x) * len(cfg.terrain.measured_points_y) if cfg.terrain.measure_heights else 0
+        F = model.n_legs
+        width = {"frame": 45, "dr": 7 + 2 * A, "dr_joint": 3, "base_lin_vel": 3, "contact_states": K, "heights": P,
+                 "feet_rel_heights": 9 * F, "feet_heights": 9 * F, "feet_normals": 3 * F, "foot_clearance": F, "next_state": 45}
+        kind = {"frame": abi.SEG_FRAME, "dr": abi.SEG_DR, "dr_joint": abi.SEG_DR_JOINT, "base_lin_vel": abi.SEG_BASE_LIN_VEL,
+                "contact_states": abi.SEG_CONTACT_STATES, "heights": abi.SEG_HEIGHTS, "feet_rel_heights": abi.SEG_FEET_REL_HEIGHTS,
+                "feet_heights": abi.SEG_FEET_HEIGHTS, "feet_normals": abi.SEG_FEET_NORMALS, "foot_clearance": abi.SEG_FOOT_CLEARANCE,
+                "next_state": abi.SEG_NEXT_STATE}
+
+        def fill(prog, blocks, clip):
+            assert len(blocks) <= abi.MAX_SEGS
+            off = 0
+            for i, (name, scale) in enumerate(blocks):
+                prog.kind[i], prog.offset[i], prog.scale[i] = kind[name], off, scale
+                off += width[name]
+            prog.n_segs, prog.clip = len(blocks), int(clip)
+            return off
+        t.obs_frame, t.obs_stack, t.num_obs = 45, e.frame_stack, 45 * e.frame_stack
+        t.priv_frame = fill(t.priv_prog, cfg.reset.critic_program, cfg.reset.critic_clip)
+        t.priv_stack, t.num_priv_obs = e.c_frame_stack, e.c_frame_stack * t.priv_frame
+        t.num_labels = fill(t.labels_prog, cfg.reset.aux_program, cfg.reset.aux_clip)
+        assert t.priv_frame == e.single_critic_obs_len, (t.priv_frame, e.single_critic_obs_len)
+        abi.fill_array(t.noise_vec, go2_noise_vec(cfg))            # go2_ts.py:110-131
+        t.slots = go2_slots(A, 45)
+        t.heights_offset, t.heights_clip_scale = 0.5, 1             # go2_ts.py:50-52
     elif layout == "tron1_ee":
         e = cfg.env
         t.obs_frame, t.obs_stack, t.num_obs = e.num_single_obs, e.frame_stack, e.num_estimator_features
@@ -177,6 +207,7 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
     t.base_height_sigma = getattr(r, "base_height_tracking_sigma", 0.01)
     t.euler_sigma = getattr(r, "euler_tracking_sigma", 0.1)
     t.foot_distance_threshold = getattr(r, "foot_distance_threshold", 0.0)
+    t.foot_clearance_ref = {"none": 0, "mean": 1, "max": 2}[getattr(cfg.reset, "foot_clearance_ref", "none")]
     sc = cfg.normalization.obs_scales
     t.obs_scale_lin_vel, t.obs_scale_ang_vel = sc.lin_vel, sc.ang_vel
     t.obs_scale_dof_pos, t.obs_scale_dof_vel, t.obs_scale_height = sc.dof_pos, sc.dof_vel, sc.height_measurements

@@ -291,7 +291,66 @@ class GO2EECfg(LeggedRobotCfg):
         joint_armature_range=[0.015, 0.025], joint_friction_range=[0.01, 0.02], joint_damping_range=[0.25, 0.3])
     # go2_ee.py:77-98 (per-joint reset ranges), legged_robot.py:283-298 (base-class root reset), :124-134 (air time 0.25)
     reset = section(dof_ranges={"hip": 0.2, "thigh": 0.4, "calf": 0.4}, root_vel_range=0.5, robot="go2",
-                    obs_layout="go2_ee", feet_air_time_threshold=0.25)
+                    obs_layout="go2_ee", feet_air_time_threshold=0.25, foot_clearance_ref="mean")
+
+
+# ---- the other Go2-rough task heads (legged_gym/envs/__init__.py:82-86): same robot, terrain, rewards, resets and domain
+# randomisation as go2_ee (verified by diffing the reference's instantiated config trees); they differ in how the step's
+# outputs are packaged.  Frames are described as observation programs (include/lgsim.h LgObsSeg): (block, extra scale).
+# K = 17 contact-state links AS CONFIGURED (Go2RoughCommonCfg.asset.contact_state_link_names, common_cfgs.py:100-101); the
+# reference's own size fields (go2_ts_config.py:8-14: 94 = 82 + 12, 172 = 160 + 12) were written for 12 links, so its critic
+# deque starts with 172-wide zero frames and fills with 177-wide real ones.  Pinned here: what the reference EMITS per step
+# (tests/golden/go2_ts_mdp.npz ...): privileged 99, critic frame 177; the history is 5 x 177 from the first step on.
+_TS_CRITIC = [("frame", 1.0), ("dr", 1.0), ("base_lin_vel", 1.0), ("contact_states", 1.0), ("heights", 1.0)]
+
+
+# go2/go2_ts/go2_ts_config.py:5-92 (Go2TSCfg) + go2_ts.py:5-86
+class GO2TSCfg(GO2EECfg):
+    env = section(GO2EECfg.env, num_observations=45, num_privileged_obs=31 + 36 + 12 + 3 + 17, frame_stack=20, num_history_obs=45 * 20,
+                  num_latent_dims=31 + 36 + 12 + 3 + 17, c_frame_stack=5, single_critic_obs_len=45 + 31 + 3 + 17 + 81,
+                  num_critic_obs=5 * (45 + 31 + 3 + 17 + 81), env_spacing=0.5)
+    reset = section(GO2EECfg.reset, obs_layout="program", critic_program=_TS_CRITIC, critic_clip=False,
+                    aux_program=[("dr", 1.0), ("feet_rel_heights", 1.0), ("feet_normals", 1.0), ("base_lin_vel", 1.0),
+                                 ("contact_states", 1.0)], aux_clip=True)
+
+
+# go2/go2_cts/go2_cts_config.py:5-82 (Go2CTSCfg) + go2_cts.py:11-95: privileged frame carries the raw heights around the feet
+class GO2CTSCfg(GO2TSCfg):
+    env = section(GO2TSCfg.env, num_teacher=4096 // 4 * 3, env_spacing=1.0)
+    domain_rand = section(GO2TSCfg.domain_rand, joint_friction_range=[0.0, 0.1])
+    # go2_cts.py:156-170: foot clearance above the MAX of the heights around the foot (TS / EE / Dreamwaq / CaT use the mean)
+    reset = section(GO2TSCfg.reset, foot_clearance_ref="max",
+                    aux_program=[("dr", 1.0), ("feet_heights", 1.0), ("feet_normals", 1.0), ("base_lin_vel", 1.0), ("contact_states", 1.0)])
+
+
+# go2/go2_dreamwaq/go2_dreamwaq_config.py:5-87 (Go2DreamwaqCfg) + go2_dreamwaq.py:7-84: the critic stack is returned as the
+# privileged observation (clipped), the auxiliary row is [explicit labels 24 | next state 45]
+class GO2DreamwaqCfg(GO2EECfg):
+    env = section(GO2EECfg.env, num_envs=3000, num_observations=45, frame_stack=20, num_history_obs=45 * 20, num_latent_dims=16,
+                  num_explicit_dims=24, num_decoder_output=45, c_frame_stack=5, single_critic_obs_len=45 + 31 + 81 + 17 + 3,
+                  num_privileged_obs=5 * (45 + 31 + 81 + 17 + 3), env_spacing=1.0)
+    reset = section(GO2EECfg.reset, obs_layout="program",
+                    critic_program=[("base_lin_vel", 1.0), ("frame", 1.0), ("dr", 1.0), ("contact_states", 1.0), ("heights", 1.0)],
+                    critic_clip=True,
+                    aux_program=[("base_lin_vel", 0.5), ("contact_states", 1.0), ("foot_clearance", 1.0), ("next_state", 1.0)],
+                    aux_clip=False)
+
+
+# go2/go2_cat/go2_cat_config.py:4-45 (Go2CaTCfg) + go2_cat.py: constraints as terminations on top of the TS packaging
+class GO2CaTCfg(GO2TSCfg):
+    env = section(GO2TSCfg.env, num_privileged_obs=34 + 36 + 12 + 17, num_latent_dims=34 + 36 + 12 + 17,
+                  single_critic_obs_len=45 + 34 + 17 + 81, num_critic_obs=5 * (45 + 34 + 17 + 81))
+    rewards = section(
+        GO2TSCfg.rewards, soft_dof_pos_limit=0.9, base_height_target=0.34, foot_clearance_target=0.09, foot_height_offset=0.022,
+        foot_clearance_tracking_sigma=0.01, only_positive_rewards=True,
+        scales=section(GO2TSCfg.rewards.scales, dof_pos_limits=0.0, collision=0.0, dof_pos_stand_still=0.0, lin_vel_z=-1.0,
+                       orientation=-0.5, hip_pos=-0.2, dof_close_to_default=-0.05, foot_clearance=0.2))
+    constraints = section(enable="cat", tau_constraint=0.95, soft_p=0.25,
+                          limits=section(action_rate=100.0, max_projected_gravity=-0.1, min_base_height=0.25))
+    normalization = section(GO2TSCfg.normalization, clip_actions=10.0)
+    reset = section(GO2TSCfg.reset,
+                    critic_program=[("frame", 1.0), ("dr", 1.0), ("dr_joint", 1.0), ("contact_states", 1.0), ("heights", 1.0)],
+                    aux_program=[("dr", 1.0), ("dr_joint", 1.0), ("feet_heights", 1.0), ("feet_normals", 1.0), ("contact_states", 1.0)])
 
 
 # tron1_pf/tron1_pf_ee/tron1_pf_ee_config.py:4-174 (TRON1PF_EECfg, experiment "tron1_pf_rough"): 6-DOF point-foot biped
@@ -346,4 +405,4 @@ class TRON1PFEECfg(LeggedRobotCfg):
     normalization = section(LeggedRobotCfg.normalization, clip_actions=20.0)
     # tron1_pf_ee.py:258-275 (per-joint reset ranges), base-class root reset, sit-pose branch :204-210, 277-310
     reset = section(dof_ranges={"abad": 0.2, "hip": 0.4, "knee": 0.4}, root_vel_range=0.5, robot="tron1_pf",
-                    obs_layout="tron1_ee", feet_air_time_threshold=0.3)
+                    obs_layout="tron1_ee", feet_air_time_threshold=0.3, foot_clearance_ref="max")

@@ -69,6 +69,7 @@ struct LgHot {
     float base_height_sigma;
     float euler_sigma;
     float foot_distance_threshold;
+    int32_t foot_clearance_ref;
     float obs_scale_lin_vel;
     float obs_scale_ang_vel;
     float obs_scale_dof_pos;
@@ -189,6 +190,7 @@ static void fill_hot(LgHot &H, const LgTaskCfg &t, const LgSimOptions &o, const 
     H.base_height_sigma = t.base_height_sigma;
     H.euler_sigma = t.euler_sigma;
     H.foot_distance_threshold = t.foot_distance_threshold;
+    H.foot_clearance_ref = t.foot_clearance_ref;
     H.obs_scale_lin_vel = t.obs_scale_lin_vel;
     H.obs_scale_ang_vel = t.obs_scale_ang_vel;
     H.obs_scale_dof_pos = t.obs_scale_dof_pos;
@@ -1538,8 +1540,9 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         }
         if (RON(LG_R_FOOT_CLEARANCE)) {                           // :575-588
             const float vxy = sqrtf(foot_v.x * foot_v.x + foot_v.y * foot_v.y);
-            // go2_ee.py:136-150 measures the clearance above the mean terrain height around the foot
-            const float d = foot_p.z - (hc_obs_layout == LG_OBS_GO2_EE ? foot_hmean : (hc_obs_layout == LG_OBS_TRON1_EE ? foot_hmax : 0.f))
+            // go2_ee.py:136-150 measures the clearance above the mean terrain height around the foot, tron1_pf_ee.py:442-456 and
+            // go2_cts.py:156-170 above the max (LgTaskCfg.foot_clearance_ref)
+            const float d = foot_p.z - (HOT(foot_clearance_ref) == 1 ? foot_hmean : (HOT(foot_clearance_ref) == 2 ? foot_hmax : 0.f))
                             - hc_foot_clearance_target - hc_foot_height_offset;   // tron1_pf_ee.py:442-456 uses the max
             const float err = quad_sum<LEGS>(vxy * (d * d));
             add(LG_R_FOOT_CLEARANCE, __expf(-err / hc_foot_clearance_sigma));
@@ -1887,8 +1890,20 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 rs.block3(3 * LEGS + 2 + leg, uclk[0], uclk[1], dummy);
             }
         }
+        // observation programs: where the noise-free actor frame sits inside the critic frame (0 in the fixed layouts, -1: not at
+        // all) and where the "next state" copy goes in the labels row (-1: none)
+        int pfo = 0, nxo = -1;
+        float *labp = nullptr;
+        if (hc_obs_layout == LG_OBS_PROGRAM) {
+            pfo = -1;
+            for (int s_ = 0; s_ < T->priv_prog.n_segs; s_++) if (T->priv_prog.kind[s_] == LG_SEG_FRAME) pfo = T->priv_prog.offset[s_];
+            for (int s_ = 0; s_ < T->labels_prog.n_segs; s_++) if (T->labels_prog.kind[s_] == LG_SEG_NEXT_STATE) nxo = T->labels_prog.offset[s_];
+            if (B.labels_buf) labp = B.labels_buf + ((size_t)cs * N + e) * hc_num_labels;
+        }
+        const float pclip = (hc_obs_layout == LG_OBS_PROGRAM && !T->priv_prog.clip) ? 3.0e38f : co;
         auto put = [&](int idx, float v, float u, float nscale) {   // critic copy of the frame is noise-free
-            if (pn) { const float c = clampf(v, -co, co); pn[idx] = c; if (pn2) pn2[idx] = c; }
+            if (pn && pfo >= 0) { const float c = clampf(v, -pclip, pclip); pn[pfo + idx] = c; if (pn2) pn2[pfo + idx] = c; }
+            if (nxo >= 0) labp[nxo + idx] = idx >= 9 + 2 * A ? v * HOT(o_action_scale) : v;     // go2_dreamwaq.py:66-74, not clipped
             if (nz) v += (2.f * u - 1.f) * nscale;
             const float c = clampf(v, -co, co);
             on[idx] = c;
@@ -2039,6 +2054,85 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 if (M->state_link_mask & 1u) { const float cst = norm(f_base) > 1.f ? 1.f : 0.f; putp(oK, cst); lab[3] = cst; }
                 lab[0] = blv.x * hc_obs_scale_lin_vel; lab[1] = blv.y * hc_obs_scale_lin_vel; lab[2] = blv.z * hc_obs_scale_lin_vel;
             }
+        } else if (hc_obs_layout == LG_OBS_PROGRAM) {
+            // go2_ts / go2_cts / go2_dreamwaq / go2_cat: actor frame = go2's 45 (written above); the critic frame and the
+            // auxiliary output are concatenations of the blocks of LgObsSeg at the offsets the task's programs give
+            const int K = __popc(M->state_link_mask);
+            const int l0 = foot_link - 3;
+            auto run = [&](const LgObsProgram &pr, const bool to_lab) {
+                const float cl = pr.clip ? co : 3.0e38f;
+                auto Wr = [&](int idx, float v) {
+                    v = clampf(v, -cl, cl);
+                    if (to_lab) labp[idx] = v;
+                    else { pn[idx] = v; if (pn2) pn2[idx] = v; }
+                };
+                for (int s_ = 0; s_ < pr.n_segs; s_++) {
+                    const int kind = pr.kind[s_], off = pr.offset[s_];
+                    const float sc = pr.scale[s_];
+                    if (kind == LG_SEG_DR) {
+                        if (live) {
+#pragma unroll
+                            for (int j = 0; j < 3; j++) { Wr(off + 7 + d0 + j, ld_kp[j] - HOT(kp_offset)); Wr(off + 7 + A + d0 + j, ld_kd[j] - HOT(kd_offset)); }
+                        }
+                        if (lead) {
+                            Wr(off + 0, ld_fric - HOT(friction_offset)); Wr(off + 1, ld_mass);
+                            Wr(off + 2, ld_com[0]); Wr(off + 3, ld_com[1]); Wr(off + 4, ld_com[2]);
+                            Wr(off + 5, ld_push[0]); Wr(off + 6, ld_push[1]);
+                        }
+                    } else if (kind == LG_SEG_DR_JOINT) {
+                        if (lead) { Wr(off + 0, ld_jnt[0]); Wr(off + 1, ld_jnt[1]); Wr(off + 2, ld_jnt[2]); }
+                    } else if (kind == LG_SEG_BASE_LIN_VEL) {
+                        if (lead) { Wr(off + 0, blv.x * hc_obs_scale_lin_vel * sc); Wr(off + 1, blv.y * hc_obs_scale_lin_vel * sc); Wr(off + 2, blv.z * hc_obs_scale_lin_vel * sc); }
+                    } else if (kind == LG_SEG_CONTACT_STATES) {
+                        // contact states are those of the physics read-back (stale for a just-reset env, as in the reference)
+                        if (live) {
+#pragma unroll
+                            for (int k = 0; k < 4; k++) {
+                                const int l = l0 + k;
+                                if ((M->state_link_mask >> l) & 1u) Wr(off + __popc(M->state_link_mask & ((1u << l) - 1u)), norm(f_link[k]) > 1.f ? 1.f : 0.f);
+                            }
+                        }
+                        if (lead && (M->state_link_mask & 1u)) Wr(off, norm(f_base) > 1.f ? 1.f : 0.f);
+                    } else if (kind == LG_SEG_HEIGHTS) {
+                        if (live) {
+                            if (hreg) {
+#pragma unroll
+                                for (int i = 0; i < HMAX; i++) {
+                                    const int k = leg + i * LEGS;
+                                    float hv = pos.z - hc_heights_offset - hts[i];
+                                    if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
+                                    if (k < P) Wr(off + k, hv);
+                                }
+                            } else {
+                                for (int k = leg; k < P; k += LEGS) {
+                                    float hv = pos.z - hc_heights_offset - B.measured_heights[(size_t)e * P + k];
+                                    if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
+                                    Wr(off + k, hv);
+                                }
+                            }
+                        }
+                    } else if (kind == LG_SEG_FEET_REL_HEIGHTS) {
+                        if (live) {
+#pragma unroll
+                            for (int k = 0; k < 9; k++) Wr(off + 9 * foot_slot + k, clampf(foot_p.z - ld_haf[k], -1.f, 1.f));
+                        }
+                    } else if (kind == LG_SEG_FEET_HEIGHTS) {
+                        if (live) {
+#pragma unroll
+                            for (int k = 0; k < 9; k++) Wr(off + 9 * foot_slot + k, ld_haf[k]);
+                        }
+                    } else if (kind == LG_SEG_FEET_NORMALS) {
+                        if (live) {
+#pragma unroll
+                            for (int k = 0; k < 3; k++) Wr(off + 3 * foot_slot + k, ld_nv3[k]);
+                        }
+                    } else if (kind == LG_SEG_FOOT_CLEARANCE) {
+                        if (live) Wr(off + foot_slot, clampf(foot_p.z - foot_hmean - hc_foot_height_offset, -1.f, 1.f));
+                    }   // LG_SEG_FRAME / LG_SEG_NEXT_STATE: written entry by entry in put()
+                }
+            };
+            if (pn) run(T->priv_prog, false);
+            if (labp) run(T->labels_prog, true);
         }
     }
     if (WTW && lead) {

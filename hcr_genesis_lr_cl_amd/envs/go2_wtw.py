@@ -60,11 +60,19 @@ class GO2WTW(LeggedRobot):
         self._update_behavior_param_curriculum(env_ids)
 
     def _update_behavior_param_curriculum(self, env_ids):
-        """go2_wtw.py:220-247."""
-        if len(env_ids) == 0:
-            return
+        """go2_wtw.py:220-247.  The means run over the resetting envs of EVERY rank (distributed.global_mean, called on all
+        ranks at the gate step, also with no local reset), so the behaviour ranges and the gait set advance identically on
+        all shards, as in a single-process run."""
+        from ..distributed import global_mean
         es, L = self._engine.buf["episode_sums"], self.max_episode_length
-        m = lambda name: float(torch.mean(es[abi.REWARD_ID[name]][env_ids])) / L
+        n = len(env_ids)
+        stats = {}
+        for name in ("quad_periodic_gait", "tracking_base_height", "tracking_foot_clearance", "tracking_orientation"):
+            local = es[abi.REWARD_ID[name]][env_ids].sum() if n > 0 else torch.zeros((), device=self.device)
+            stats[name], count = global_mean(local, n)
+        if count == 0:
+            return
+        m = lambda name: stats[name] / L
         if m("quad_periodic_gait") > 0.8 * self.reward_scales["quad_periodic_gait"]:
             self.gait_period_range[0] = max(self.gait_period_range[0] - 0.05, self.gait_period_min)
             self.gait_period_range[1] = min(self.gait_period_range[1] + 0.05, self.gait_period_max)

@@ -164,8 +164,7 @@ class LeggedRobot:
             self._engine.step(abi.PHASE_PRE | abi.PHASE_SIM | abi.PHASE_POST, actions, c)
             env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()
             self._update_command_curriculum(env_ids)      # collective across ranks: called even with no local reset
-            if len(env_ids) > 0:
-                self._on_curriculum_gate(env_ids)
+            self._on_curriculum_gate(env_ids)             # likewise (task curricula reduce over all ranks too)
             self._engine.step(abi.PHASE_RESET, None, c)
         else:
             self._engine.step(abi.PHASE_ALL, actions, c)

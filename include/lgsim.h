@@ -119,8 +119,35 @@ enum LgObsLayout {
     LG_OBS_GO2 = 0,      /* go2.py:40-56        45 */
     LG_OBS_GO2_WTW = 1,  /* go2_wtw.py:53-111   61x5 / 99x5 */
     LG_OBS_GO2_EE = 2,   /* go2_ee.py:10-75     45x20 / 174x5 / 24 labels */
-    LG_OBS_TRON1_EE = 3  /* tron1_pf_ee.py:53-141 31x10 / 134x10 / 17 labels */
+    LG_OBS_TRON1_EE = 3, /* tron1_pf_ee.py:53-141 31x10 / 134x10 / 17 labels */
+    LG_OBS_PROGRAM = 4   /* go2 actor frame 45 x stack; critic frame and labels assembled by LgTaskCfg.priv_prog / labels_prog */
 };
+
+/* Observation programs (obs_layout == LG_OBS_PROGRAM): the critic frame and the auxiliary per-step output ("labels") of the
+ * Go2-rough task heads are concatenations of the same few blocks in different orders (go2_ts.py:16-86, go2_cts.py:13-87,
+ * go2_dreamwaq.py:7-84, go2_cat.py:19-95).  A program lists the blocks with the offset each one starts at. */
+enum LgObsSeg {
+    LG_SEG_END = 0,
+    LG_SEG_FRAME,         /* the actor frame without noise (obs_frame wide) */
+    LG_SEG_DR,            /* friction - offset, added mass, CoM 3, push xy 2, kp - offset A, kd - offset A (go2_ts.py:26-37) */
+    LG_SEG_DR_JOINT,      /* joint armature, frictionloss, damping (go2_cat.py:40-42) */
+    LG_SEG_BASE_LIN_VEL,  /* body-frame base velocity * obs_scales.lin_vel * scale */
+    LG_SEG_CONTACT_STATES,/* link_contact_states (genesis_simulator.py:53-55), K wide */
+    LG_SEG_HEIGHTS,       /* clip(base_z - heights_offset - measured_heights, +-1) * obs_scales.height_measurements, P wide */
+    LG_SEG_FEET_REL_HEIGHTS, /* clip(foot_z - height_around_feet, +-1), 9 F (go2_ts.py:72) */
+    LG_SEG_FEET_HEIGHTS,  /* height_around_feet, 9 F (go2_cts.py:73) */
+    LG_SEG_FEET_NORMALS,  /* normal_vector_around_feet, 3 F */
+    LG_SEG_FOOT_CLEARANCE,/* clip(foot_z - mean(height_around_feet) - foot_height_offset, +-1), F (go2_dreamwaq.py:79-81) */
+    LG_SEG_NEXT_STATE     /* the actor frame without noise, actions * action_scale (go2_dreamwaq.py:66-74) */
+};
+#define LG_MAX_SEGS 8
+typedef struct LgObsProgram {
+    int32_t n_segs;
+    int32_t clip;                 /* 1: clip every entry to +-clip_obs (what step() does to that output in the reference) */
+    int32_t kind[LG_MAX_SEGS];    /* enum LgObsSeg */
+    int32_t offset[LG_MAX_SEGS];  /* first column of the block inside the frame */
+    float scale[LG_MAX_SEGS];     /* extra factor (LG_SEG_BASE_LIN_VEL: 0.5 for dreamwaq's explicit labels), else 1 */
+} LgObsProgram;
 
 /* uniform-draw slot layout: every random number the reference draws per env per step has a
  * fixed slot so that tests can inject the reference's own draws (rand_in) and the Philox
@@ -178,6 +205,9 @@ typedef struct LgTaskCfg {
     float tracking_sigma, base_height_target, foot_clearance_target, foot_height_offset;
     float foot_clearance_sigma, about_landing_threshold, feet_air_time_threshold;
     float base_height_sigma, euler_sigma, foot_distance_threshold;
+    int32_t foot_clearance_ref;      /* terrain height _reward_foot_clearance measures from: 0 none (legged_robot.py:575-588), 1 mean of the
+                                      * 9 heights around the foot (go2_ee.py:136-150, go2_ts.py:146-160), 2 their max (tron1_pf_ee.py:442-456,
+                                      * go2_cts.py:156-170) */
     float obs_scale_lin_vel, obs_scale_ang_vel, obs_scale_dof_pos, obs_scale_dof_vel, obs_scale_height;
     int32_t add_noise;
     float noise_vec[LG_MAX_OBS];     /* _get_noise_scale_vec (go2.py:92-117) */
@@ -211,6 +241,7 @@ typedef struct LgTaskCfg {
     float sit_percent;               /* 0 = feature off */
     float sit_pos[3], sit_quat[4], sit_dof_pos[LG_MAX_DOF];
     int32_t task_state_width;
+    LgObsProgram priv_prog, labels_prog; /* obs_layout == LG_OBS_PROGRAM */
     LgRandSlots slots;
     uint64_t seed;
     int64_t env_id_offset;           /* global index of local env 0 (multi-GPU sharding) */

@@ -132,7 +132,7 @@ class MdpOracle:
         self.terrain_levels = np.zeros(N, np.int64)
         self.terrain_types = np.zeros(N, np.int64)
         self.terrain_origins = None
-        if task.obs_layout == abi.OBS_GO2_EE:
+        if task.obs_layout in (abi.OBS_GO2_EE, abi.OBS_PROGRAM):
             self.obs_hist = z(N, task.obs_stack, task.obs_frame)
             self.priv_hist = z(N, task.priv_stack, task.priv_frame)
         if task.gait_mode == 1:
@@ -335,9 +335,9 @@ class MdpOracle:
         if on("foot_clearance"):                                           # :575-588
             vxy = np.linalg.norm(feet_vel[:, :, :2], axis=-1)
             zf = feet_pos[:, :, 2]
-            if T.obs_layout == abi.OBS_GO2_EE:                                # go2_ee.py:136-150
+            if T.foot_clearance_ref == 1:                                     # go2_ee.py:136-150, go2_ts.py:146-160
                 zf = zf - np.mean(sim["height_around_feet"].reshape(N, F, 9), axis=-1)
-            elif T.obs_layout == abi.OBS_TRON1_EE:                            # tron1_pf_ee.py:442-456
+            elif T.foot_clearance_ref == 2:                                   # tron1_pf_ee.py:442-456, go2_cts.py:156-170
                 zf = zf - np.max(sim["height_around_feet"].reshape(N, F, 9), axis=-1)
             err = np.sum(vxy * (zf - f32(T.foot_clearance_target) - f32(T.foot_height_offset)) ** 2, axis=-1)
             add("foot_clearance", np.exp(-err / f32(T.foot_clearance_sigma)))
@@ -559,6 +559,46 @@ class MdpOracle:
             self.priv_obs_buf = np.clip(self.priv_hist.reshape(N, -1), -co, co).astype(f32)
             fh = np.clip(fpz - np.max(har, axis=-1) - f32(T.foot_height_offset), -1, 1)
             self.labels_buf = np.concatenate([blv * f32(T.obs_scale_lin_vel), states, fh, sim["normals"]], axis=1).astype(f32)
+        elif T.obs_layout == abi.OBS_PROGRAM:   # go2_ts.py:5-86, go2_cts.py:11-87, go2_dreamwaq.py:7-84, go2_cat.py:19-95
+            cs = np.array([T.obs_scale_lin_vel, T.obs_scale_lin_vel, T.obs_scale_ang_vel], f32)
+            head = [self.commands[:, :3] * cs, pg, bav * f32(T.obs_scale_ang_vel), (sim["dof_pos"] - self.q0) * f32(T.obs_scale_dof_pos),
+                    sim["dof_vel"] * f32(T.obs_scale_dof_vel)]
+            frame = np.concatenate(head + [self.actions], axis=1).astype(f32)
+            har = sim["height_around_feet"].reshape(N, F, 9)
+            fpz = sim["feet_pos"].reshape(N, F, 3)[:, :, 2]
+            blocks = {
+                abi.SEG_FRAME: lambda sc_: frame,
+                abi.SEG_DR: lambda sc_: np.concatenate([self.friction_values - f32(T.friction_offset), self.added_base_mass, self.base_com_bias,
+                                                        self.rand_push_vels[:, :2], self.kp_scale - f32(T.kp_offset),
+                                                        self.kd_scale - f32(T.kd_offset)], axis=1),
+                abi.SEG_DR_JOINT: lambda sc_: np.concatenate([self.joint_armature, self.joint_friction, self.joint_damping], axis=1),
+                abi.SEG_BASE_LIN_VEL: lambda sc_: blv * f32(T.obs_scale_lin_vel) * f32(sc_),
+                abi.SEG_CONTACT_STATES: lambda sc_: (1.0 * (np.linalg.norm(F_l[:, self.state_links], axis=-1) > 1.0)).astype(f32),
+                abi.SEG_HEIGHTS: lambda sc_: np.clip(sim["base_pos"][:, 2:3] - f32(T.heights_offset) - sim["measured_heights"], -1, 1) * f32(T.obs_scale_height),
+                abi.SEG_FEET_REL_HEIGHTS: lambda sc_: np.clip((fpz[:, :, None] - har).reshape(N, -1), -1.0, 1.0),
+                abi.SEG_FEET_HEIGHTS: lambda sc_: har.reshape(N, -1),
+                abi.SEG_FEET_NORMALS: lambda sc_: sim["normals"],
+                abi.SEG_FOOT_CLEARANCE: lambda sc_: np.clip(fpz - np.mean(har, axis=-1) - f32(T.foot_height_offset), -1, 1),
+                abi.SEG_NEXT_STATE: lambda sc_: np.concatenate(head + [self.actions * f32(self.cfg.control.action_scale)], axis=1),
+            }
+
+            def run(prog):
+                parts = [blocks[prog.kind[i]](prog.scale[i]).astype(f32) for i in range(prog.n_segs)]
+                off = 0
+                for i, p_ in enumerate(parts):
+                    assert prog.offset[i] == off, (i, prog.offset[i], off)
+                    off += p_.shape[1]
+                v = np.concatenate(parts, axis=1).astype(f32)
+                return np.clip(v, -f32(T.clip_obs), f32(T.clip_obs)).astype(f32) if prog.clip else v
+            crit = run(T.priv_prog)
+            now = frame
+            if T.add_noise:
+                now = frame + (f32(2) * R[:, S.noise:S.noise + frame.shape[1]] - f32(1)) * self.noise_vec
+            self.obs_hist = np.concatenate([self.obs_hist[:, 1:], now[:, None]], axis=1)
+            self.priv_hist = np.concatenate([self.priv_hist[:, 1:], crit[:, None]], axis=1)
+            self.obs_buf = self.obs_hist.reshape(N, -1).astype(f32)          # the history itself is not clipped (legged_robot_ts.py:71)
+            self.priv_obs_buf = self.priv_hist.reshape(N, -1).astype(f32)
+            self.labels_buf = run(T.labels_prog)
         else:
             raise NotImplementedError
         if T.double_shift:                                                   # go2_wtw.py:45-46

@@ -665,8 +665,125 @@ def gen_tron1(N=24, T=48, seed=31):
         torch.rand_like, torch.rand, np.random.random = orig
 
 
+def gen_head(name, N=16, T=36, seed=41):
+    """The other Go2-rough heads -- Go2TS, Go2CTS, Go2Dreamwaq, Go2CaT (legged_gym/envs/__init__.py:82-86) -- run AS CONFIGURED
+    on the rough fake simulator: same recording as gen_ee.  Stored per step: the clipped actor frame, the newest frame of the
+    20-deep actor history and of the 5-deep critic stack, and the single-frame auxiliary output (TS / CTS / CaT: privileged
+    encoder input; Dreamwaq: explicit labels | next state), plus the full stacks at the last step.  As configured the asset
+    selects 17 contact-state links while the size fields assume 12 (go2_ts_config.py:8-14): what the class EMITS is pinned."""
+    import importlib
+    import legged_gym.envs.base.base_task as base_task
+    import legged_gym.envs.base.legged_robot as lr_mod
+    from legged_gym.utils.helpers import class_to_dict
+    from hcr_genesis_lr_cl_amd import config as mycfg
+    mod_name, cls_name, cfg_mod, cfg_name, my_name = {
+        "go2_ts": ("legged_gym.envs.go2.go2_ts.go2_ts", "Go2TS", "legged_gym.envs.go2.go2_ts.go2_ts_config", "Go2TSCfg", "GO2TSCfg"),
+        "go2_cts": ("legged_gym.envs.go2.go2_cts.go2_cts", "Go2CTS", "legged_gym.envs.go2.go2_cts.go2_cts_config", "Go2CTSCfg", "GO2CTSCfg"),
+        "go2_dreamwaq": ("legged_gym.envs.go2.go2_dreamwaq.go2_dreamwaq", "Go2Dreamwaq", "legged_gym.envs.go2.go2_dreamwaq.go2_dreamwaq_config",
+                         "Go2DreamwaqCfg", "GO2DreamwaqCfg"),
+        "go2_cat": ("legged_gym.envs.go2.go2_cat.go2_cat", "Go2CaT", "legged_gym.envs.go2.go2_cat.go2_cat_config", "Go2CaTCfg", "GO2CaTCfg"),
+    }[name]
+    env_mod = importlib.import_module(mod_name)
+    ref_cfg_cls = getattr(importlib.import_module(cfg_mod), cfg_name)
+    rec = rh.DrawRecorder(seed)
+    base_task.GenesisSimulator = RoughFakeSimulator
+    lr_mod.torch_rand_float = rec.rand_float
+    env_mod.torch_rand_float = rec.rand_float
+    orig_rand_like = torch.rand_like
+    torch.rand_like = rec.rand_like
+    try:
+        cfg = ref_cfg_cls()
+        cfg.env.num_envs = N
+        if hasattr(cfg.env, "num_teacher"):
+            cfg.env.num_teacher = N // 4 * 3
+        env = getattr(env_mod, cls_name)(cfg, class_to_dict(cfg.sim), "cpu", True)
+        sim = env.simulator
+        sim.rec = rec
+        if name == "go2_cat":          # properties of the Simulator ABC the constraints read (simulator.py: torque_limits, dof_vel_limits)
+            type(sim).torque_limits = property(lambda s_: torch.tensor(s_.model.arrays["effort"], dtype=torch.float))
+            type(sim).dof_vel_limits = property(lambda s_: torch.tensor(s_._cfg.asset.dof_vel_limits, dtype=torch.float).unsqueeze(0))
+        rng = np.random.default_rng(seed + 1)
+        model = sim.model
+        script = make_script(rng, model, cfg, N, T)
+        org = sim._env_origins.numpy()
+        off = rng.normal(size=(T, N, 2)) * 1.5 + np.where(rng.random((T, N, 1)) < 0.3, 4.5, 0.0)
+        script["base_pos"][:, :, :2] = (org[None, :, :2] + off).astype(np.float32)
+        script["base_pos"][:, :, 2] += org[None, :, 2]
+        script["feet_pos"][:, :, :, :2] += script["base_pos"][:, :, None, :2]
+        script["feet_pos"][:, :, :, 2] += org[None, :, None, 2]
+        sim.script = script
+        task = builders.make_task_cfg(model, getattr(mycfg, my_name)())
+        slots = task.slots
+        groups = [[0, 3, 6, 9], [1, 4, 7, 10], [2, 5, 8, 11]]
+        env.episode_length_buf[:] = torch.from_numpy(rng.choice([3, 470, 495, 498, 499, 968, 972, 977, 981, 985, 989, 992, 995, 998, 999, 1000], N).astype(np.int32))
+        env.commands[:] = torch.from_numpy((rng.normal(size=(N, 4)) * [0.4, 0.4, 0.5, 1.5]).astype(np.float32))
+        env.commands[:3] = 0.0                                   # standing-still envs (feet_contact_stand_still, CaT's style constraint)
+        env.common_step_counter = 495
+        env.reset_buf[:] = 0
+        env.extras.setdefault("episode", {})      # exists after the runner's env.reset(); go2_cts.py:96 / go2_cat.py:101 index it on every step
+        rec.take()
+        init = dict(episode_length_buf=env.episode_length_buf.numpy().copy(), commands=env.commands.numpy().copy(),
+                    env_origins=sim._env_origins.numpy().copy(), terrain_levels=sim._terrain_levels.numpy().copy(),
+                    terrain_types=sim._terrain_types.numpy().copy(), height_points=sim._height_points[0, :, :2].numpy().copy())
+        keys = ("actions_in", "rand", "counter", "obs", "feat_new", "priv_new", "labels", "rew", "reset", "time_out", "commands", "ep_len",
+                "fail_buf", "feet_air_time", "episode_sums", "sim_dof_pos", "sim_base_pos", "terrain_levels", "env_origins",
+                "measured_heights", "height_around_feet", "normals", "contact_states", "last_dof_vel_in", "last_feet_vel_in", "esum_override",
+                "cstr_prob", "cstr_sums")
+        out = {k: [] for k in keys}
+        names = env.reward_names
+        cstr_names = ["torque", "dof_vel", "action_rate", "base_height", "collision", "feet_stumble", "dof_pos", "base_orientation", "stand_still"]
+        for t in range(T):
+            act = torch.from_numpy((rng.normal(size=(N, 12)) * (1.0 if t % 7 else 60.0)).astype(np.float32))
+            out["last_dof_vel_in"].append(sim._dof_vel.numpy().copy()); out["last_feet_vel_in"].append(sim._feet_vel.numpy().copy())
+            res = env.step(act)
+            if name == "go2_dreamwaq":
+                obs, critic, hist, explicit, nxt, rew, reset, extras = res
+                aux = torch.cat([explicit, nxt], dim=-1)
+            else:
+                obs, aux, hist, critic, rew, reset, extras = res
+            calls = rec.take()
+            FW = critic.shape[1] - 4 * cfg.env.single_critic_obs_len if t < 4 else critic.shape[1] // 5   # newest frame width
+            out["actions_in"].append(act.numpy().copy()); out["rand"].append(slots_from_calls(calls, slots, N, 12, groups))
+            out["counter"].append(env.common_step_counter); out["esum_override"].append(0.0)
+            out["obs"].append(obs.numpy().copy())
+            out["feat_new"].append(hist.numpy()[:, -45:].copy()); out["priv_new"].append(critic.numpy()[:, -177:].copy())
+            assert critic.shape[1] in (4 * cfg.env.single_critic_obs_len + 177, 3 * cfg.env.single_critic_obs_len + 2 * 177,
+                                       2 * cfg.env.single_critic_obs_len + 3 * 177, cfg.env.single_critic_obs_len + 4 * 177, 5 * 177), critic.shape
+            out["labels"].append(aux.numpy().copy()); out["rew"].append(rew.numpy().copy())
+            out["reset"].append(reset.numpy().astype(np.uint8)); out["time_out"].append(env.time_out_buf.numpy().astype(np.uint8))
+            out["commands"].append(env.commands.numpy().copy()); out["ep_len"].append(env.episode_length_buf.numpy().copy())
+            out["fail_buf"].append(env.fail_buf.numpy().copy()); out["feet_air_time"].append(env.feet_air_time.numpy().copy())
+            out["episode_sums"].append(np.stack([env.episode_sums[n].numpy().copy() for n in names]))
+            out["sim_dof_pos"].append(sim._dof_pos.numpy().copy()); out["sim_base_pos"].append(sim._base_pos.numpy().copy())
+            out["terrain_levels"].append(sim._terrain_levels.numpy().copy()); out["env_origins"].append(sim._env_origins.numpy().copy())
+            out["measured_heights"].append(sim._measured_heights.numpy().copy())
+            out["height_around_feet"].append(sim._height_around_feet.numpy().copy())
+            out["normals"].append(sim._normal_vector_around_feet.numpy().copy())
+            out["contact_states"].append(sim._link_contact_states.numpy().copy())
+            if name == "go2_cat":
+                out["cstr_prob"].append(env.cstr_prob.numpy().copy())
+                out["cstr_sums"].append(np.stack([env.episode_sums["cstr_" + n].numpy().copy() for n in cstr_names]))
+            else:
+                out["cstr_prob"].append(np.zeros(N, np.float32)); out["cstr_sums"].append(np.zeros((0, N), np.float32))
+        arrays = {k: np.stack(v) for k, v in out.items()}
+        arrays["feat_last"], arrays["priv_last"] = hist.numpy().copy(), critic.numpy().copy()
+        arrays.update({"script_" + k: v for k, v in sim.script.items()})
+        arrays.update({"init_" + k: v for k, v in init.items()})
+        arrays["reward_names"] = np.array(names)
+        arrays["terrain_seed"] = RoughFakeSimulator.TERRAIN_SEED
+        path = os.path.join(HERE, f"{name}_mdp.npz")
+        np.savez_compressed(path, **arrays)
+        print("wrote", path, os.path.getsize(path), "aux width", arrays["labels"].shape[-1], "critic stack", arrays["priv_last"].shape,
+              "resets/step", arrays["reset"].sum(1), "levels moved", int((arrays["terrain_levels"][-1] != init["terrain_levels"]).sum()))
+    finally:
+        torch.rand_like = orig_rand_like
+
+
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["go2", "wtw", "ee", "tron1"]
+    which = sys.argv[1:] or ["go2", "wtw", "ee", "tron1", "go2_ts", "go2_cts", "go2_dreamwaq", "go2_cat"]
+    for h in ("go2_ts", "go2_cts", "go2_dreamwaq", "go2_cat"):
+        if h in which:
+            gen_head(h)
     if "tron1" in which:
         gen_tron1()
     if "ee" in which:

@@ -228,13 +228,15 @@ def test_wtw_env_runs_and_histories_shift():
 
 # ------------------------------- go2_ee (rough terrain) ------------------------------------------
 class EEKernelStepper:
+    head = "go2_ee"
+
     def __init__(self, fx, N):
         import torch
         from hcr_genesis_lr_cl_amd import builders
         from hcr_genesis_lr_cl_amd.engine import Engine
         from hcr_genesis_lr_cl_amd.model_compiler import load_model
         from tests.test_mdp_oracle import ee_terrain
-        cfg, terrain = ee_terrain(fx)
+        cfg, terrain = ee_terrain(fx, self.head)
         self.cfg, self.terrain = cfg, terrain
         model = load_model("go2")
         desc, opts, task = builders.make_model_desc(model, cfg), builders.make_sim_options(model, cfg, terrain), builders.make_task_cfg(model, cfg)
@@ -256,23 +258,60 @@ class EEKernelStepper:
         load_sim(eng, sim)
         # terrain read-backs of the SIM phase (checked separately against the numpy sampler): injected
         put(eng, "measured_heights", fx["measured_heights"][t]); put(eng, "height_around_feet", fx["height_around_feet"][t])
+        put(eng, "normal_vector_around_feet", fx["normals"][t])
         put(eng, "rand_in", R)
         eng.step(abi.PHASE_PRE | abi.PHASE_POST | abi.PHASE_RESET, torch.from_numpy(actions).cuda(), counter)
         torch.cuda.synchronize()
         es = get(eng, "episode_sums")
         lab = get(eng, "labels_buf")
-        return dict(feat_new=get(eng, "obs_buf")[:, -45:], priv_new=get(eng, "priv_obs_buf")[:, -174:], labels=lab, rew=get(eng, "rew_buf"),
+        from tests.test_mdp_oracle import HEADS
+        W, cols = HEADS[self.head][1], HEADS[self.head][2]
+        return dict(feat_new=get(eng, "obs_buf")[:, -45:], priv_new=get(eng, "priv_obs_buf")[:, -W:], labels=lab, rew=get(eng, "rew_buf"),
                     reset=get(eng, "reset_buf"), time_out=get(eng, "time_out_buf"), commands=get(eng, "commands"),
                     ep_len=get(eng, "episode_length_buf"), fail_buf=get(eng, "fail_buf"), feet_air_time=get(eng, "feet_air_time"),
                     episode_sums=np.stack([es[abi.REWARD_ID[n]] for n in self.names]), sim_dof_pos=get(eng, "dof_pos"),
                     sim_base_pos=get(eng, "base_pos"), terrain_levels=get(eng, "terrain_levels"), env_origins=get(eng, "env_origins"),
                     measured_heights=fx["measured_heights"][t], height_around_feet=fx["height_around_feet"][t], normals=fx["normals"][t],
-                    contact_states=lab[:, 3:20], feat_full=get(eng, "obs_buf"), priv_full=get(eng, "priv_obs_buf"))
+                    contact_states=get(eng, "priv_obs_buf")[:, -W:][:, cols], feat_full=get(eng, "obs_buf"), priv_full=get(eng, "priv_obs_buf"),
+                    obs=get(eng, "obs_buf")[:, -45:])
 
 
 def test_kernel_reproduces_reference_go2_ee_golden_vectors():
     from tests.test_mdp_oracle import replay_ee, check_ee
     replay_ee(EEKernelStepper, lambda t, fx, out: check_ee(t, fx, out, rtol=1e-5, atol=5e-5))
+
+
+@pytest.mark.parametrize("head", ["go2_ts", "go2_cts", "go2_dreamwaq"])
+def test_kernel_reproduces_reference_head_golden_vectors(head):
+    """the other Go2-rough heads.  Golden vectors from the reference's own Go2TS / Go2CTS / Go2Dreamwaq classes as
+    configured (tests/golden/gen_mdp_fixtures.py gen_head): actor frame, newest frames of the 20-deep actor history and the
+    5-deep critic stack (full stacks at the last step), the single-frame auxiliary output, rewards, resets, curricula."""
+    from tests.test_mdp_oracle import replay_ee, check_head, head_gold
+    stepper = type("KStepper_" + head, (EEKernelStepper,), {"head": head})
+    replay_ee(stepper, lambda t, fx, out: check_head(t, fx, out, rtol=1e-5, atol=5e-5), head_gold(head))
+
+
+@pytest.mark.parametrize("head", ["go2_ts", "go2_cts", "go2_dreamwaq"])
+def test_head_env_returns_the_reference_tuple(head):
+    """Arity and shapes of step() / reset() / get_observations() (legged_robot_ts.py:59-83, legged_robot_dreamwaq.py:63-89)."""
+    import torch
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    env, cfg = make_env(head, 64)
+    r = env.reset()
+    out = env.step(torch.zeros(64, 12, device="cuda"))
+    if head == "go2_dreamwaq":
+        assert len(r) == 5 and len(out) == 8
+        obs, priv, hist, explicit, nxt, rew, done, extras = out
+        assert explicit.shape == (64, 24) and nxt.shape == (64, 45) and priv.shape == (64, 5 * 177)
+    else:
+        assert len(r) == 4 and len(out) == 7
+        obs, priv, hist, critic, rew, done, extras = out
+        assert priv.shape == (64, 99) and critic.shape == (64, 5 * 177)
+        if head == "go2_cts":
+            assert "teacher_terrain_level" in extras["episode"] and "student_terrain_level" in extras["episode"]
+    assert obs.shape == (64, 45) and hist.shape == (64, 900) and rew.shape == (64,) and done.dtype == torch.bool
+    assert torch.equal(obs, hist[:, -45:]) and all(torch.isfinite(o).all() for o in out[:-3])
+    assert [o.shape for o in env.get_observations()] == [o.shape for o in out[:len(r)]]
 
 
 def test_sim_phase_terrain_sampling_matches_numpy_sampler():

@@ -148,22 +148,32 @@ def test_mdp_oracle_reproduces_reference_go2_wtw():
 
 # ------------------------------- go2_ee (rough terrain) ------------------------------------------
 GOLD_EE = os.path.join(os.path.dirname(__file__), "golden", "go2_ee_mdp.npz")
+# the other Go2-rough heads replay through the same steppers: (config class, critic frame width, contact-state columns of the
+# critic frame, fixture)
+HEADS = {"go2_ee": ("GO2EECfg", 174, slice(76, 93)), "go2_ts": ("GO2TSCfg", 177, slice(79, 96)), "go2_cts": ("GO2CTSCfg", 177, slice(79, 96)),
+         "go2_dreamwaq": ("GO2DreamwaqCfg", 177, slice(79, 96)), "go2_cat": ("GO2CaTCfg", 177, slice(79, 96))}
 
 
-def ee_terrain(fx):
-    from hcr_genesis_lr_cl_amd.config import GO2EECfg
+def head_gold(head):
+    return os.path.join(os.path.dirname(__file__), "golden", f"{head}_mdp.npz")
+
+
+def ee_terrain(fx, head="go2_ee"):
+    from hcr_genesis_lr_cl_amd import config as cfgmod
     from hcr_genesis_lr_cl_amd.terrain import Terrain
-    cfg = GO2EECfg()
+    cfg = getattr(cfgmod, HEADS[head][0])()
     np.random.seed(int(fx["terrain_seed"]))
     return cfg, Terrain(cfg.terrain)
 
 
 class EEOracleStepper:
+    head = "go2_ee"
+
     def __init__(self, fx, N):
         import oracle.mdp_oracle as mo
         self.mo = mo
         model = load_model("go2")
-        self.cfg, self.terrain = ee_terrain(fx)
+        self.cfg, self.terrain = ee_terrain(fx, self.head)
         task = builders.make_task_cfg(model, self.cfg)
         o = self.o = MdpOracle(model, self.cfg, task, N, fx["init_env_origins"])
         o.episode_length_buf[:] = fx["init_episode_length_buf"]
@@ -182,13 +192,15 @@ class EEOracleStepper:
                                                                           c.horizontal_scale, c.vertical_scale)
         mh, har, nrm = sim["measured_heights"].copy(), sim["height_around_feet"].copy(), sim["normals"].copy()
         o.step(sim, actions, R, counter)
-        return dict(feat_new=o.obs_buf[:, -45:], priv_new=o.priv_obs_buf[:, -174:], labels=o.labels_buf, rew=o.rew_buf,
+        W, cols = HEADS[self.head][1], HEADS[self.head][2]
+        return dict(feat_new=o.obs_buf[:, -45:], priv_new=o.priv_obs_buf[:, -W:], labels=o.labels_buf, rew=o.rew_buf,
                     reset=o.reset_buf, time_out=o.time_out_buf, commands=o.commands, ep_len=o.episode_length_buf,
                     fail_buf=o.fail_buf, feet_air_time=o.feet_air_time,
                     episode_sums=np.stack([o.episode_sums[abi.REWARD_ID[n]] for n in self.names]),
                     sim_dof_pos=sim["dof_pos"], sim_base_pos=sim["base_pos"], terrain_levels=o.terrain_levels,
                     env_origins=o.env_origins, measured_heights=mh, height_around_feet=har, normals=nrm,
-                    contact_states=o.labels_buf[:, 3:20], feat_full=o.obs_buf, priv_full=o.priv_obs_buf)
+                    contact_states=o.priv_obs_buf[:, -W:][:, cols], feat_full=o.obs_buf, priv_full=o.priv_obs_buf,
+                    obs=np.clip(o.obs_buf[:, -45:], -100.0, 100.0))
 
 
 EE_EXACT = ("reset", "time_out", "ep_len", "fail_buf", "terrain_levels")
@@ -206,8 +218,8 @@ def check_ee(t, fx, out, rtol=2e-6, atol=2e-6):
         np.testing.assert_allclose(out["priv_full"], fx["priv_last"], rtol=rtol, atol=atol, err_msg="stacked critic obs")
 
 
-def replay_ee(make_stepper, check):
-    fx = np.load(GOLD_EE)
+def replay_ee(make_stepper, check, gold=GOLD_EE):
+    fx = np.load(gold)
     T, N = fx["rew"].shape
     st = make_stepper(fx, N)
     for t in range(T):
@@ -228,6 +240,29 @@ def test_ee_fixture_exercises_the_branches():
 
 def test_mdp_oracle_reproduces_reference_go2_ee():
     replay_ee(EEOracleStepper, check_ee)
+
+
+# ------------------------------- go2_ts / go2_cts / go2_dreamwaq (same physics and rewards, other packaging) ------------
+def check_head(t, fx, out, rtol=2e-6, atol=2e-6):
+    check_ee(t, fx, out, rtol, atol)
+    np.testing.assert_allclose(out["obs"], fx["obs"][t], rtol=rtol, atol=atol, err_msg=f"clipped actor frame @ step {t}")
+
+
+@pytest.mark.parametrize("head", ["go2_ts", "go2_cts", "go2_dreamwaq"])
+def test_head_fixture_is_what_the_reference_emits_as_configured(head):
+    """17 contact-state links as configured (common_cfgs.py:100-101) although the head's size fields assume 12
+    (go2_ts_config.py:8-14): privileged 99 wide / critic frames 177 wide."""
+    fx = np.load(head_gold(head))
+    assert fx["priv_new"].shape[-1] == 177 and fx["priv_last"].shape[-1] == 5 * 177 and fx["feat_last"].shape[-1] == 20 * 45
+    assert fx["labels"].shape[-1] == (69 if head == "go2_dreamwaq" else 99)
+    assert fx["reset"].sum() >= 6 and (fx["counter"] % 500 == 0).any()
+    np.testing.assert_array_equal(fx["obs"], np.clip(fx["feat_new"], -100, 100))      # obs = newest history frame, clipped
+
+
+@pytest.mark.parametrize("head", ["go2_ts", "go2_cts", "go2_dreamwaq"])
+def test_mdp_oracle_reproduces_reference_head(head):
+    stepper = type("Stepper_" + head, (EEOracleStepper,), {"head": head})
+    replay_ee(stepper, check_head, head_gold(head))
 
 
 # ------------------------------- tron1_pf_ee (biped, rough terrain) -------------------------------
