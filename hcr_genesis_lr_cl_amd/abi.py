@@ -78,6 +78,9 @@ class LgRandSlots(C.Structure):
 
 
 MAX_SEGS = 8
+NUM_CSTR = 9
+CR_ANY_FAST = 17
+CSTR_NAMES = ["torque", "dof_vel", "action_rate", "base_height", "collision", "feet_stumble", "dof_pos", "base_orientation", "stand_still"]
 (SEG_END, SEG_FRAME, SEG_DR, SEG_DR_JOINT, SEG_BASE_LIN_VEL, SEG_CONTACT_STATES, SEG_HEIGHTS, SEG_FEET_REL_HEIGHTS,
  SEG_FEET_HEIGHTS, SEG_FEET_NORMALS, SEG_FOOT_CLEARANCE, SEG_NEXT_STATE) = range(12)
 
@@ -121,6 +124,8 @@ class LgTaskCfg(C.Structure):
         ("sit_percent", f32), ("sit_pos", f32 * 3), ("sit_quat", f32 * 4), ("sit_dof_pos", f32 * MAX_DOF),
         ("task_state_width", i32),
         ("priv_prog", LgObsProgram), ("labels_prog", LgObsProgram),
+        ("cat_enable", i32), ("cat_soft_p", f32), ("cat_action_rate", f32), ("cat_min_base_height", f32),
+        ("cat_max_projected_gravity", f32), ("dof_vel_limits", f32 * MAX_DOF),
         ("slots", LgRandSlots), ("seed", u64), ("env_id_offset", i64),
     ]
 
@@ -140,7 +145,8 @@ _BUF_FIELDS = [
         "feet_air_time", "last_contacts", "episode_length_buf", "fail_buf",
         "reset_buf", "time_out_buf",
         "rew_buf", "obs_buf", "priv_obs_buf", "labels_buf", "obs_dirty",
-        "episode_sums", "episode_done_sums", "episode_done_step", "command_ranges", "task_state", "rand_in")],
+        "episode_sums", "episode_done_sums", "episode_done_step", "cstr_prob", "cstr_sums", "cstr_done_sums",
+        "command_ranges", "task_state", "rand_in")],
 ]
 
 

@@ -246,6 +246,14 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
     t.terrain_cols_n = cfg.terrain.num_cols
     t.terrain_env_length = cfg.terrain.terrain_length
     t.episode_length_s = cfg.env.episode_length_s
+    cst = getattr(cfg, "constraints", None)                          # go2_cat_config.py:24-33
+    if cst is not None and cst.enable == "cat":
+        t.cat_enable, t.cat_soft_p = 1, cst.soft_p
+        t.cat_action_rate, t.cat_min_base_height = cst.limits.action_rate, cst.limits.min_base_height
+        t.cat_max_projected_gravity = cst.limits.max_projected_gravity
+        t.double_shift = 1                                             # go2_cat.py:119-122: second history shift at the end of the step
+    dvl = list(getattr(cfg.asset, "dof_vel_limits", [])) or [1e30] * A
+    abi.fill_array(t.dof_vel_limits, np.asarray(dvl, np.float32))
     t.seed = int(cfg.hip.seed if seed is None else seed)
     t.env_id_offset = int(env_id_offset)
     # history stacks: slide a window over rows with slack instead of moving the history every step (288 GB of HBM

@@ -1416,6 +1416,44 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
 #ifdef LG_DBG_RET_TERM
         if (p.counter >= 0) { if (lead) B.rew_buf[e] = cmd2 + (float)fail_buf + (reset ? 1.f : 0.f); return; }
 #endif
+        // ---- constraints as terminations (go2_cat.py:143-205): nine 0/1 violation flags; p = 1 for a violated hard constraint,
+        //      soft_p for a violated soft / style one (constraint_manager.py:25-74 with binary inputs), per-episode violation counts
+        float cat_keep = 1.f;     // (1 - p), applied to the reward before the positive clip (go2_cat.py:219-223)
+        float cstr_p = 0.f;
+        if (T->cat_enable) {
+            int c_tq = 0, c_qd = 0, c_ar = 0, lo_any = 0, hi_any = 0, c_fast = 0;
+#pragma unroll
+            for (int j = 0; j < 3; j++) {
+                c_tq |= fabsf(torque[j]) > M->effort[d0 + j] ? 1 : 0;
+                c_qd |= fabsf(qd[j]) > T->dof_vel_limits[d0 + j] ? 1 : 0;
+                c_ar |= fabsf(act[j] - last_act[j]) / cdt > T->cat_action_rate ? 1 : 0;
+                lo_any |= q[j] < soft_lo[j] ? 1 : 0;
+                hi_any |= q[j] > soft_hi[j] ? 1 : 0;
+                c_fast |= fabsf(qd[j]) > 4.0f ? 1 : 0;
+            }
+            int c_col = 0;
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if ((M->pen_link_mask >> (l0 + k)) & 1u) c_col |= norm(f_link[k]) > 10.0f ? 1 : 0;
+            const int c_stb = norm(f_link[3]) > 4.f * fabsf(f_link[3].z) ? 1 : 0;
+            // one packed OR over the env's lanes
+            int bits = c_tq | (c_qd << 1) | (c_ar << 2) | (c_col << 4) | (c_stb << 5) | (lo_any << 9) | (hi_any << 10) | (c_fast << 11);
+            bits = quad_or<LEGS>(bits);
+            if (M->pen_link_mask & 1u) bits |= norm(f_base) > 10.0f ? (1 << 4) : 0;
+            if (((P > 0 ? mean_height : pos.z)) < T->cat_min_base_height) bits |= 1 << 3;
+            if ((bits & (1 << 9)) && (bits & (1 << 10))) bits |= 1 << 6;                 // any(q < lo) * any(q > hi)  (go2_cat.py:170-171)
+            if (pg.z > T->cat_max_projected_gravity) bits |= 1 << 7;
+            const float cmdn = sqrtf(cmd0 * cmd0 + cmd1 * cmd1 + cmd2 * cmd2);
+            if (CR(LG_CR_ANY_FAST) != 0.f && cmdn < 0.1f) bits |= 1 << 8;               // job-wide motion flag x own zero command
+            bits &= 0x1FF;
+            cstr_p = (bits & 0xF0) ? 1.f : ((bits & 0x10F) ? T->cat_soft_p : 0.f);
+            cat_keep = 1.0f - cstr_p;
+            if (lead) {
+                B.cstr_prob[e] = cstr_p;
+#pragma unroll
+                for (int k = 0; k < LG_NUM_CSTR; k++) B.cstr_sums[(size_t)k * N + e] += (float)((bits >> k) & 1);
+            }
+        }
         // ---- compute_reward (legged_robot.py:150-168), alphabetical order ----
         float scl[LG_R_COUNT];   // one burst of broadcast LDS reads instead of one exposed round trip per active term
 #pragma unroll
@@ -1590,7 +1628,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         if (p.counter >= 0) { if (lead) B.rew_buf[e] = total + es[0] + es[5] + es[28]; return; }
 #endif
         STAMP(7);
-        if (hc_only_positive_rewards) total = fmaxf(total, 0.f);        // :161-162
+        if (hc_only_positive_rewards) total = fmaxf(total * cat_keep, 0.f);        // :161-162; go2_cat.py:219-223 scales by (1 - p) first
         if (RON(LG_R_TERMINATION)) add(LG_R_TERMINATION, (reset && !time_out) ? 1.f : 0.f);  // :163-168
         if (GAIT) {  // gait clock (go2_wtw.py:29-36, tron1_pf_ee.py:28-35).  The reference additionally restarts env 0's clock whenever
                      // ANY env wraps (index-flatten bug); that grid-wide coupling is deliberately not reproduced.
@@ -1785,6 +1823,10 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     if (RON(k)) { B.episode_done_sums[(size_t)k * N + e] = es[k]; es[k] = 0.f; }
                 }
                 B.episode_done_step[e] = (int)p.counter;
+                if (B.cstr_sums) {      // the constraint counters live in episode_sums in the reference and are logged / zeroed with them
+#pragma unroll
+                    for (int k = 0; k < LG_NUM_CSTR; k++) { B.cstr_done_sums[(size_t)k * N + e] = B.cstr_sums[(size_t)k * N + e]; B.cstr_sums[(size_t)k * N + e] = 0.f; }
+                }
             }
         }
     }
@@ -2425,13 +2467,14 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
         hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_PRE | LG_PHASE_POST | LG_PHASE_RESET>), grid, block, 0, st, p); break;
     case LG_PHASE_PRE | LG_PHASE_SIM | LG_PHASE_POST:
         LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_PRE | LG_PHASE_SIM | LG_PHASE_POST>), grid); break;
+    case LG_PHASE_PRE | LG_PHASE_SIM: LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_PRE | LG_PHASE_SIM>), grid); break;
     case LG_PHASE_RESET: hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_RESET>), grid, block, 0, st, p); break;
     case LG_PHASE_PRE | LG_PHASE_POST:
         hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_PRE | LG_PHASE_POST>), grid, block, 0, st, p); break;
     case LG_PHASE_POST | LG_PHASE_RESET:
         hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET>), grid, block, 0, st, p); break;
     case LG_PHASE_POST: hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST>), grid, block, 0, st, p); break;
-    default: return fail("lg_step: unsupported phase combination (ALL, SIM, PRE|POST|RESET, PRE|SIM|POST, PRE|POST, POST|RESET, POST, RESET)");
+    default: return fail("lg_step: unsupported phase combination (ALL, SIM, PRE|SIM, PRE|POST|RESET, PRE|SIM|POST, PRE|POST, POST|RESET, POST, RESET)");
     }
     HIPCHK(hipGetLastError());
     return 0;
@@ -2446,6 +2489,7 @@ static int check_mdp_bufs(const LgEngine *h, uint32_t ph) {
         REQ(episode_sums); REQ(episode_done_sums); REQ(episode_done_step); REQ(command_ranges); REQ(rand_push_vels);
         REQ(friction_values); REQ(added_base_mass); REQ(base_com_bias); REQ(kp_scale); REQ(kd_scale);
 #undef REQ
+        if (h->task.cat_enable && (!b.cstr_prob || !b.cstr_sums || !b.cstr_done_sums)) return fail("lg_step: cat_enable needs buffers cstr_prob, cstr_sums, cstr_done_sums");
         if (h->task.obs_sets > 1 && h->task.obs_slack > 0 && !b.obs_dirty) return fail("lg_step: two observation sets with history stacks need buffer obs_dirty");
     }
     return 0;

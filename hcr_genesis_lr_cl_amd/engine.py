@@ -130,6 +130,10 @@ class Engine:
         self.buf["episode_done_sums"] = torch.zeros((abi.R_COUNT, self.n), device=self.device)
         self.buf["episode_done_step"] = torch.full((self.n,), -1, dtype=torch.int32, device=self.device)
         self.buf["command_ranges"] = torch.zeros(abi.CMD_RANGE_FLOATS, device=self.device)
+        if int(task.cat_enable):
+            self.buf["cstr_prob"] = torch.zeros(self.n, device=self.device)
+            self.buf["cstr_sums"] = torch.zeros((abi.NUM_CSTR, self.n), device=self.device)
+            self.buf["cstr_done_sums"] = torch.zeros((abi.NUM_CSTR, self.n), device=self.device)
         if inject_rand:
             self.buf["rand_in"] = torch.zeros((self.n, task.slots.n_slots), device=self.device)
         b = self.buf

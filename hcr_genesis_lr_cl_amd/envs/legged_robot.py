@@ -77,7 +77,11 @@ class _EpisodeExtras(MutableMapping):
         m = self._ids()
         if not bool(m.any()):
             return torch.zeros((), device=env.device)
-        return torch.mean(env._engine.buf["episode_done_sums"][abi.REWARD_ID[name]][m]) / env.max_episode_length_s
+        if name.startswith("cstr_"):      # constraint violation counters (go2_cat): logged like reward sums (constraint_manager.py:91-97)
+            done = env._engine.buf["cstr_done_sums"][abi.CSTR_NAMES.index(name[5:])]
+        else:
+            done = env._engine.buf["episode_done_sums"][abi.REWARD_ID[name]]
+        return torch.mean(done[m]) / env.max_episode_length_s
 
     def _lazy_keys(self):
         env = self._env
@@ -158,18 +162,24 @@ class LeggedRobot:
         """legged_robot.py:37-53 in one launch (two on the rare command-curriculum steps)."""
         self.common_step_counter += 1
         c = self.common_step_counter
+        self._engine_step(actions, c)
+        self.extras["episode"] = _EpisodeExtras(self, c)
+        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def _engine_step(self, actions, c):
         if self.cfg.commands.curriculum and (c % self.max_episode_length == 0):
             # the curriculum decision needs the episode sums of the envs that reset at this very
             # step, before they are zeroed (legged_robot.py:110-111, 336-348): split the launch
             self._engine.step(abi.PHASE_PRE | abi.PHASE_SIM | abi.PHASE_POST, actions, c)
-            env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()
-            self._update_command_curriculum(env_ids)      # collective across ranks: called even with no local reset
-            self._on_curriculum_gate(env_ids)             # likewise (task curricula reduce over all ranks too)
+            self._command_curriculum_gate()
             self._engine.step(abi.PHASE_RESET, None, c)
         else:
             self._engine.step(abi.PHASE_ALL, actions, c)
-        self.extras["episode"] = _EpisodeExtras(self, c)
-        return self.obs_buf, self.privileged_obs_buf, self.rew_buf, self.reset_buf, self.extras
+
+    def _command_curriculum_gate(self):
+        env_ids = self.reset_buf.nonzero(as_tuple=False).flatten()
+        self._update_command_curriculum(env_ids)      # collective across ranks: called even with no local reset
+        self._on_curriculum_gate(env_ids)             # likewise (task curricula reduce over all ranks too)
 
     def reset(self):
         """base_task.py:60-64: reset every env, then one zero-action step."""

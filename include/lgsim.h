@@ -37,6 +37,10 @@ extern "C" {
 #define LG_NUM_REWARDS 40
 #define LG_CMD_RANGE_FLOATS 24 /* [0..7] command ranges; [8..15] wtw behaviour-parameter ranges; [16] num_gaits */
 #define LG_TASK_STATE_WTW 22   /* gait_time, phi, gait_period, base_h_tgt, clr_tgt, pitch_tgt, theta[4], clock[8], exp_C_frc[4] */
+#define LG_NUM_CSTR 9          /* go2_cat.py:143-205: torque, dof_vel, action_rate, base_height | collision, feet_stumble, dof_pos,
+                                 base_orientation | stand_still (soft | hard | style) */
+#define LG_CR_ANY_FAST 17      /* command_ranges[17]: 1 when SOME env of the whole job moves a joint faster than 4 rad/s (set by the
+                                 host between the physics and the MDP launch; see LgTaskCfg.cat_enable) */
 #define LG_TASK_STATE_BIPED 12 /* gait_time, phi, gait_period(unused), pad, theta[2], clock[4], exp_C_frc[2] */
 
 /* ---- robot model (output of hcr_genesis_lr_cl_amd/model_compiler.py) -------------------
@@ -242,6 +246,15 @@ typedef struct LgTaskCfg {
     float sit_pos[3], sit_quat[4], sit_dof_pos[LG_MAX_DOF];
     int32_t task_state_width;
     LgObsProgram priv_prog, labels_prog; /* obs_layout == LG_OBS_PROGRAM */
+    /* constraints as terminations (go2_cat.py:143-232, utils/constraint_manager.py:3-106).  Every constraint of the task is a
+     * 0/1 violation flag, so the manager's running-max normalisation clamps to 1 and the termination probability of an env is
+     * max_p of its worst violated constraint: 1 for a hard one, cat_soft_p for a soft / style one, else 0.  The reward is
+     * clip(rew * (1 - p), 0).  The style constraint multiplies a (N,) flag with a (N,1) flag (go2_cat.py:179-180): env e violates
+     * it when ITS command is ~0 and ANY env moves a joint faster than 4 rad/s -- reproduced, the job-wide flag comes in through
+     * command_ranges[LG_CR_ANY_FAST]. */
+    int32_t cat_enable;
+    float cat_soft_p, cat_action_rate, cat_min_base_height, cat_max_projected_gravity;
+    float dof_vel_limits[LG_MAX_DOF];   /* cfg.asset.dof_vel_limits (Simulator.dof_vel_limits) */
     LgRandSlots slots;
     uint64_t seed;
     int64_t env_id_offset;           /* global index of local env 0 (multi-GPU sharding) */
@@ -282,6 +295,9 @@ typedef struct LgBuffers {
     float *episode_done_sums;         /* (LG_R_COUNT, N): each env's episode sums as they stood at its latest reset */
     int32_t *episode_done_step;       /* (N): common_step_counter of that reset; together they back the lazy
                                          extras["episode"] means (legged_robot.py:128-132) without atomics */
+    float *cstr_prob;                 /* (N) termination probability of the step (go2_cat.py:205), may be NULL */
+    float *cstr_sums;                 /* (LG_NUM_CSTR, N) steps with a violation this episode (constraint_manager.py:91-97), may be NULL */
+    float *cstr_done_sums;            /* (LG_NUM_CSTR, N) the same as they stood at the env's latest reset, may be NULL */
     float *command_ranges;            /* (LG_CMD_RANGE_FLOATS): vx lo/hi, vy lo/hi, yaw lo/hi, heading lo/hi */
     float *task_state;                /* task specific per-env block (gait phase ...), may be NULL */
     const float *rand_in;             /* (N, slots.n_slots) injected uniforms, NULL => Philox */

@@ -129,6 +129,7 @@ class MdpOracle:
         self.priv_obs_buf = z(N, max(task.num_priv_obs, 1))
         self.labels_buf = z(N, max(task.num_labels, 1))
         self.state_links = model.find_link_indices(cfg.asset.contact_state_link_names) if cfg.asset.obtain_link_contact_states else []
+        self.cstr_prob, self.cstr_sums = z(N), z(abi.NUM_CSTR, N)
         self.terrain_levels = np.zeros(N, np.int64)
         self.terrain_types = np.zeros(N, np.int64)
         self.terrain_origins = None
@@ -268,6 +269,31 @@ class MdpOracle:
         self.fail_buf += fail
         self.time_out_buf = self.episode_length_buf > T.max_episode_length
         self.reset_buf = (self.fail_buf > T.fail_threshold) | self.time_out_buf
+        # ---- constraints as terminations: go2_cat.py:143-205 + utils/constraint_manager.py:25-97.  Every constraint is a 0/1 flag, so
+        #      the manager's ratio to the running max clamps to 1: p = max_p of the worst violated constraint
+        cat_keep = f32(1.0)
+        if T.cat_enable:
+            tq_lim = self.model.arrays["effort"].astype(f32)
+            vlim = np.ctypeslib.as_array(T.dof_vel_limits)[:A]
+            lo_, hi_ = np.ctypeslib.as_array(T.soft_dof_lo)[:A], np.ctypeslib.as_array(T.soft_dof_hi)[:A]
+            mh = sim["measured_heights"] if "measured_heights" in sim else np.zeros((N, 1), f32)
+            still = (np.linalg.norm(self.commands[:, :3], axis=1) < 0.1)
+            flags = [
+                np.any(np.abs(sim["torques"]) > tq_lim, axis=1),
+                np.any(np.abs(sim["dof_vel"]) > vlim, axis=1),
+                np.any(np.abs(self.actions - self.last_actions) / self.dt > f32(T.cat_action_rate), axis=1),
+                np.mean(sim["base_pos"][:, 2:3] - mh, axis=1) < f32(T.cat_min_base_height),
+                np.any(np.linalg.norm(F_l[:, self.pen], axis=-1) > 10.0, axis=1),
+                np.any(np.linalg.norm(F_l[:, self.feet], axis=-1) > 4 * np.abs(F_l[:, self.feet, 2]), axis=1),
+                np.any(sim["dof_pos"] < lo_, axis=1) & np.any(sim["dof_pos"] > hi_, axis=1),
+                pg[:, 2] > f32(T.cat_max_projected_gravity),
+                # (N,) * (N,1) in the reference (go2_cat.py:179-180): row j of the (N,N) product is still_j * any-env-fast
+                still & bool(np.any(np.abs(sim["dof_vel"]) > 4.0)),
+            ]
+            max_p = [T.cat_soft_p] * 4 + [1.0] * 4 + [T.cat_soft_p]
+            self.cstr_prob = np.max(np.stack([f.astype(f32) * f32(p_) for f, p_ in zip(flags, max_p)]), axis=0).astype(f32)
+            self.cstr_sums += np.stack(flags).astype(f32)
+            cat_keep = (f32(1.0) - self.cstr_prob).astype(f32)
         # ---- compute_reward: :150-168 (alphabetical)
         total = np.zeros(N, f32)
         cmd = self.commands
@@ -394,7 +420,7 @@ class MdpOracle:
             eul = get_euler_xyz(q)
             add("tracking_orientation", np.exp(-(eul[:, 0] ** 2 + (eul[:, 1] - self.pitch_target[:, 0]) ** 2) / f32(T.euler_sigma)))
         if T.only_positive_rewards:
-            total = np.clip(total, 0, None)
+            total = np.clip(total * cat_keep, 0, None)                        # go2_cat.py:219-223
         if on("termination"):
             k = R_["termination"]
             rew = (1.0 * (self.reset_buf & ~self.time_out_buf) * sc[k]).astype(f32)
@@ -478,6 +504,8 @@ class MdpOracle:
             if T.obs_stack > 1:                                            # go2_wtw.py:174-178, legged_robot_ee.py:115-121
                 self.obs_hist[ids] = 0; self.priv_hist[ids] = 0
             self.done_sums = (self.episode_sums[:, ids].sum(1), len(ids))
+            if T.cat_enable:
+                self.cstr_sums[:, ids] = 0
             self.episode_sums[:, ids] = np.where((sc[:abi.R_COUNT] != 0)[:, None], 0, self.episode_sums[:, ids])
         # ---- compute_observations: go2.py:40-64, clip legged_robot.py:48-49
         if T.obs_layout == abi.OBS_GO2:

@@ -260,6 +260,8 @@ class EEKernelStepper:
         put(eng, "measured_heights", fx["measured_heights"][t]); put(eng, "height_around_feet", fx["height_around_feet"][t])
         put(eng, "normal_vector_around_feet", fx["normals"][t])
         put(eng, "rand_in", R)
+        if "cstr_prob" in eng.buf:       # go2_cat: the job-wide "some env moves a joint faster than 4 rad/s" flag (envs/go2_ts.py Go2CaT._any_fast)
+            eng.buf["command_ranges"][abi.CR_ANY_FAST] = float(np.any(np.abs(sim["dof_vel"]) > 4.0))
         eng.step(abi.PHASE_PRE | abi.PHASE_POST | abi.PHASE_RESET, torch.from_numpy(actions).cuda(), counter)
         torch.cuda.synchronize()
         es = get(eng, "episode_sums")
@@ -273,7 +275,8 @@ class EEKernelStepper:
                     sim_base_pos=get(eng, "base_pos"), terrain_levels=get(eng, "terrain_levels"), env_origins=get(eng, "env_origins"),
                     measured_heights=fx["measured_heights"][t], height_around_feet=fx["height_around_feet"][t], normals=fx["normals"][t],
                     contact_states=get(eng, "priv_obs_buf")[:, -W:][:, cols], feat_full=get(eng, "obs_buf"), priv_full=get(eng, "priv_obs_buf"),
-                    obs=get(eng, "obs_buf")[:, -45:])
+                    obs=get(eng, "obs_buf")[:, -45:], cstr_prob=get(eng, "cstr_prob") if "cstr_prob" in eng.buf else None,
+                    cstr_sums=get(eng, "cstr_sums") if "cstr_sums" in eng.buf else None)
 
 
 def test_kernel_reproduces_reference_go2_ee_golden_vectors():
@@ -281,7 +284,7 @@ def test_kernel_reproduces_reference_go2_ee_golden_vectors():
     replay_ee(EEKernelStepper, lambda t, fx, out: check_ee(t, fx, out, rtol=1e-5, atol=5e-5))
 
 
-@pytest.mark.parametrize("head", ["go2_ts", "go2_cts", "go2_dreamwaq"])
+@pytest.mark.parametrize("head", ["go2_ts", "go2_cts", "go2_dreamwaq", "go2_cat"])
 def test_kernel_reproduces_reference_head_golden_vectors(head):
     """the other Go2-rough heads.  Golden vectors from the reference's own Go2TS / Go2CTS / Go2Dreamwaq classes as
     configured (tests/golden/gen_mdp_fixtures.py gen_head): actor frame, newest frames of the 20-deep actor history and the
@@ -291,7 +294,7 @@ def test_kernel_reproduces_reference_head_golden_vectors(head):
     replay_ee(stepper, lambda t, fx, out: check_head(t, fx, out, rtol=1e-5, atol=5e-5), head_gold(head))
 
 
-@pytest.mark.parametrize("head", ["go2_ts", "go2_cts", "go2_dreamwaq"])
+@pytest.mark.parametrize("head", ["go2_ts", "go2_cts", "go2_dreamwaq", "go2_cat"])
 def test_head_env_returns_the_reference_tuple(head):
     """Arity and shapes of step() / reset() / get_observations() (legged_robot_ts.py:59-83, legged_robot_dreamwaq.py:63-89)."""
     import torch
@@ -309,6 +312,16 @@ def test_head_env_returns_the_reference_tuple(head):
         assert priv.shape == (64, 99) and critic.shape == (64, 5 * 177)
         if head == "go2_cts":
             assert "teacher_terrain_level" in extras["episode"] and "student_terrain_level" in extras["episode"]
+        if head == "go2_cat":
+            g = torch.Generator(device="cuda"); g.manual_seed(0)
+            for _ in range(30):
+                out = env.step(torch.randn(64, 12, generator=g, device="cuda") * 3.0)
+            ep = out[-1]["episode"]
+            p = env.cstr_prob
+            assert 0.0 <= float(ep["cstr_probs"]) <= 1.0 and "rew_cstr_action_rate" in list(ep)
+            assert set(p.unique().tolist()) <= {0.0, 0.25, 1.0} and float(p.max()) > 0
+            assert float(env.episode_sums["cstr_action_rate"].max()) > 0 and (out[4] >= 0).all()
+            obs, priv, hist, critic, rew, done, extras = out
     assert obs.shape == (64, 45) and hist.shape == (64, 900) and rew.shape == (64,) and done.dtype == torch.bool
     assert torch.equal(obs, hist[:, -45:]) and all(torch.isfinite(o).all() for o in out[:-3])
     assert [o.shape for o in env.get_observations()] == [o.shape for o in out[:len(r)]]

@@ -200,7 +200,7 @@ class EEOracleStepper:
                     sim_dof_pos=sim["dof_pos"], sim_base_pos=sim["base_pos"], terrain_levels=o.terrain_levels,
                     env_origins=o.env_origins, measured_heights=mh, height_around_feet=har, normals=nrm,
                     contact_states=o.priv_obs_buf[:, -W:][:, cols], feat_full=o.obs_buf, priv_full=o.priv_obs_buf,
-                    obs=np.clip(o.obs_buf[:, -45:], -100.0, 100.0))
+                    obs=np.clip(o.obs_buf[:, -45:], -100.0, 100.0), cstr_prob=o.cstr_prob, cstr_sums=o.cstr_sums)
 
 
 EE_EXACT = ("reset", "time_out", "ep_len", "fail_buf", "terrain_levels")
@@ -246,9 +246,24 @@ def test_mdp_oracle_reproduces_reference_go2_ee():
 def check_head(t, fx, out, rtol=2e-6, atol=2e-6):
     check_ee(t, fx, out, rtol, atol)
     np.testing.assert_allclose(out["obs"], fx["obs"][t], rtol=rtol, atol=atol, err_msg=f"clipped actor frame @ step {t}")
+    if fx["cstr_sums"].shape[1]:          # go2_cat: termination probability and per-episode violation counters, exact
+        np.testing.assert_array_equal(out["cstr_prob"], fx["cstr_prob"][t], err_msg=f"cstr_prob @ step {t}")
+        np.testing.assert_array_equal(out["cstr_sums"], fx["cstr_sums"][t], err_msg=f"cstr_sums @ step {t}")
 
 
-@pytest.mark.parametrize("head", ["go2_ts", "go2_cts", "go2_dreamwaq"])
+ALL_HEADS = ["go2_ts", "go2_cts", "go2_dreamwaq", "go2_cat"]
+
+
+def test_cat_fixture_exercises_the_constraints():
+    fx = np.load(head_gold("go2_cat"))
+    p = fx["cstr_prob"]
+    assert (p == 0).any() and (p == 0.25).any() and (p == 1.0).any() and set(np.unique(p)) <= {0.0, 0.25, 1.0}
+    seen = fx["cstr_sums"].max(axis=(0, 2)) > 0
+    assert seen[[2, 3, 4, 5]].all()                 # action rate, base height, collision, feet stumble all occur
+    assert (fx["reset"].sum(1) > 0).any() and (fx["cstr_sums"][-1] < fx["cstr_sums"].max(0)).any()    # counters zeroed at resets
+
+
+@pytest.mark.parametrize("head", ALL_HEADS)
 def test_head_fixture_is_what_the_reference_emits_as_configured(head):
     """17 contact-state links as configured (common_cfgs.py:100-101) although the head's size fields assume 12
     (go2_ts_config.py:8-14): privileged 99 wide / critic frames 177 wide."""
@@ -259,7 +274,7 @@ def test_head_fixture_is_what_the_reference_emits_as_configured(head):
     np.testing.assert_array_equal(fx["obs"], np.clip(fx["feat_new"], -100, 100))      # obs = newest history frame, clipped
 
 
-@pytest.mark.parametrize("head", ["go2_ts", "go2_cts", "go2_dreamwaq"])
+@pytest.mark.parametrize("head", ALL_HEADS)
 def test_mdp_oracle_reproduces_reference_head(head):
     stepper = type("Stepper_" + head, (EEOracleStepper,), {"head": head})
     replay_ee(stepper, check_head, head_gold(head))
