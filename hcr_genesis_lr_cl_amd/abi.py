@@ -30,7 +30,7 @@ REWARD_NAMES = [
     "collision", "dof_acc", "dof_close_to_default", "dof_pos_limits", "dof_pos_stand_still",
     "dof_power", "dof_vel", "dof_vel_stand_still", "feet_air_time", "feet_contact_stand_still",
     "feet_distance", "foot_acc", "foot_clearance", "foot_landing_vel", "hip_pos", "keep_balance",
-    "lin_vel_z", "orientation", "quad_periodic_gait", "torques", "tracking_ang_vel",
+    "lin_vel_z", "no_fly", "orientation", "quad_periodic_gait", "torques", "tracking_ang_vel",
     "tracking_base_height", "tracking_foot_clearance", "tracking_lin_vel", "tracking_orientation",
     "termination",
 ]
@@ -82,7 +82,7 @@ NUM_CSTR = 9
 CR_ANY_FAST = 17
 CSTR_NAMES = ["torque", "dof_vel", "action_rate", "base_height", "collision", "feet_stumble", "dof_pos", "base_orientation", "stand_still"]
 (SEG_END, SEG_FRAME, SEG_DR, SEG_DR_JOINT, SEG_BASE_LIN_VEL, SEG_CONTACT_STATES, SEG_HEIGHTS, SEG_FEET_REL_HEIGHTS,
- SEG_FEET_HEIGHTS, SEG_FEET_NORMALS, SEG_FOOT_CLEARANCE, SEG_NEXT_STATE) = range(12)
+ SEG_FEET_HEIGHTS, SEG_FEET_NORMALS, SEG_FOOT_CLEARANCE, SEG_NEXT_STATE, SEG_LAST_ACTIONS, SEG_DR_BASE, SEG_FEET_AIR_TIME) = range(15)
 
 
 class LgObsProgram(C.Structure):

@@ -53,14 +53,14 @@ def make_sim_options(model, cfg, terrain=None):
     return o
 
 
-def go2_noise_vec(cfg):
-    """go2.py:92-117 for the 45-wide frame."""
+def go2_noise_vec(cfg, A=12):
+    """go2.py:92-117 for the 9 + 3 A wide frame (45 for Go2; tron1_pf.py:105-128 for A = 6)."""
     ns, lvl, sc = cfg.noise.noise_scales, cfg.noise.noise_level, cfg.normalization.obs_scales
-    v = np.zeros(45, np.float32)
+    v = np.zeros(9 + 3 * A, np.float32)
     v[3:6] = ns.gravity * lvl
     v[6:9] = ns.ang_vel * lvl * sc.ang_vel
-    v[9:21] = ns.dof_pos * lvl * sc.dof_pos
-    v[21:33] = ns.dof_vel * lvl * sc.dof_vel
+    v[9:9 + A] = ns.dof_pos * lvl * sc.dof_pos
+    v[9 + A:9 + 2 * A] = ns.dof_vel * lvl * sc.dof_vel
     return v
 
 
@@ -126,12 +126,15 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
         K = len(model.find_link_indices(cfg.asset.contact_state_link_names)) if cfg.asset.obtain_link_contact_states else 0
         P = len(cfg.terrain.measured_points_x) * len(cfg.terrain.measured_points_y) if cfg.terrain.measure_heights else 0
         F = model.n_legs
-        width = {"frame": 45, "dr": 7 + 2 * A, "dr_joint": 3, "base_lin_vel": 3, "contact_states": K, "heights": P,
-                 "feet_rel_heights": 9 * F, "feet_heights": 9 * F, "feet_normals": 3 * F, "foot_clearance": F, "next_state": 45}
+        FW = 9 + 3 * A
+        width = {"frame": FW, "dr": 7 + 2 * A, "dr_joint": 3, "base_lin_vel": 3, "contact_states": K, "heights": P,
+                 "feet_rel_heights": 9 * F, "feet_heights": 9 * F, "feet_normals": 3 * F, "foot_clearance": F, "next_state": FW,
+                 "last_actions": A, "dr_base": 7, "feet_air_time": F}
         kind = {"frame": abi.SEG_FRAME, "dr": abi.SEG_DR, "dr_joint": abi.SEG_DR_JOINT, "base_lin_vel": abi.SEG_BASE_LIN_VEL,
                 "contact_states": abi.SEG_CONTACT_STATES, "heights": abi.SEG_HEIGHTS, "feet_rel_heights": abi.SEG_FEET_REL_HEIGHTS,
                 "feet_heights": abi.SEG_FEET_HEIGHTS, "feet_normals": abi.SEG_FEET_NORMALS, "foot_clearance": abi.SEG_FOOT_CLEARANCE,
-                "next_state": abi.SEG_NEXT_STATE}
+                "next_state": abi.SEG_NEXT_STATE, "last_actions": abi.SEG_LAST_ACTIONS, "dr_base": abi.SEG_DR_BASE,
+                "feet_air_time": abi.SEG_FEET_AIR_TIME}
 
         def fill(prog, blocks, clip):
             assert len(blocks) <= abi.MAX_SEGS
@@ -141,13 +144,14 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
                 off += width[name]
             prog.n_segs, prog.clip = len(blocks), int(clip)
             return off
-        t.obs_frame, t.obs_stack, t.num_obs = 45, e.frame_stack, 45 * e.frame_stack
+        t.obs_frame, t.obs_stack, t.num_obs = FW, e.frame_stack, FW * e.frame_stack
         t.priv_frame = fill(t.priv_prog, cfg.reset.critic_program, cfg.reset.critic_clip)
         t.priv_stack, t.num_priv_obs = e.c_frame_stack, e.c_frame_stack * t.priv_frame
         t.num_labels = fill(t.labels_prog, cfg.reset.aux_program, cfg.reset.aux_clip)
-        assert t.priv_frame == e.single_critic_obs_len, (t.priv_frame, e.single_critic_obs_len)
-        abi.fill_array(t.noise_vec, go2_noise_vec(cfg))            # go2_ts.py:110-131
-        t.slots = go2_slots(A, 45)
+        want = getattr(e, "single_critic_obs_len", None) or e.num_single_privileged_obs
+        assert t.priv_frame == want, (t.priv_frame, want)
+        abi.fill_array(t.noise_vec, go2_noise_vec(cfg, A))         # go2_ts.py:110-131, tron1_pf.py:105-128
+        t.slots = go2_slots(A, FW)
         t.heights_offset, t.heights_clip_scale = 0.5, 1             # go2_ts.py:50-52
     elif layout == "tron1_ee":
         e = cfg.env

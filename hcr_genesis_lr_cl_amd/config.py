@@ -294,6 +294,44 @@ class GO2EECfg(LeggedRobotCfg):
                     obs_layout="go2_ee", feet_air_time_threshold=0.25, foot_clearance_ref="mean")
 
 
+# tron1_pf/tron1_pf_config.py:4-122 (TRON1PFCfg, experiment "tron1_pf"): the point-foot biped on the plane, 5-frame actor / critic
+# stacks (tron1_pf.py:15-66): actor frame 9 + 3 A = 27; critic frame [v_b 3 | frame 27 | last actions 6 | friction, mass, CoM, push 7 |
+# feet air time 2] = 45
+class TRON1PFCfg(LeggedRobotCfg):
+    env = section(LeggedRobotCfg.env, num_envs=4096, num_single_obs=27, frame_stack=5, c_frame_stack=5, num_observations=27 * 5,
+                  num_single_privileged_obs=27 + 18, num_privileged_obs=(27 + 18) * 5, num_actions=6, env_spacing=2.0)
+    terrain = section(LeggedRobotCfg.terrain, mesh_type="plane")
+    init_state = section(
+        LeggedRobotCfg.init_state, pos=[0.0, 0.0, 0.8],
+        default_joint_angles={f"{j}_{s}_Joint": 0.0 for s in ("L", "R") for j in ("abad", "hip", "knee", "foot")})
+    control = section(LeggedRobotCfg.control, stiffness={"Joint": 42.0}, damping={"Joint": 2.5}, action_scale=0.25, decimation=4)
+    asset = section(
+        LeggedRobotCfg.asset, name="tron1_pf", file="{LEGGED_GYM_ROOT_DIR}/resources/robots/PF_TRON1A/urdf/robot.urdf",
+        foot_name="foot", penalize_contacts_on=["knee", "hip"], terminate_after_contacts_on=["base", "abad"],
+        base_link_name="base_Link", dof_names=[f"{j}_{s}_Joint" for s in ("L", "R") for j in ("abad", "hip", "knee")],
+        links_to_keep=["foot_L_Link", "foot_R_Link"], dof_vel_limits=[])
+    rewards = section(
+        LeggedRobotCfg.rewards, soft_dof_pos_limit=0.9, base_height_target=0.68, foot_clearance_target=0.07, foot_height_offset=0.032,
+        foot_clearance_tracking_sigma=0.01, foot_distance_threshold=0.115, about_landing_threshold=0.1, only_positive_rewards=False,
+        scales=section(
+            LeggedRobotCfg.rewards.scales, keep_balance=1.0, dof_pos_limits=-2.0, collision=-1.0, feet_distance=-100.0,
+            tracking_lin_vel=1.0, tracking_ang_vel=0.5, lin_vel_z=-0.5, base_height=-2.0, ang_vel_xy=-0.05, orientation=-3.0,
+            dof_vel=-5.0e-4, dof_acc=-2.0e-7, action_rate=-0.01, action_smoothness=-0.01, torques=-2.0e-5, feet_air_time=1.0,
+            foot_clearance=0.5, no_fly=0.5, foot_landing_vel=-0.15))
+    commands = section(
+        LeggedRobotCfg.commands, curriculum=True, max_curriculum=1.0, num_commands=4, resampling_time=10.0, heading_command=True,
+        ranges=section(LeggedRobotCfg.commands.ranges, lin_vel_x=[-0.5, 0.5], lin_vel_y=[-0.6, 0.6], ang_vel_yaw=[-1, 1],
+                       heading=[-3.14, 3.14]))
+    domain_rand = section(
+        LeggedRobotCfg.domain_rand, randomize_friction=True, friction_range=[0.5, 1.25], randomize_base_mass=True,
+        added_mass_range=[-1.0, 1.0], push_robots=True, push_interval_s=10, max_push_vel_xy=1.0, randomize_com_displacement=True,
+        com_pos_x_range=[-0.03, 0.03], com_pos_y_range=[-0.03, 0.03], com_pos_z_range=[-0.03, 0.03])
+    # TRON1PF derives from LeggedRobot: base-class reset distribution (legged_robot.py:274-298); air time 0.25 (tron1_pf.py:131-141)
+    reset = section(dof_ranges={"Joint": 0.2}, root_vel_range=0.5, robot="tron1_pf", obs_layout="program", feet_air_time_threshold=0.25,
+                    critic_program=[("base_lin_vel", 1.0), ("frame", 1.0), ("last_actions", 1.0), ("dr_base", 1.0), ("feet_air_time", 1.0)],
+                    critic_clip=True, aux_program=[], aux_clip=False)
+
+
 # ---- the other Go2-rough task heads (legged_gym/envs/__init__.py:82-86): same robot, terrain, rewards, resets and domain
 # randomisation as go2_ee (verified by diffing the reference's instantiated config trees); they differ in how the step's
 # outputs are packaged.  Frames are described as observation programs (include/lgsim.h LgObsSeg): (block, extra scale).

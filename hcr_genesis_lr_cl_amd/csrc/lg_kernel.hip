@@ -1594,6 +1594,10 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         if (RON(LG_R_HIP_POS)) add(LG_R_HIP_POS, quad_sum<LEGS>(dq0[0] * dq0[0]));   // go2_ee.py:152-159
         if (RON(LG_R_KEEP_BALANCE)) add(LG_R_KEEP_BALANCE, 1.f);                      // :601-603
         if (RON(LG_R_LIN_VEL_Z)) add(LG_R_LIN_VEL_Z, blv.z * blv.z);                  // :458-460
+        if (RON(LG_R_NO_FLY)) {                                   // tron1_pf.py:151-154: exactly one foot on the ground
+            const float cnt = quad_sum<LEGS>(f_link[3].z > 0.1f ? 1.f : 0.f);
+            add(LG_R_NO_FLY, cnt == 1.f ? 1.f : 0.f);
+        }
         if (RON(LG_R_ORIENTATION)) add(LG_R_ORIENTATION, pg.x * pg.x + pg.y * pg.y);  // :466-468
         if (RON(LG_R_QUAD_PERIODIC_GAIT)) add(LG_R_QUAD_PERIODIC_GAIT, gait_reward());   // go2_wtw.py:472-484
         if (RON(LG_R_TORQUES)) {                                  // :478-480
@@ -2168,6 +2172,19 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
 #pragma unroll
                             for (int k = 0; k < 3; k++) Wr(off + 3 * foot_slot + k, ld_nv3[k]);
                         }
+                    } else if (kind == LG_SEG_LAST_ACTIONS) {     // a_{t-1}: zero for an env that was just reset
+                        if (live) {
+#pragma unroll
+                            for (int j = 0; j < 3; j++) Wr(off + d0 + j, last_act[j]);
+                        }
+                    } else if (kind == LG_SEG_DR_BASE) {
+                        if (lead) {
+                            Wr(off + 0, ld_fric - HOT(friction_offset)); Wr(off + 1, ld_mass);
+                            Wr(off + 2, ld_com[0]); Wr(off + 3, ld_com[1]); Wr(off + 4, ld_com[2]);
+                            Wr(off + 5, ld_push[0]); Wr(off + 6, ld_push[1]);
+                        }
+                    } else if (kind == LG_SEG_FEET_AIR_TIME) {
+                        if (live) Wr(off + foot_slot, air);
                     } else if (kind == LG_SEG_FOOT_CLEARANCE) {
                         if (live) Wr(off + foot_slot, clampf(foot_p.z - foot_hmean - hc_foot_height_offset, -1.f, 1.f));
                     }   // LG_SEG_FRAME / LG_SEG_NEXT_STATE: written entry by entry in put()

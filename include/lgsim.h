@@ -111,7 +111,7 @@ enum LgReward {
     LG_R_DOF_POS_LIMITS, LG_R_DOF_POS_STAND_STILL, LG_R_DOF_POWER, LG_R_DOF_VEL,
     LG_R_DOF_VEL_STAND_STILL, LG_R_FEET_AIR_TIME, LG_R_FEET_CONTACT_STAND_STILL,
     LG_R_FEET_DISTANCE, LG_R_FOOT_ACC, LG_R_FOOT_CLEARANCE, LG_R_FOOT_LANDING_VEL,
-    LG_R_HIP_POS, LG_R_KEEP_BALANCE, LG_R_LIN_VEL_Z, LG_R_ORIENTATION,
+    LG_R_HIP_POS, LG_R_KEEP_BALANCE, LG_R_LIN_VEL_Z, LG_R_NO_FLY, LG_R_ORIENTATION,
     LG_R_QUAD_PERIODIC_GAIT, LG_R_TORQUES, LG_R_TRACKING_ANG_VEL, LG_R_TRACKING_BASE_HEIGHT,
     LG_R_TRACKING_FOOT_CLEARANCE, LG_R_TRACKING_LIN_VEL, LG_R_TRACKING_ORIENTATION,
     LG_R_TERMINATION, /* added after the positive clip (legged_robot.py:163-168) */
@@ -124,7 +124,7 @@ enum LgObsLayout {
     LG_OBS_GO2_WTW = 1,  /* go2_wtw.py:53-111   61x5 / 99x5 */
     LG_OBS_GO2_EE = 2,   /* go2_ee.py:10-75     45x20 / 174x5 / 24 labels */
     LG_OBS_TRON1_EE = 3, /* tron1_pf_ee.py:53-141 31x10 / 134x10 / 17 labels */
-    LG_OBS_PROGRAM = 4   /* go2 actor frame 45 x stack; critic frame and labels assembled by LgTaskCfg.priv_prog / labels_prog */
+    LG_OBS_PROGRAM = 4   /* actor frame = go2's 9 + 3 A (45; 27 for tron1_pf) x stack; critic frame and labels assembled by LgTaskCfg.priv_prog / labels_prog */
 };
 
 /* Observation programs (obs_layout == LG_OBS_PROGRAM): the critic frame and the auxiliary per-step output ("labels") of the
@@ -142,7 +142,10 @@ enum LgObsSeg {
     LG_SEG_FEET_HEIGHTS,  /* height_around_feet, 9 F (go2_cts.py:73) */
     LG_SEG_FEET_NORMALS,  /* normal_vector_around_feet, 3 F */
     LG_SEG_FOOT_CLEARANCE,/* clip(foot_z - mean(height_around_feet) - foot_height_offset, +-1), F (go2_dreamwaq.py:79-81) */
-    LG_SEG_NEXT_STATE     /* the actor frame without noise, actions * action_scale (go2_dreamwaq.py:66-74) */
+    LG_SEG_NEXT_STATE,    /* the actor frame without noise, actions * action_scale (go2_dreamwaq.py:66-74) */
+    LG_SEG_LAST_ACTIONS,  /* last_actions, A (tron1_pf.py:36) */
+    LG_SEG_DR_BASE,       /* friction - offset, added mass, CoM 3, push xy 2 (tron1_pf.py:37-41) */
+    LG_SEG_FEET_AIR_TIME  /* feet_air_time, F (tron1_pf.py:42) */
 };
 #define LG_MAX_SEGS 8
 typedef struct LgObsProgram {

@@ -377,6 +377,8 @@ class MdpOracle:
             add("keep_balance", np.ones(N, f32))
         if on("lin_vel_z"):
             add("lin_vel_z", blv[:, 2] ** 2)
+        if on("no_fly"):                                                   # tron1_pf.py:151-154
+            add("no_fly", 1.0 * (np.sum(1.0 * (feet_f[:, :, 2] > 0.1), axis=1) == 1))
         if on("orientation"):
             add("orientation", np.sum(pg[:, :2] ** 2, axis=1))
         if on("quad_periodic_gait"):                                       # go2_wtw.py:377-484 ("step" indicator)
@@ -592,9 +594,14 @@ class MdpOracle:
             head = [self.commands[:, :3] * cs, pg, bav * f32(T.obs_scale_ang_vel), (sim["dof_pos"] - self.q0) * f32(T.obs_scale_dof_pos),
                     sim["dof_vel"] * f32(T.obs_scale_dof_vel)]
             frame = np.concatenate(head + [self.actions], axis=1).astype(f32)
-            har = sim["height_around_feet"].reshape(N, F, 9)
+            har = sim["height_around_feet"].reshape(N, F, 9) if "height_around_feet" in sim else np.zeros((N, F, 9), f32)
             fpz = sim["feet_pos"].reshape(N, F, 3)[:, :, 2]
+            dr_base = lambda sc_: np.concatenate([self.friction_values - f32(T.friction_offset), self.added_base_mass, self.base_com_bias,
+                                                  self.rand_push_vels[:, :2]], axis=1)
             blocks = {
+                abi.SEG_LAST_ACTIONS: lambda sc_: self.last_actions,           # tron1_pf.py:36
+                abi.SEG_DR_BASE: dr_base,                                      # tron1_pf.py:37-41
+                abi.SEG_FEET_AIR_TIME: lambda sc_: self.feet_air_time,         # tron1_pf.py:42
                 abi.SEG_FRAME: lambda sc_: frame,
                 abi.SEG_DR: lambda sc_: np.concatenate([self.friction_values - f32(T.friction_offset), self.added_base_mass, self.base_com_bias,
                                                         self.rand_push_vels[:, :2], self.kp_scale - f32(T.kp_offset),
@@ -612,6 +619,8 @@ class MdpOracle:
 
             def run(prog):
                 parts = [blocks[prog.kind[i]](prog.scale[i]).astype(f32) for i in range(prog.n_segs)]
+                if not parts:
+                    return np.zeros((N, 1), f32)
                 off = 0
                 for i, p_ in enumerate(parts):
                     assert prog.offset[i] == off, (i, prog.offset[i], off)

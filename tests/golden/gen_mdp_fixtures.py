@@ -665,6 +665,76 @@ def gen_tron1(N=24, T=48, seed=31):
         torch.rand_like, torch.rand, np.random.random = orig
 
 
+def gen_tron1_pf(N=16, T=40, seed=51):
+    """TRON1PF (tron1_pf.py, experiment "tron1_pf"): the point-foot biped on the plane; base-class resets, 5-frame actor /
+    critic stacks, `no_fly` reward.  Stored like gen_wtw: full stacked obs / privileged obs per step."""
+    import legged_gym.envs.base.base_task as base_task
+    import legged_gym.envs.base.legged_robot as lr_mod
+    import legged_gym.envs.tron1_pf.tron1_pf as pf_mod
+    from legged_gym.envs.tron1_pf.tron1_pf_config import TRON1PFCfg
+    from legged_gym.utils.helpers import class_to_dict
+    from hcr_genesis_lr_cl_amd.config import TRON1PFCfg as MyCfg
+
+    rec = rh.DrawRecorder(seed)
+    base_task.GenesisSimulator = FakeSimulator
+    lr_mod.torch_rand_float = rec.rand_float
+    orig_rand_like = torch.rand_like
+    torch.rand_like = rec.rand_like
+    try:
+        cfg = TRON1PFCfg()
+        cfg.env.num_envs = N
+        env = pf_mod.TRON1PF(cfg, class_to_dict(cfg.sim), "cpu", True)
+        sim = env.simulator
+        sim.rec = rec
+        rng = np.random.default_rng(seed + 1)
+        model = sim.model
+        script = make_script(rng, model, cfg, N, T)
+        script["base_pos"][:, :, 2] += 0.36                       # nominal base height 0.68
+        script["feet_pos"][:, :, :, :2] = script["feet_pos"][:, :, :, :2] * 0.4 + script["base_pos"][:, :, None, :2]
+        sim.script = script
+        task = builders.make_task_cfg(model, MyCfg())
+        slots = task.slots
+        groups = [list(range(6))]                                  # legged_robot.py:279-280: one (n, 6) draw
+        env.episode_length_buf[:] = torch.from_numpy(rng.choice([3, 120, 470, 495, 498, 499, 968, 977, 985, 992, 995, 998, 999, 1000], N).astype(np.int32))
+        env.commands[:] = torch.from_numpy((rng.normal(size=(N, 4)) * [0.4, 0.4, 0.5, 1.5]).astype(np.float32))
+        env.common_step_counter = 495                              # push interval 10 s = 500 steps
+        env.reset_buf[:] = 0
+        rec.take()
+        init = dict(episode_length_buf=env.episode_length_buf.numpy().copy(), commands=env.commands.numpy().copy(),
+                    env_origins=sim._env_origins.numpy().copy())
+        keys = ("actions_in", "rand", "counter", "obs", "priv", "rew", "reset", "time_out", "commands", "ep_len", "fail_buf", "feet_air_time",
+                "episode_sums", "act_hist", "sim_dof_pos", "sim_base_pos", "sim_base_lin_vel_w", "dr", "last_dof_vel_in", "last_feet_vel_in",
+                "esum_override")
+        out = {k: [] for k in keys}
+        names = env.reward_names
+        for t in range(T):
+            act = torch.from_numpy((rng.normal(size=(N, 6)) * (1.0 if t % 7 else 60.0)).astype(np.float32))
+            out["last_dof_vel_in"].append(sim._dof_vel.numpy().copy()); out["last_feet_vel_in"].append(sim._feet_vel.numpy().copy())
+            obs, priv, rew, reset, extras = env.step(act)
+            calls = rec.take()
+            out["actions_in"].append(act.numpy().copy()); out["rand"].append(slots_from_calls(calls, slots, N, 6, groups))
+            out["counter"].append(env.common_step_counter); out["esum_override"].append(0.0)
+            out["obs"].append(obs.numpy().copy()); out["priv"].append(priv.numpy().copy()); out["rew"].append(rew.numpy().copy())
+            out["reset"].append(reset.numpy().astype(np.uint8)); out["time_out"].append(env.time_out_buf.numpy().astype(np.uint8))
+            out["commands"].append(env.commands.numpy().copy()); out["ep_len"].append(env.episode_length_buf.numpy().copy())
+            out["fail_buf"].append(env.fail_buf.numpy().copy()); out["feet_air_time"].append(env.feet_air_time.numpy().copy())
+            out["episode_sums"].append(np.stack([env.episode_sums[n].numpy().copy() for n in names]))
+            out["act_hist"].append(np.stack([env.actions.numpy(), env.last_actions.numpy(), env.llast_actions.numpy()]).copy())
+            out["sim_dof_pos"].append(sim._dof_pos.numpy().copy()); out["sim_base_pos"].append(sim._base_pos.numpy().copy())
+            out["sim_base_lin_vel_w"].append(sim._base_lin_vel_w.numpy().copy())
+            out["dr"].append(np.concatenate([sim._friction_values.numpy(), sim._added_base_mass.numpy(), sim._base_com_bias.numpy(),
+                                             sim._rand_push_vels.numpy()[:, :2]], 1).copy())
+        arrays = {k: np.stack(v) for k, v in out.items()}
+        arrays.update({"script_" + k: v for k, v in sim.script.items()})
+        arrays.update({"init_" + k: v for k, v in init.items()})
+        arrays["reward_names"] = np.array(names)
+        path = os.path.join(HERE, "tron1_pf_mdp.npz")
+        np.savez_compressed(path, **arrays)
+        print("wrote", path, os.path.getsize(path), arrays["obs"].shape, arrays["priv"].shape, "resets/step", arrays["reset"].sum(1), list(names))
+    finally:
+        torch.rand_like = orig_rand_like
+
+
 def gen_head(name, N=16, T=36, seed=41):
     """The other Go2-rough heads -- Go2TS, Go2CTS, Go2Dreamwaq, Go2CaT (legged_gym/envs/__init__.py:82-86) -- run AS CONFIGURED
     on the rough fake simulator: same recording as gen_ee.  Stored per step: the clipped actor frame, the newest frame of the
@@ -780,7 +850,9 @@ def gen_head(name, N=16, T=36, seed=41):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["go2", "wtw", "ee", "tron1", "go2_ts", "go2_cts", "go2_dreamwaq", "go2_cat"]
+    which = sys.argv[1:] or ["go2", "wtw", "ee", "tron1", "go2_ts", "go2_cts", "go2_dreamwaq", "go2_cat", "tron1_pf"]
+    if "tron1_pf" in which:
+        gen_tron1_pf()
     for h in ("go2_ts", "go2_cts", "go2_dreamwaq", "go2_cat"):
         if h in which:
             gen_head(h)

@@ -28,7 +28,8 @@ def make_engine(N, env_origins=None, cfg_cls=None):
     from hcr_genesis_lr_cl_amd.config import GO2Cfg
     from hcr_genesis_lr_cl_amd.engine import Engine
     from hcr_genesis_lr_cl_amd.model_compiler import load_model
-    model, cfg = load_model("go2"), (cfg_cls or GO2Cfg)()
+    cfg = (cfg_cls or GO2Cfg)()
+    model = load_model(cfg.asset.name)
     desc, opts, task = builders.make_model_desc(model, cfg), builders.make_sim_options(model, cfg), builders.make_task_cfg(model, cfg)
     eng = Engine(model, desc, opts, task, N, "cuda:0", inject_rand=True)
     cr = cfg.commands.ranges
@@ -452,3 +453,56 @@ def test_tron1_env_runs_physics_and_mdp():
     assert nres > 0 and float(s.base_pos[:, 2].max()) < 3.0
     # sit-pose resets happen (pitched base, tron1_pf_ee.py:277-310)
     assert float(env.theta.max()) <= 1.5 + 1e-6
+
+
+# ------------------------------- tron1_pf (biped on the plane) ------------------------------------
+class PFKernelStepper:
+    def __init__(self, fx, N):
+        from hcr_genesis_lr_cl_amd.config import TRON1PFCfg
+        self.eng, self.model, self.cfg, self.task = make_engine(N, fx["init_env_origins"], TRON1PFCfg)
+        eng = self.eng
+        put(eng, "episode_length_buf", fx["init_episode_length_buf"])
+        put(eng, "commands", fx["init_commands"])
+        eng.buf["friction_values"].fill_(0.0); eng.buf["added_base_mass"].fill_(1.0)    # the fake simulator's initial values
+        self.names = [str(n) for n in fx["reward_names"]]
+
+    def step(self, t, sim, actions, R, counter, override):
+        import torch
+        from hcr_genesis_lr_cl_amd import abi
+        eng = self.eng
+        load_sim(eng, sim)
+        put(eng, "rand_in", R)
+        eng.step(abi.PHASE_PRE | abi.PHASE_POST | abi.PHASE_RESET, torch.from_numpy(actions).cuda(), counter)
+        torch.cuda.synchronize()
+        es = get(eng, "episode_sums")
+        return dict(obs=get(eng, "obs_buf"), priv=get(eng, "priv_obs_buf"), rew=get(eng, "rew_buf"), reset=get(eng, "reset_buf"),
+                    time_out=get(eng, "time_out_buf"), commands=get(eng, "commands"), ep_len=get(eng, "episode_length_buf"),
+                    fail_buf=get(eng, "fail_buf"), feet_air_time=get(eng, "feet_air_time"),
+                    episode_sums=np.stack([es[abi.REWARD_ID[n]] for n in self.names]),
+                    act_hist=np.stack([get(eng, "actions"), get(eng, "last_actions"), get(eng, "llast_actions")]),
+                    sim_dof_pos=get(eng, "dof_pos"), sim_base_pos=get(eng, "base_pos"), sim_base_lin_vel_w=get(eng, "base_lin_vel_w"),
+                    dr=np.concatenate([get(eng, "friction_values"), get(eng, "added_base_mass"), get(eng, "base_com_bias"),
+                                       get(eng, "rand_push_vels")[:, :2]], 1))
+
+
+def test_kernel_reproduces_reference_tron1_pf_golden_vectors():
+    """TRON1PF on the plane, golden vectors from the reference's own class (gen_mdp_fixtures.py gen_tron1_pf)."""
+    from tests.test_mdp_oracle import GOLD_PF, check_pf
+    replay(PFKernelStepper, lambda t, fx, out: check_pf(t, fx, out, rtol=1e-5, atol=5e-5), GOLD_PF)
+
+
+def test_tron1_pf_env_rollout():
+    """The task through the VecEnv surface: 5-tuple, shapes of tron1_pf_config.py:6-14, physics + MDP fused for the biped."""
+    import torch
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    env, cfg = make_env("tron1_pf", 256)
+    obs, priv = env.reset()
+    assert obs.shape == (256, 135) and priv.shape == (256, 225) and env.num_actions == 6
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    n_reset = 0
+    for t in range(200):
+        obs, priv, rew, done, extras = env.step(torch.randn(256, 6, generator=g, device="cuda"))
+        n_reset += int(done.sum())
+    assert torch.isfinite(obs).all() and torch.isfinite(priv).all() and torch.isfinite(rew).all()
+    assert n_reset > 50 and "rew_no_fly" in list(extras["episode"])
+    assert float(env.simulator.base_pos[:, 2].max()) < 1.5

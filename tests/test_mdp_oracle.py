@@ -375,3 +375,53 @@ def test_tron1_fixture_exercises_the_branches():
 
 def test_mdp_oracle_reproduces_reference_tron1_pf_ee():
     replay_rough(GOLD_TRON1, Tron1OracleStepper, check_tron1)
+
+
+# ------------------------------- tron1_pf (biped on the plane) ------------------------------------
+GOLD_PF = os.path.join(os.path.dirname(__file__), "golden", "tron1_pf_mdp.npz")
+
+
+class PFOracleStepper:
+    def __init__(self, fx, N):
+        from hcr_genesis_lr_cl_amd.config import TRON1PFCfg
+        model, cfg = load_model("tron1_pf"), TRON1PFCfg()
+        task = builders.make_task_cfg(model, cfg)
+        o = self.o = MdpOracle(model, cfg, task, N, fx["init_env_origins"])
+        o.episode_length_buf[:] = fx["init_episode_length_buf"]
+        o.commands[:] = fx["init_commands"]
+        o.friction_values[:] = 0; o.added_base_mass[:] = 1          # the generator's fake simulator starts like genesis_simulator.py:646-649
+        self.names = [str(n) for n in fx["reward_names"]]
+
+    def step(self, t, sim, actions, R, counter, override):
+        o = self.o
+        o.step(sim, actions, R, counter)
+        return dict(obs=np.clip(o.obs_buf, -100, 100), priv=o.priv_obs_buf, rew=o.rew_buf, reset=o.reset_buf, time_out=o.time_out_buf,
+                    commands=o.commands, ep_len=o.episode_length_buf, fail_buf=o.fail_buf, feet_air_time=o.feet_air_time,
+                    episode_sums=np.stack([o.episode_sums[abi.REWARD_ID[n]] for n in self.names]),
+                    act_hist=np.stack([o.actions, o.last_actions, o.llast_actions]),
+                    sim_dof_pos=sim["dof_pos"], sim_base_pos=sim["base_pos"], sim_base_lin_vel_w=sim["base_lin_vel_w"],
+                    dr=np.concatenate([o.friction_values, o.added_base_mass, o.base_com_bias, o.rand_push_vels[:, :2]], 1))
+
+
+PF_FLOAT = ("obs", "priv", "rew", "commands", "feet_air_time", "episode_sums", "act_hist", "sim_dof_pos", "sim_base_pos", "sim_base_lin_vel_w", "dr")
+
+
+def check_pf(t, fx, out, rtol=2e-6, atol=2e-6):
+    for k in WTW_EXACT:
+        np.testing.assert_array_equal(np.asarray(out[k]).astype(np.int64), fx[k][t].astype(np.int64), err_msg=f"{k} @ step {t}")
+    for k in PF_FLOAT:
+        np.testing.assert_allclose(np.asarray(out[k]), fx[k][t], rtol=rtol, atol=atol, err_msg=f"{k} @ step {t}")
+
+
+def test_tron1_pf_fixture_exercises_the_branches():
+    fx = np.load(GOLD_PF)
+    names = [str(n) for n in fx["reward_names"]]
+    assert fx["reset"].sum() >= 8 and (fx["counter"] % 500 == 0).any() and "no_fly" in names and len(names) == 19
+    assert fx["obs"].shape[-1] == 5 * 27 and fx["priv"].shape[-1] == 5 * 45
+    k = names.index("no_fly")
+    d = np.diff(fx["episode_sums"][:, k], axis=0)
+    assert (d > 0).any() and (d == 0).any()
+
+
+def test_mdp_oracle_reproduces_reference_tron1_pf():
+    replay(PFOracleStepper, check_pf, GOLD_PF)
