@@ -51,40 +51,123 @@ WORKLOADS = {"go2": "go2_flat, flat-plane contact", "go2_wtw": "go2_wtw, periodi
              "tron1_pf_ee": "tron1_pf_rough (tron1_pf_ee), biped, heightfield terrain + terrain curriculum"}
 
 
-def ppo_rollout(env, iters, dev):
-    """the rollout loop of rsl_rl/runners/on_policy_runner.py:118-124 -- act, step, store -- with the go2
-    policy nets (rsl_rl/modules/actor_critic.py:57-82, dims legged_robot_config.py:279-281) as plain torch modules."""
+def ppo_rollout(task, n, iters, dev, T=24, gamma=0.99, lam=0.95):
+    """the rollout loop of rsl_rl/runners/on_policy_runner.py:118-124 -- act, step, store, then
+    compute_returns -- with the go2 policy nets (rsl_rl/modules/actor_critic.py:57-82, dims legged_robot_config.py:279-281) as
+    plain torch modules.  Two ways:
+      * "eager": the reference's data flow -- policy ops dispatched one by one, nine copy_ per step into the storage, GAE as the
+        reference's Python loop;
+      * "fused": hcr_genesis_lr_cl_amd.rollout.RolloutStorage -- the env writes each observation straight into its storage row
+        (obs_sets = T + 1), the policy's outputs land in their rows, reward / done / bootstrap in one record launch, GAE in two;
+        the policy part of a step (launch-bound: ~25 small kernels) is captured once per row in a HIP graph and replayed."""
     import torch
     import torch.nn as nn
+    from hcr_genesis_lr_cl_amd.envs import TASKS, set_seed
+    from hcr_genesis_lr_cl_amd.rollout import RolloutStorage
 
     def mlp(i, o):
         return nn.Sequential(nn.Linear(i, 512), nn.ELU(), nn.Linear(512, 256), nn.ELU(), nn.Linear(256, 128), nn.ELU(), nn.Linear(128, o)).to(dev)
+    cls, cfg_cls = TASKS[task]
+    cfg = cfg_cls()
+    cfg.env.num_envs = n
+    cfg.hip.obs_sets = T + 1
+    set_seed(int(cfg.seed))
+    env = cls(cfg, None, dev, True)
     torch.manual_seed(1)
-    n, A, O = env.num_envs, env.num_actions, int(env.num_obs)
+    A, O = env.num_actions, int(env.num_obs)
     actor, critic = mlp(O, A), mlp(O, 1)
-    obs = env.get_observations()
-    obs = obs[0] if isinstance(obs, tuple) else obs
-    store = dict(obs=torch.empty(24, n, O, device=dev), act=torch.empty(24, n, A, device=dev), rew=torch.empty(24, n, device=dev),
-                 done=torch.empty(24, n, device=dev), val=torch.empty(24, n, device=dev))
+    log_std = torch.zeros(A, device=dev)
+    env.reset()
+    st = RolloutStorage(n, T, [O], [None], [A], dev, env=env)
+    res = {"steps_per_iter": T, "iters": iters, "zero_copy_observations": bool(st.zero_copy),
+           "policy": "actor/critic MLP 512-256-128 ELU, f32, torch (hipBLASLt GEMMs), unit-std Gaussian sampling + log-prob"}
 
-    def rollout():
-        nonlocal obs
+    def policy_row(t):          # everything the policy contributes to row t, outputs written in place
+        obs = st.observations[t]
+        mu = actor(obs)
+        st.mu[t].copy_(mu)
+        std = log_std.exp().expand_as(mu)
+        st.sigma[t].copy_(std)
+        act = mu + std * torch.randn_like(mu)
+        st.actions[t].copy_(act)
+        st.actions_log_prob[t, :, 0].copy_((-0.5 * ((act - mu) / std) ** 2 - log_std - 0.9189385332046727).sum(-1))
+        st.values[t].copy_(critic(obs))
+
+    graphs = None
+    try:
         with torch.inference_mode():
-            for t in range(24):
-                act = actor(obs) + torch.randn(n, A, device=dev)          # mean + unit-std exploration noise
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                for _ in range(3):
+                    policy_row(0)
+            torch.cuda.current_stream().wait_stream(s)
+            graphs = []
+            for t in range(T):
+                gph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gph):
+                    policy_row(t)
+                graphs.append(gph)
+    except Exception as e:      # noqa: BLE001 -- report, run the same ops eagerly
+        res["graph_error"] = repr(e)[:200]
+        graphs = None
+    res["hip_graph"] = graphs is not None
+
+    def rollout_fused():
+        with torch.inference_mode():
+            for t in range(T):
+                if graphs is not None:
+                    graphs[t].replay()
+                else:
+                    policy_row(t)
+                out = env.step(st.actions[t])
+                st.add_step(out[-3], out[-2], out[-1]["time_outs"], gamma)
+            st.compute_returns(critic(env.get_observations()), gamma, lam)
+            st.clear()
+
+    # the reference's flow on the same env / nets (rollout_storage.py:89-102, 124-138)
+    ref = dict(obs=torch.zeros(T, n, O, device=dev), act=torch.zeros(T, n, A, device=dev), rew=torch.zeros(T, n, 1, device=dev),
+               done=torch.zeros(T, n, 1, device=dev, dtype=torch.uint8), val=torch.zeros(T, n, 1, device=dev), logp=torch.zeros(T, n, 1, device=dev),
+               mu=torch.zeros(T, n, A, device=dev), sigma=torch.zeros(T, n, A, device=dev), ret=torch.zeros(T, n, 1, device=dev))
+
+    def rollout_eager():
+        with torch.inference_mode():
+            obs = env.get_observations()
+            for t in range(T):
+                mu = actor(obs)
+                std = log_std.exp().expand_as(mu)
+                act = mu + std * torch.randn_like(mu)
+                logp = (-0.5 * ((act - mu) / std) ** 2 - log_std - 0.9189385332046727).sum(-1)
                 val = critic(obs)
-                store["obs"][t], store["act"][t], store["val"][t] = obs, act, val[:, 0]
-                out = env.step(act)
-                obs, store["rew"][t], store["done"][t] = out[0], out[-3], out[-2]
-    rollout()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for _ in range(iters):
-        rollout()
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
-    return {"value": n * 24 * iters / dt, "unit": "env-steps/s", "iters": iters, "steps_per_iter": 24,
-            "ms_per_step": dt / (24 * iters) * 1e3, "policy": "actor/critic MLP 512-256-128 ELU, f32, torch (hipBLASLt GEMMs)"}
+                held = obs
+                obs, _, rew, done, extras = env.step(act)
+                rew = rew.clone() + gamma * torch.squeeze(val * extras["time_outs"].unsqueeze(1), 1)
+                ref["obs"][t].copy_(held); ref["act"][t].copy_(act); ref["rew"][t].copy_(rew.view(-1, 1)); ref["done"][t].copy_(done.view(-1, 1))
+                ref["val"][t].copy_(val); ref["logp"][t].copy_(logp.view(-1, 1)); ref["mu"][t].copy_(mu); ref["sigma"][t].copy_(std)
+            last = critic(obs)
+            adv = 0
+            for t in reversed(range(T)):
+                nv = last if t == T - 1 else ref["val"][t + 1]
+                nt = 1.0 - ref["done"][t].float()
+                delta = ref["rew"][t] + nt * gamma * nv - ref["val"][t]
+                adv = delta + nt * gamma * lam * adv
+                ref["ret"][t] = adv + ref["val"][t]
+            a = ref["ret"] - ref["val"]
+            a = (a - a.mean()) / (a.std() + 1e-8)
+            return a
+
+    for name, fn in (("fused", rollout_fused), ("eager", rollout_eager)):
+        fn()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize()
+        dt = time.perf_counter() - t0
+        res[name] = {"value": n * T * iters / dt, "unit": "env-steps/s", "ms_per_step": dt / (T * iters) * 1e3}
+    res["value"], res["unit"], res["ms_per_step"] = res["fused"]["value"], "env-steps/s", res["fused"]["ms_per_step"]
+    res["speedup_vs_eager"] = res["fused"]["value"] / res["eager"]["value"]
+    return res
 
 
 def host_threads():
@@ -338,7 +421,8 @@ def main():
             "build_flags": build_flags(),
         }
         if world == 1 and args.ppo_rollout > 0:
-            out["ppo_rollout"] = ppo_rollout(env, args.ppo_rollout, dev)
+            del env
+            out["ppo_rollout"] = ppo_rollout(args.task, n_local, args.ppo_rollout, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
         print(json.dumps(out), flush=True)

@@ -225,13 +225,19 @@ def load_lib():
     lib.lg_time_steps.argtypes = [H, C.c_void_p, i64, i32, C.c_void_p, C.POINTER(C.c_float)]
     lib.lg_obs_window.argtypes = [H, C.POINTER(i32)]
     lib.lg_obs_set.argtypes = [H, C.POINTER(i32)]
+    lib.lg_obs_set_select.argtypes = [H, i32]
     lib.lg_profile.argtypes = [H, i32]
     lib.lg_profile_read.argtypes = [H, C.POINTER(C.c_float), C.POINTER(i32)]
     lib.lg_philox.argtypes = [C.POINTER(u32 * 4), C.POINTER(u32 * 2), C.POINTER(u32 * 4)]
     lib.lg_philox.restype = C.c_int
+    lib.lg_rollout_record.argtypes = [i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, f32, C.c_void_p, C.c_void_p,
+                                      C.POINTER(LgRowCopy), i32, C.c_void_p]
+    lib.lg_rollout_gae.argtypes = [i32, i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, f32, f32, C.c_void_p, C.c_void_p,
+                                   C.c_void_p, C.c_void_p]
+    lib.lg_rollout_record.restype = lib.lg_rollout_gae.restype = C.c_int
     lib.lg_last_error.restype = C.c_char_p
     lib.lg_abi_version.restype = C.c_int
-    for f in ("lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step", "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_profile",
+    for f in ("lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step", "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_obs_set_select", "lg_profile",
               "lg_profile_read"):
         getattr(lib, f).restype = C.c_int
     _LIB = lib
@@ -239,7 +245,14 @@ def load_lib():
 
 
 EXPORTS = ["lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step",
-           "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_profile", "lg_profile_read", "lg_philox", "lg_last_error", "lg_abi_version"]
+           "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_obs_set_select", "lg_profile", "lg_profile_read", "lg_philox", "lg_last_error",
+           "lg_abi_version"]
+ROLLOUT_EXPORTS = ["lg_rollout_record", "lg_rollout_gae"]          # include/lgrollout.h
+ROLLOUT_MAX_COPIES = 8
+
+
+class LgRowCopy(C.Structure):
+    _fields_ = [("src", C.c_void_p), ("dst", C.c_void_p), ("width", i32), ("src_stride", i32)]
 
 
 def check(rc, lib=None):

@@ -4,7 +4,7 @@ import subprocess
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SRC = ["lg_kernel.hip"]
+SRC = ["lg_kernel.hip", "lg_rollout.hip"]
 OUT = os.path.join(CSRC, "liblgsim.so")
 # -fno-slp-vectorize: packing scalars into v_pk_* costs more v_mov / AGPR shuffles than it saves here.
 # iterative-ilp scheduling: the kernels run one wave per SIMD, so occupancy is irrelevant and the scheduler should fill DPP /
@@ -17,6 +17,7 @@ def needs_build():
         return True
     deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
     deps.append(os.path.join(HERE, "..", "include", "lgsim.h"))
+    deps.append(os.path.join(HERE, "..", "include", "lgrollout.h"))
     return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
 
 

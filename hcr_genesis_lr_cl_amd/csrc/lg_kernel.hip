@@ -166,7 +166,7 @@ static void fill_hot(LgHot &H, const LgTaskCfg &t, const LgSimOptions &o, const 
     H.obs_stack = t.obs_stack;
     H.priv_stack = t.priv_stack;
     H.obs_slack = t.obs_slack;
-    H.obs_sets = t.obs_sets > 1 ? 2 : 1;
+    H.obs_sets = t.obs_sets > 1 ? t.obs_sets : 1;
     H.reward_mask = 0;
     for (int i = 0; i < LG_R_COUNT; i++) if (t.reward_scales[i] != 0.f) H.reward_mask |= (int32_t)(1u << i);
     H.control_dt = t.control_dt;
@@ -316,6 +316,7 @@ struct KParams {
     // loads that return before anything else): reading them from the hot block would put a full memory round trip in
     // front of the burst
     struct { int m_n_links, m_foot_link[4], obs_layout, o_n_height_points; unsigned reward_mask; float clip_actions;
+             int cat_enable;      // LgTaskCfg.cat_enable: tested on every step, so not behind a memory round trip
              int joint_axis[3];   // per joint index: 0/1/2 if that joint's axis is +-e_x/e_y/e_z on every leg, else -1 (lg_quad.h joint_rot)
     } k;
     int obs_win;         // first frame of the observation window this launch writes (sliding history, LgTaskCfg.obs_slack)
@@ -483,7 +484,10 @@ enum { XA = 0, XLA = 3, XLLA = 6, XQ = 9, XQD = 12, XLQD = 15, XTQ = 18, XFL = 2
 // The body of the leg-per-lane step.  FUSED = called from the tail of quad_sim_kernel (lg_quad.h) by the first 16 lanes of
 // the wave, one per leg of the wave's envs: the model table, the hot constants and the command ranges are already in
 // LDS, `vtid` is the leg-lane index and nothing is staged here.
-template <int LEGS, unsigned PH, bool FUSED>
+// FLAT: the launch is known (host-checked, `flat_profile`) to be the plain go2-on-a-plane task -- one unstacked 45-wide
+// observation, no privileged output, no gait clock, no terrain, no task extras: those switches become compile-time constants
+// and every other task's code drops out of the instantiation (fewer scalar registers, a shorter tail).
+template <int LEGS, unsigned PH, bool FUSED, bool FLAT = false>
 LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF, const float *sX, const int vtid, const int vlane) {
     constexpr bool DO_PRE = (PH & LG_PHASE_PRE) != 0, DO_SIM = (PH & LG_PHASE_SIM) != 0;
     constexpr bool DO_POST = (PH & LG_PHASE_POST) != 0, DO_RESET = (PH & LG_PHASE_RESET) != 0;
@@ -607,7 +611,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             rdof_lo[j] = T->reset_dof_lo[d0 + j]; rdof_span[j] = T->reset_dof_span[d0 + j];
             nv_q[j] = T->noise_vec[9 + d0 + j]; nv_qd[j] = T->noise_vec[9 + A + d0 + j]; nv_act[j] = T->noise_vec[9 + 2 * A + d0 + j];
         }
-        if (p.k.obs_layout == LG_OBS_TRON1_EE) { nv_clk[0] = T->noise_vec[9 + 3 * A + foot_slot]; nv_clk[1] = T->noise_vec[9 + 3 * A + LEGS + foot_slot]; }
+        if (!FLAT && p.k.obs_layout == LG_OBS_TRON1_EE) { nv_clk[0] = T->noise_vec[9 + 3 * A + foot_slot]; nv_clk[1] = T->noise_vec[9 + 3 * A + LEGS + foot_slot]; }
         cmd0 = B.commands[4 * e]; cmd1 = B.commands[4 * e + 1]; cmd2 = B.commands[4 * e + 2]; cmd3 = B.commands[4 * e + 3];
         ep_len = B.episode_length_buf[e];
         fail_buf = B.fail_buf[e];
@@ -635,7 +639,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     float hts[HMAX];
 #pragma unroll
     for (int i = 0; i < HMAX; i++) hts[i] = 0.f;
-    const int P = p.k.o_n_height_points;
+    const int P = FLAT ? 0 : p.k.o_n_height_points;
     const bool hreg = P <= HMAX * LEGS;
     float foot_hmean = 0.f, foot_hmax = 0.f;  // mean / max of the 9 terrain heights around this lane's foot (a8)
     float mean_height = 0.f;         // mean over the height-sample grid of (base_z - h) is formed from this (a7)
@@ -1271,32 +1275,32 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     const auto hc_resample_steps = HOT(resample_steps);
     const auto hc_heading_command = HOT(heading_command);
     const auto hc_push_interval = HOT(push_interval);
-    const auto hc_obs_layout = HOT(obs_layout);
-    const auto hc_gait_mode = HOT(gait_mode);
+    const auto hc_obs_layout = FLAT ? (HOT_T(obs_layout))(LG_OBS_GO2) : HOT(obs_layout);
+    const auto hc_gait_mode = FLAT ? (HOT_T(gait_mode))(0) : HOT(gait_mode);
     const auto hc_add_noise = HOT(add_noise);
-    const auto hc_double_shift = HOT(double_shift);
+    const auto hc_double_shift = FLAT ? (HOT_T(double_shift))(0) : HOT(double_shift);
     const auto hc_obs_frame = HOT(obs_frame);
-    const auto hc_obs_stack = HOT(obs_stack);
-    const auto hc_obs_slack = HOT(obs_slack);
+    const auto hc_obs_stack = FLAT ? (HOT_T(obs_stack))(1) : HOT(obs_stack);
+    const auto hc_obs_slack = FLAT ? (HOT_T(obs_slack))(0) : HOT(obs_slack);
     const auto hc_obs_sets = HOT(obs_sets);
-    const auto hc_priv_frame = HOT(priv_frame);
-    const auto hc_priv_stack = HOT(priv_stack);
+    const auto hc_priv_frame = FLAT ? (HOT_T(priv_frame))(0) : HOT(priv_frame);
+    const auto hc_priv_stack = FLAT ? (HOT_T(priv_stack))(0) : HOT(priv_stack);
     const auto hc_num_obs = HOT(num_obs);
-    const auto hc_num_priv_obs = HOT(num_priv_obs);
+    const auto hc_num_priv_obs = FLAT ? (HOT_T(num_priv_obs))(0) : HOT(num_priv_obs);
     const auto hc_max_push_vel_xy = HOT(max_push_vel_xy);
     const auto hc_episode_length_s = HOT(episode_length_s);
     const auto hc_seed = HOT(seed);
     const auto hc_env_id_offset = HOT(env_id_offset);
     const auto hc_heights_offset = HOT(heights_offset);
     const auto hc_obs_scale_height = HOT(obs_scale_height);
-    const auto hc_noise_act0 = HOT(noise_act0);
+    const auto hc_noise_act0 = FLAT ? (HOT_T(noise_act0))(0) : HOT(noise_act0);
     const auto hc_about_landing_threshold = HOT(about_landing_threshold);
-    const auto hc_terrain_curriculum = HOT(terrain_curriculum);
-    const auto hc_custom_origins = HOT(custom_origins);
-    const auto hc_sit_percent = HOT(sit_percent);
-    const auto hc_behavior_resample_steps = HOT(behavior_resample_steps);
+    const auto hc_terrain_curriculum = FLAT ? (HOT_T(terrain_curriculum))(0) : HOT(terrain_curriculum);
+    const auto hc_custom_origins = FLAT ? (HOT_T(custom_origins))(0) : HOT(custom_origins);
+    const auto hc_sit_percent = FLAT ? (HOT_T(sit_percent))(0) : HOT(sit_percent);
+    const auto hc_behavior_resample_steps = FLAT ? (HOT_T(behavior_resample_steps))(0) : HOT(behavior_resample_steps);
     const auto hc_heights_clip_scale = HOT(heights_clip_scale);
-    const auto hc_num_labels = HOT(num_labels);
+    const auto hc_num_labels = FLAT ? (HOT_T(num_labels))(0) : HOT(num_labels);
     asm volatile("" ::: "memory");
     if (STASH || FUSED) {   // bring the MDP working set back from LDS (fused: prefetched by quad_sim_kernel's prologue)
         const int t = threadIdx.x;
@@ -1333,7 +1337,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
 
     // ---- periodic-gait task state (go2_wtw.py:295-346): per-env scalars + this lane's foot entries
     const bool WTW = hc_gait_mode == 1, BIPED = hc_gait_mode == 2, GAIT = WTW || BIPED;
-    float *ts = B.task_state ? B.task_state + (size_t)e * HOT(task_state_width) : nullptr;
+    float *ts = (!FLAT && B.task_state) ? B.task_state + (size_t)e * HOT(task_state_width) : nullptr;
     float gait_time = 0.f, phi = 0.f, gait_period = 1.f, bh_tgt = 0.f, fc_tgt = 0.f, pitch_tgt = 0.f, theta = 0.f, expC = 0.f;
     if (WTW) {
         gait_time = ts[0]; phi = ts[1]; gait_period = ts[2]; bh_tgt = ts[3]; fc_tgt = ts[4]; pitch_tgt = ts[5];
@@ -1420,7 +1424,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         //      soft_p for a violated soft / style one (constraint_manager.py:25-74 with binary inputs), per-episode violation counts
         float cat_keep = 1.f;     // (1 - p), applied to the reward before the positive clip (go2_cat.py:219-223)
         float cstr_p = 0.f;
-        if (T->cat_enable) {
+        if (!FLAT && p.k.cat_enable) {
             int c_tq = 0, c_qd = 0, c_ar = 0, lo_any = 0, hi_any = 0, c_fast = 0;
 #pragma unroll
             for (int j = 0; j < 3; j++) {
@@ -1891,6 +1895,9 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         float *on2 = (two && SL > 0 && ST > 1) ? oset_x + (size_t)e * orow + (size_t)p.obs_win * FR + (size_t)(ST - 1) * FR : nullptr;
         float *pn2 = (two && SL > 0 && PST > 1 && pset_x) ? pset_x + (size_t)e * prow + (size_t)p.obs_win * PF + (size_t)(PST - 1) * PF : nullptr;
         float *on = o + (ST - 1) * FR, *pn = pv ? pv + (PST - 1) * PF : nullptr;
+        // wave-uniform copies of "is there a privileged frame / a second copy to write" (the pointers themselves are per lane:
+        // a test on them costs a compare and an EXEC update per store)
+        const bool has_pn = hc_num_priv_obs > 0, has_on2 = two && SL > 0 && ST > 1, has_pn2 = two && SL > 0 && PST > 1 && hc_num_priv_obs > 0;
         const bool nz = hc_add_noise != 0;
         const int ns = HOT(slots.noise);
         // uniforms for the noisy entries only (commands and actions carry zero noise scale): q, qd per lane,
@@ -1948,14 +1955,14 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         }
         const float pclip = (hc_obs_layout == LG_OBS_PROGRAM && !T->priv_prog.clip) ? 3.0e38f : co;
         auto put = [&](int idx, float v, float u, float nscale) {   // critic copy of the frame is noise-free
-            if (pn && pfo >= 0) { const float c = clampf(v, -pclip, pclip); pn[pfo + idx] = c; if (pn2) pn2[pfo + idx] = c; }
+            if (has_pn && pfo >= 0) { const float c = clampf(v, -pclip, pclip); pn[pfo + idx] = c; if (has_pn2) pn2[pfo + idx] = c; }
             if (nxo >= 0) labp[nxo + idx] = idx >= 9 + 2 * A ? v * HOT(o_action_scale) : v;     // go2_dreamwaq.py:66-74, not clipped
             if (nz) v += (2.f * u - 1.f) * nscale;
             const float c = clampf(v, -co, co);
             on[idx] = c;
-            if (on2) on2[idx] = c;
+            if (has_on2) on2[idx] = c;
         };
-        auto putp = [&](int idx, float v) { const float c = clampf(v, -co, co); pn[idx] = c; if (pn2) pn2[idx] = c; };
+        auto putp = [&](int idx, float v) { const float c = clampf(v, -co, co); pn[idx] = c; if (has_pn2) pn2[idx] = c; };
         if (live) {
 #pragma unroll
             for (int j = 0; j < 3; j++) {
@@ -2110,7 +2117,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 auto Wr = [&](int idx, float v) {
                     v = clampf(v, -cl, cl);
                     if (to_lab) labp[idx] = v;
-                    else { pn[idx] = v; if (pn2) pn2[idx] = v; }
+                    else { pn[idx] = v; if (has_pn2) pn2[idx] = v; }
                 };
                 for (int s_ = 0; s_ < pr.n_segs; s_++) {
                     const int kind = pr.kind[s_], off = pr.offset[s_];
@@ -2244,6 +2251,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
 // =============================== host side: the C ABI ==========================================
 static thread_local std::string g_err;
 static int fail(const std::string &m) { g_err = m; return 1; }
+int lg_fail_msg(const std::string &m) { return fail(m); }   // for the other translation units of the library (lg_rollout.hip)
 #define HIPCHK(x) do { hipError_t _e = (x); if (_e != hipSuccess) return fail(std::string(#x) + ": " + hipGetErrorString(_e)); } while (0)
 
 struct LgEngine {
@@ -2312,6 +2320,9 @@ extern "C" int lg_create(const LgModelDesc *model, const LgSimOptions *opts, con
         return fail("lg_create: obs_slack must be 0 or at least as large as the history stacks");
     if (task->obs_sets > 1 && task->obs_slack > 0 && (task->obs_slack <= task->obs_stack || task->obs_slack <= task->priv_stack))
         return fail("lg_create: with two observation sets obs_slack must exceed the history stacks");
+    if (task->obs_sets > 2 && (task->obs_stack > 1 || task->priv_stack > 1))
+        return fail("lg_create: more than two observation sets (rollout-resident observations) need unstacked observations");
+    if (task->obs_sets > 4096) return fail("lg_create: obs_sets out of range");
     LgEngine *h = new LgEngine();
     h->model = *model; h->opts = *opts; h->task = *task;
     memset(&h->bufs, 0, sizeof(h->bufs));
@@ -2395,6 +2406,17 @@ static int prof_begin(LgEngine *h, hipStream_t st) {
         if ((pi) >= 0) hipExtLaunchKernelGGL(kern, grid_, block, 0, st, nullptr, h->prof_ev[2 * (pi) + 1], 0, p); \
         else hipLaunchKernelGGL(kern, grid_, block, 0, st, p); } while (0)
 
+// the plain go2-on-a-plane task: every switch the FLAT instantiations hard-wire (env_step_body) really has that value
+static bool flat_profile(const LgEngine *h) {
+    const LgTaskCfg &t = h->task;
+    const LgSimOptions &o = h->opts;
+    const LgBuffers &b = h->bufs;
+    return t.obs_layout == LG_OBS_GO2 && t.gait_mode == 0 && t.double_shift == 0 && t.obs_stack == 1 && t.obs_slack == 0 && t.priv_frame == 0 &&
+           t.priv_stack <= 1 && t.num_priv_obs == 0 && t.terrain_curriculum == 0 && t.custom_origins == 0 && t.sit_percent == 0.f &&
+           t.behavior_resample_steps == 0 && t.num_labels == 0 && t.cat_enable == 0 && t.noise_vec[9 + 6 * h->model.n_legs] == 0.f &&
+           o.n_height_points == 0 && o.terrain_rows == 0 && o.feet_terrain_info == 0 && !b.link_contact_states && !b.task_state && !h->hf;
+}
+
 template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *actions, int64_t counter, hipStream_t st) {
     KParams p;
     p.M = h->d_model; p.O = h->d_opts; p.T = h->d_task; p.H = h->d_hot; p.hf = h->hf; p.B = h->bufs; p.actions = actions; p.counter = counter;
@@ -2405,6 +2427,7 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
         for (int i = 0; i < 4; i++) p.k.m_foot_link[i] = hot.m_foot_link[i];
         p.k.obs_layout = hot.obs_layout; p.k.o_n_height_points = hot.o_n_height_points;
         p.k.reward_mask = (unsigned)hot.reward_mask; p.k.clip_actions = hot.clip_actions;
+        p.k.cat_enable = h->task.cat_enable;
         for (int j = 0; j < 3; j++) {
             int code = -2;
             for (int l = 0; l < LEGS; l++) {
@@ -2426,8 +2449,8 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
     p.obs_set = h->obs_set;
     if (ph & LG_PHASE_RESET) {
         const LgTaskCfg &t = h->task;
-        const int sets = t.obs_sets > 1 ? 2 : 1;
-        if (sets == 2) p.obs_set = (h->obs_set ^= 1);      // this launch writes the copy the caller is NOT holding
+        const int sets = t.obs_sets > 1 ? t.obs_sets : 1;
+        if (sets > 1) p.obs_set = h->obs_set = (h->obs_set + 1) % sets;      // this launch writes a copy the caller is NOT holding
         if (t.obs_slack > 0) {
             // the observation written by this launch lives one frame further; out of slack -> compact first (source and
             // destination ranges are disjoint because lg_create enforces slack >= stack, and with two sets the window the
@@ -2461,7 +2484,8 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
         // MDP phases: in the tail of the same launch for the quadruped (measured 39.5 vs 40.6 us for go2, 69.6 vs 72.5
         // for go2_ee), as a second launch for the biped (84.7 vs 90.6 us for tron1_pf_ee: 8 envs per wave there)
         const bool fuse = LEGS == 4 && pre && rest != 0;
-        if (fuse && rest == (LG_PHASE_POST | LG_PHASE_RESET)) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET>), qgrid);
+        if (fuse && rest == (LG_PHASE_POST | LG_PHASE_RESET) && flat_profile(h)) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET, true>), qgrid);
+        else if (fuse && rest == (LG_PHASE_POST | LG_PHASE_RESET)) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET>), qgrid);
         else if (fuse && rest == LG_PHASE_POST) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST>), qgrid);
         else if (pre && rest) LG_LAUNCH_FIRST(pi, (quad_sim_kernel<LEGS, true, 0u>), qgrid);
         else if (pre) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, 0u>), qgrid);
@@ -2559,6 +2583,14 @@ extern "C" int lg_obs_window(LgHandle h, int32_t *first_frame) {
 extern "C" int lg_obs_set(LgHandle h, int32_t *set) {
     if (!h || !set) return fail("lg_obs_set: null argument");
     *set = h->task.obs_sets > 1 ? h->obs_set : 0;
+    return 0;
+}
+
+extern "C" int lg_obs_set_select(LgHandle h, int32_t set) {
+    if (!h) return fail("lg_obs_set_select: null handle");
+    const int sets = h->task.obs_sets > 1 ? h->task.obs_sets : 1;
+    if (set < 0 || set >= sets) return fail("lg_obs_set_select: set out of range");
+    h->obs_set = set;
     return 0;
 }
 

@@ -113,7 +113,7 @@ class Engine:
             specs["obs_buf"] = (((task.obs_stack + SL) * task.obs_frame,), torch.float32)
             if task.num_priv_obs:
                 specs["priv_obs_buf"] = (((task.priv_stack + SL) * task.priv_frame,), torch.float32)
-        sets = 2 if int(task.obs_sets) > 1 else 1
+        sets = int(task.obs_sets) if int(task.obs_sets) > 1 else 1
         outs = [k for k in ("obs_buf", "priv_obs_buf", "labels_buf") if k in specs]
         if sets == 2 and SL:
             specs["obs_dirty"] = ((), torch.uint8)

@@ -191,8 +191,8 @@ typedef struct LgTaskCfg {
     int32_t obs_slack;               /* history stacks only: extra frames per row; the stacked observation is a window that
                                       * slides one frame per step over rows of (stack + slack) frames (lg_obs_window), so a
                                       * step writes one frame instead of moving the whole history; 0 = shift in place */
-    int32_t obs_sets;                /* 1 or 2 copies of obs_buf / priv_obs_buf / labels_buf.  With 2, consecutive launches
-                                      * alternate between the copies, so the observation tensors handed out by one step stay
+    int32_t obs_sets;                /* copies of obs_buf / priv_obs_buf / labels_buf (1, 2, or more when nothing is stacked).  Consecutive
+                                      * launches cycle through the copies, so the observation tensors handed out by one step stay
                                       * intact while the next step runs (the reference's step() returns a fresh tensor,
                                       * legged_robot.py:48-49, and rsl_rl keeps it across env.step(), ppo.py:103-104);
                                       * needs obs_slack >= stack + 1 when obs_slack > 0 */
@@ -345,6 +345,11 @@ int lg_obs_window(LgHandle h, int32_t *first_frame);
 /* Copy (0 or 1; always 0 with obs_sets == 1) of obs_buf / priv_obs_buf / labels_buf that holds the most recent
  * observation: copy s starts s * n_envs * row floats into the allocation. */
 int lg_obs_set(LgHandle h, int32_t *set);
+/* Declare copy `set` to be the one holding the current observation (the caller has put it there): the next observation
+ * launch writes copy (set + 1) % obs_sets.  With obs_sets = T + 1 unstacked copies a rollout storage of T steps lays its
+ * observation rows over copies 0 .. T-1 and the env writes every step's observation straight into its row
+ * (rsl_rl/storage/rollout_storage.py:92 without the copy). */
+int lg_obs_set_select(LgHandle h, int32_t set);
 int lg_profile(LgHandle h, int32_t stride);
 int lg_profile_read(LgHandle h, float *mean_us, int32_t *samples);
 /* Diagnostic: one Philox4x32-10 block computed on the device by the kernel's own generator (known-answer tests). */

@@ -12,11 +12,12 @@ from hcr_genesis_lr_cl_amd import abi
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 HEADER = os.path.join(ROOT, "include", "lgsim.h")
+HEADER_ROLLOUT = os.path.join(ROOT, "include", "lgrollout.h")
 
 
 def _probe(structs):
     """Compile a C probe printing sizeof + offsetof of every field."""
-    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', "int main(void){"]
+    lines = ['#include <stdio.h>', '#include <stddef.h>', f'#include "{HEADER}"', f'#include "{HEADER_ROLLOUT}"', "int main(void){"]
     for cname, cls in structs:
         lines.append(f'printf("{cname} %zu\\n", sizeof({cname}));')
         for fname, _ in cls._fields_:
@@ -32,7 +33,7 @@ def _probe(structs):
 
 def test_struct_layouts_match_header():
     structs = [("LgModelDesc", abi.LgModelDesc), ("LgSimOptions", abi.LgSimOptions), ("LgRandSlots", abi.LgRandSlots),
-               ("LgTaskCfg", abi.LgTaskCfg), ("LgBuffers", abi.LgBuffers)]
+               ("LgObsProgram", abi.LgObsProgram), ("LgTaskCfg", abi.LgTaskCfg), ("LgBuffers", abi.LgBuffers), ("LgRowCopy", abi.LgRowCopy)]
     got = _probe(structs)
     for cname, cls in structs:
         assert int(got[cname]) == C.sizeof(cls), cname
@@ -59,8 +60,10 @@ def test_library_exports_every_declared_symbol():
     h = open(HEADER).read()
     declared = set(re.findall(r"\b(lg_\w+)\s*\(", h))
     assert declared == set(abi.EXPORTS)
+    declared_r = set(re.findall(r"\b(lg_\w+)\s*\(", open(HEADER_ROLLOUT).read()))
+    assert declared_r == set(abi.ROLLOUT_EXPORTS)
     lib = C.CDLL(abi.lib_path())        # loads without a GPU; nothing is called
-    for sym in declared:
+    for sym in declared | declared_r:
         assert hasattr(lib, sym), sym
 
 
