@@ -226,6 +226,7 @@ def load_lib():
     lib.lg_obs_window.argtypes = [H, C.POINTER(i32)]
     lib.lg_obs_set.argtypes = [H, C.POINTER(i32)]
     lib.lg_obs_set_select.argtypes = [H, i32]
+    lib.lg_obs_window_select.argtypes = [H, i32]
     lib.lg_profile.argtypes = [H, i32]
     lib.lg_profile_read.argtypes = [H, C.POINTER(C.c_float), C.POINTER(i32)]
     lib.lg_philox.argtypes = [C.POINTER(u32 * 4), C.POINTER(u32 * 2), C.POINTER(u32 * 4)]
@@ -237,7 +238,7 @@ def load_lib():
     lib.lg_rollout_record.restype = lib.lg_rollout_gae.restype = C.c_int
     lib.lg_last_error.restype = C.c_char_p
     lib.lg_abi_version.restype = C.c_int
-    for f in ("lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step", "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_obs_set_select", "lg_profile",
+    for f in ("lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step", "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_obs_set_select", "lg_obs_window_select", "lg_profile",
               "lg_profile_read"):
         getattr(lib, f).restype = C.c_int
     _LIB = lib
@@ -245,7 +246,7 @@ def load_lib():
 
 
 EXPORTS = ["lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step",
-           "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_obs_set_select", "lg_profile", "lg_profile_read", "lg_philox", "lg_last_error",
+           "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_obs_set_select", "lg_obs_window_select", "lg_profile", "lg_profile_read", "lg_philox", "lg_last_error",
            "lg_abi_version"]
 ROLLOUT_EXPORTS = ["lg_rollout_record", "lg_rollout_gae"]          # include/lgrollout.h
 ROLLOUT_MAX_COPIES = 8

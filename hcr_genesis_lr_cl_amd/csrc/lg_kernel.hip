@@ -2594,6 +2594,13 @@ extern "C" int lg_obs_set_select(LgHandle h, int32_t set) {
     return 0;
 }
 
+extern "C" int lg_obs_window_select(LgHandle h, int32_t first_frame) {
+    if (!h) return fail("lg_obs_window_select: null handle");
+    if (first_frame < 0 || first_frame > h->task.obs_slack) return fail("lg_obs_window_select: window out of range");
+    h->obs_win = h->task.obs_slack > 0 ? first_frame : 0;
+    return 0;
+}
+
 extern "C" int lg_profile(LgHandle h, int32_t stride) {
     if (!h || stride < 0) return fail("lg_profile: bad argument");
     h->prof_stride = stride; h->prof_seen = 0;

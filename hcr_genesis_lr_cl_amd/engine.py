@@ -209,6 +209,35 @@ class Engine:
         """Copy of the observation buffers the latest observation launch wrote (0 with a single set)."""
         return self._obs_slot[0]
 
+    # ---- checkpointing (SURVEY 8(f)4): the reference never saves simulator or curriculum state (SURVEY section 5); here a run
+    #      can be resumed exactly, because every piece of state is a caller-owned buffer plus two integers in the handle ----
+    def state_dict(self):
+        """All device buffers (the whole allocations, both observation copies and the history slack) and the position of the
+        observation window / copy.  Random draws need no state: Philox is keyed on (seed, global env id, step counter, slot)."""
+        sd = {"buffers": {k: self.buf.raw(k).detach().clone() for k in self.buf.keys()},
+              "obs_slot": tuple(self._obs_slot), "n_envs": self.n}
+        if getattr(self, "height_samples", None) is not None:
+            sd["height_samples"] = self.height_samples.detach().clone()     # the int16 heightfield the state was produced on
+        return sd
+
+    def load_state_dict(self, sd):
+        if int(sd["n_envs"]) != self.n:
+            raise ValueError("checkpoint was taken with a different number of envs")
+        hs = sd.get("height_samples")
+        if (hs is None) != (getattr(self, "height_samples", None) is None) or (hs is not None and not torch.equal(hs.to(self.device), self.height_samples)):
+            raise ValueError("checkpoint was taken on a different terrain (heightfield differs): build the env with the same terrain seed")
+        for k, v in sd["buffers"].items():
+            if k not in self.buf:
+                raise KeyError(f"checkpoint buffer {k!r} does not exist in this engine")
+            dst = self.buf.raw(k)
+            if dst.shape != v.shape or dst.dtype != v.dtype:
+                raise ValueError(f"checkpoint buffer {k!r}: {tuple(v.shape)} {v.dtype} != {tuple(dst.shape)} {dst.dtype}")
+            dst.copy_(v)
+        s_, w = sd["obs_slot"]
+        abi.check(self.lib.lg_obs_set_select(self.handle, int(s_)), self.lib)
+        abi.check(self.lib.lg_obs_window_select(self.handle, int(w)), self.lib)
+        self._refresh_obs_slot()
+
     def profile(self, stride):
         """Time the physics kernel of every `stride`-th step with HIP events (0 = off)."""
         abi.check(self.lib.lg_profile(self.handle, int(stride)), self.lib)

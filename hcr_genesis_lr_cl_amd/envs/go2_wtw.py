@@ -23,6 +23,9 @@ from .legged_robot import LeggedRobot
 
 
 class GO2WTW(LeggedRobot):
+    _HOST_STATE = LeggedRobot._HOST_STATE + ("gait_period_range", "foot_clearance_target_range", "base_height_target_range",
+                                             "pitch_target_range", "num_gaits")
+
     def _parse_cfg(self, cfg):
         super()._parse_cfg(cfg)
         bp = cfg.rewards.behavior_params_range                      # go2_wtw.py:348-376

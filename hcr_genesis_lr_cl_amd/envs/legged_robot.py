@@ -198,6 +198,34 @@ class LeggedRobot:
     def get_observations(self):
         return self.obs_buf
 
+    # ---- checkpoint / resume ---------------------------------------------------------------------------
+    _HOST_STATE = ("common_step_counter", "command_ranges")
+
+    def state_dict(self):
+        """Everything needed to continue this env bit for bit: the engine's buffers (physics state, MDP state, episode sums,
+        observation histories, DR parameters, terrain levels / origins), the step counter that keys the Philox draws, and the
+        host-side curriculum state (command ranges; task classes add theirs through `_HOST_STATE`)."""
+        import copy
+        return {"engine": self._engine.state_dict(), "host": {k: copy.deepcopy(getattr(self, k)) for k in self._HOST_STATE},
+                "task": type(self).__name__, "seed": int(self._engine.task.seed), "env_id_offset": int(self._engine.task.env_id_offset)}
+
+    def load_state_dict(self, sd):
+        import copy
+        if sd["task"] != type(self).__name__:
+            raise ValueError(f"checkpoint of task {sd['task']} loaded into {type(self).__name__}")
+        if int(sd["seed"]) != int(self._engine.task.seed) or int(sd["env_id_offset"]) != int(self._engine.task.env_id_offset):
+            raise ValueError("checkpoint seed / env shard differ from this env's: the random streams would not continue")
+        self._engine.load_state_dict(sd["engine"])
+        for k, v in sd["host"].items():
+            setattr(self, k, copy.deepcopy(v))
+        self._upload_command_ranges()          # also rebinds nothing: the device copy is part of the buffers, this keeps host and device equal
+
+    def save_checkpoint(self, path):
+        torch.save(self.state_dict(), path)
+
+    def load_checkpoint(self, path):
+        self.load_state_dict(torch.load(path, map_location=self.device, weights_only=True))
+
     def get_privileged_observations(self):
         return self.privileged_obs_buf
 

@@ -350,6 +350,9 @@ int lg_obs_set(LgHandle h, int32_t *set);
  * observation rows over copies 0 .. T-1 and the env writes every step's observation straight into its row
  * (rsl_rl/storage/rollout_storage.py:92 without the copy). */
 int lg_obs_set_select(LgHandle h, int32_t set);
+/* Restore the window position of the sliding observation history (checkpoint resume: the buffers are the caller's, the
+ * position of the window inside them is the only observation state the handle keeps besides the copy index). */
+int lg_obs_window_select(LgHandle h, int32_t first_frame);
 int lg_profile(LgHandle h, int32_t stride);
 int lg_profile_read(LgHandle h, float *mean_us, int32_t *samples);
 /* Diagnostic: one Philox4x32-10 block computed on the device by the kernel's own generator (known-answer tests). */

@@ -336,3 +336,42 @@ def test_runner_statements_on_the_env():
             ep_info[key] = ep_info[key].unsqueeze(0)
         assert ep_info[key].shape == (1,)
     assert len(list(ep_info)) == 16
+
+
+@pytest.mark.parametrize("task", ["go2", "go2_wtw", "go2_ee", "tron1_pf_ee"])
+def test_checkpoint_resume_is_bit_exact(task, tmp_path):
+    """save after k steps, keep going, restore into a FRESH env, replay the same actions: every output and every
+    buffer identical to the uninterrupted run (curriculum levels, command ranges, episode sums, observation histories and the
+    counter-keyed random streams all continue)."""
+    import torch
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    N = 96
+    env, _ = make_env(task, N, "cuda:0")
+    env.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(9)
+    env.episode_length_buf = torch.randint(940, 1001, (N,), generator=g, device="cuda", dtype=torch.int32)
+    env.common_step_counter = 960                      # the command-curriculum gate (step 1000) falls inside the replayed part
+    acts = [torch.randn(N, env.num_actions, generator=g, device="cuda") * 1.5 for _ in range(70)]
+    for a in acts[:25]:
+        env.step(a)
+    path = str(tmp_path / "ckpt.pt")
+    env.save_checkpoint(path)
+    ref = []
+    for a in acts[25:]:
+        out = env.step(a)
+        ref.append([o.clone() for o in out[:-1] if torch.is_tensor(o)])
+    final = {k: env._engine.buf.raw(k).clone() for k in env._engine.buf.keys()}
+    ranges = dict(env.command_ranges)
+    env2, _ = make_env(task, N, "cuda:0")
+    env2.reset()
+    env2.load_checkpoint(path)
+    assert env2.common_step_counter == 985
+    for a, want in zip(acts[25:], ref):
+        out = env2.step(a)
+        got = [o for o in out[:-1] if torch.is_tensor(o)]
+        assert len(got) == len(want) and all(torch.equal(x, y) for x, y in zip(got, want))
+    for k, v in final.items():
+        assert torch.equal(env2._engine.buf.raw(k), v), k
+    assert {k: list(v) for k, v in env2.command_ranges.items()} == {k: list(v) for k, v in ranges.items()}
+    with pytest.raises(ValueError):
+        make_env("go2" if task != "go2" else "go2_wtw", N, "cuda:0")[0].load_checkpoint(path)
