@@ -2406,6 +2406,12 @@ static int prof_begin(LgEngine *h, hipStream_t st) {
         if ((pi) >= 0) hipExtLaunchKernelGGL(kern, grid_, block, 0, st, nullptr, h->prof_ev[2 * (pi) + 1], 0, p); \
         else hipLaunchKernelGGL(kern, grid_, block, 0, st, p); } while (0)
 
+static bool flat_noise_ok(const LgEngine *h) {   // commands and actions carry no observation noise (go2.py:92-117)
+    const int A = 3 * h->model.n_legs;
+    for (int i = 0; i < 3; i++) if (h->task.noise_vec[i] != 0.f) return false;
+    for (int i = 0; i < A; i++) if (h->task.noise_vec[9 + 2 * A + i] != 0.f) return false;
+    return true;
+}
 // the plain go2-on-a-plane task: every switch the FLAT instantiations hard-wire (env_step_body) really has that value
 static bool flat_profile(const LgEngine *h) {
     const LgTaskCfg &t = h->task;
@@ -2414,7 +2420,12 @@ static bool flat_profile(const LgEngine *h) {
     return t.obs_layout == LG_OBS_GO2 && t.gait_mode == 0 && t.double_shift == 0 && t.obs_stack == 1 && t.obs_slack == 0 && t.priv_frame == 0 &&
            t.priv_stack <= 1 && t.num_priv_obs == 0 && t.terrain_curriculum == 0 && t.custom_origins == 0 && t.sit_percent == 0.f &&
            t.behavior_resample_steps == 0 && t.num_labels == 0 && t.cat_enable == 0 && t.noise_vec[9 + 6 * h->model.n_legs] == 0.f &&
-           o.n_height_points == 0 && o.terrain_rows == 0 && o.feet_terrain_info == 0 && !b.link_contact_states && !b.task_state && !h->hf;
+           o.n_height_points == 0 && o.terrain_rows == 0 && o.feet_terrain_info == 0 && !b.link_contact_states && !b.task_state && !h->hf &&
+           !b.rand_in && !b.joint_armature && !t.dr_joint_on && flat_noise_ok(h) &&
+           // reward terms the component-layout tail (lg_quad.h) does not carry: gait clocks, biped and wtw-only terms
+           ((unsigned)h->hot.reward_mask & ((1u << LG_R_BIPED_PERIODIC_GAIT) | (1u << LG_R_QUAD_PERIODIC_GAIT) | (1u << LG_R_FEET_DISTANCE) |
+                                            (1u << LG_R_TRACKING_BASE_HEIGHT) | (1u << LG_R_TRACKING_FOOT_CLEARANCE) |
+                                            (1u << LG_R_TRACKING_ORIENTATION))) == 0;
 }
 
 template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *actions, int64_t counter, hipStream_t st) {

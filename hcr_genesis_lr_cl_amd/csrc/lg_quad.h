@@ -362,9 +362,28 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     // (env_step_body<.., FUSED>) reads it back after the physics instead of paying the round trips then.  Layout = the
     // stash of env_step_body (NST values x 16 lanes).
     constexpr int NST = LG_R_COUNT + 36;
-    __shared__ float sStF[MPH != 0 ? NST * 16 : 1];
-    float wsv[MPH != 0 ? NST : 1];
-    if (MPH != 0 && threadIdx.x < 16) {
+    constexpr bool QTAIL = FLAT && MPH == (LG_PHASE_POST | LG_PHASE_RESET);   // MDP phases in component layout on all 64 lanes (below)
+    __shared__ float sStF[(MPH != 0 && !QTAIL) ? NST * 16 : 1];
+    float wsv[(MPH != 0 && !QTAIL) ? NST : 1];
+    // QTAIL working set, one value per lane: command component c, the two episode sums this lane owns (terms ei and ei + 16 of its
+    // env, ei = 4 leg + c), this lane's joint constants; per-env / per-leg scalars replicated
+    static_assert(LG_R_COUNT <= 32, "two episode sums per lane");
+    const int ei = (leg << 2) | L.c;
+    float m_cmd = 0.f, m_air = 0.f, m_es0 = 0.f, m_es1 = 0.f, m_slo = 0.f, m_shi = 0.f, m_rlo = 0.f, m_rsp = 0.f, m_nq = 0.f, m_nqd = 0.f;
+    int m_ep = 0, m_fail = 0, m_lc = 0;
+    if (QTAIL) {
+        m_cmd = k_commands[4 * e + L.c];
+        m_ep = k_episode_length_buf[e];
+        m_fail = (int)k_fail_buf[e];
+        m_air = k_feet_air_time[e * F + foot_slot];
+        m_lc = (int)k_last_contacts[e * F + foot_slot];
+        m_es0 = k_episode_sums[(size_t)ei * N + e];
+        if (ei + 16 < LG_R_COUNT) m_es1 = k_episode_sums[(size_t)(ei + 16) * N + e];
+        m_slo = kT->soft_dof_lo[d0 + cj]; m_shi = kT->soft_dof_hi[d0 + cj];
+        m_rlo = kT->reset_dof_lo[d0 + cj]; m_rsp = kT->reset_dof_span[d0 + cj];
+        m_nq = kT->noise_vec[9 + d0 + cj]; m_nqd = kT->noise_vec[9 + A + d0 + cj];
+    }
+    if (MPH != 0 && !QTAIL && threadIdx.x < 16) {
         const LgTaskCfg GAS *T = kT;
         const int lt = blockIdx.x * 16 + (int)threadIdx.x, legL = lt % LEGS, dL = 3 * legL;
         const int eL = min(lt / LEGS, N - 1);
@@ -396,7 +415,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     sHot[threadIdx.x] = hv0; sHot[threadIdx.x + 64] = hv1; sHot[threadIdx.x + 128] = hv2; sHot[threadIdx.x + 192] = hv3;
     if (MPH != 0) {
         sHot[threadIdx.x + 256] = crv;
-        if (threadIdx.x < 16) {
+        if (!QTAIL && threadIdx.x < 16) {
             const unsigned rm = p.k.reward_mask;
             const bool leadL = (blockIdx.x * 16 + threadIdx.x) % LEGS == 0;
 #pragma unroll
@@ -830,8 +849,8 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         eul = L.is1 ? pit : at;
     }
     const QM Rb = quat_rows(L, quat);
-    const float blv = multv(L, Rb, vw), bav = multv(L, Rb, ww);
-    const float pg = -L.sel(bc<2>(Rb.c0), bc<2>(Rb.c1), bc<2>(Rb.c2));
+    float blv = multv(L, Rb, vw), bav = multv(L, Rb, ww);
+    float pg = -L.sel(bc<2>(Rb.c0), bc<2>(Rb.c1), bc<2>(Rb.c2));
     float foot_p, foot_v;
     {   // foot frame at the final state
         float sv, cv;
@@ -952,8 +971,273 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
 
     STAMP(22);
     STAMPB(8192);
-    // ---------------- MDP phases in the same launch -------------------------------------------------
-    if (MPH != 0) {
+    // ---------------- MDP phases in the same launch, go2-flat profile: component layout, all 64 lanes ------------
+    // Same statements as env_step_body's POST / RESET phases (legged_robot.py:55-168, 300-348, go2.py:17-134) for the plain go2
+    // task, computed on the registers the physics left behind: per-joint values sit in joint lanes, vectors one component per
+    // lane, per-env scalars replicated over the env's 16 lanes.  No LDS hand-off, every lane loads / stores its own share of the
+    // MDP state (two episode sums, one command component ...), and independent Philox blocks are evaluated side by side in
+    // different lanes (a call is ~800 cycles of quarter-rate multiplies whatever the number of lanes using it).  The random
+    // stream is the one of env_step_body (same counters), so both instantiations produce the same rollout.
+    if constexpr (QTAIL) {
+        const float cdt = HOT(control_dt);
+        const unsigned rmask = (unsigned)p.k.reward_mask;
+        const bool heading = HOT(heading_command) != 0;
+        unsigned k0, k1, e_lo, e_hi;
+        {
+            const unsigned long long seed = HOT(seed), gid = (unsigned long long)(HOT(env_id_offset) + e);
+            k0 = (unsigned)(seed & 0xFFFFFFFFu); k1 = (unsigned)(seed >> 32);
+            e_lo = (unsigned)(gid & 0xFFFFFFFFu); e_hi = (unsigned)(gid >> 32);
+        }
+        const unsigned rstep = (unsigned)p.counter;
+        auto philox = [&](unsigned c3) { const U4 c = {e_lo, e_hi, rstep, c3}; return philox4x32_10(c, k0, k1); };
+        auto pick = [](const U4 &r, int k) { return k == 0 ? r.x : (k == 1 ? r.y : (k == 2 ? r.z : r.w)); };
+        auto anyl = [](bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; };
+        auto lane_of_row = [&](int l16) { return (int)((threadIdx.x & 48u) | (unsigned)l16) << 2; };   // byte address for ds_bpermute
+        auto fetch = [&](float v, int l16) { return __int_as_float(__builtin_amdgcn_ds_bpermute(lane_of_row(l16), __float_as_int(v))); };
+        auto jsum = [&](float v) { return bc<0>(legsum<LEGS>(sum3(v))); };       // over the env's joints (value in joint lanes), to all lanes
+        auto vnorm2 = [&](float v) { return bc<0>(sum3(v * v)); };               // |v|^2 of a component-layout vector, to the quad
+
+        float cmdv = m_cmd, air = m_air, es0 = m_es0, es1 = m_es1;
+        int ep_len = m_ep + 1, failb = m_fail, last_contact = m_lc;              // legged_robot.py:60
+        const float CRlo = L.is0 ? CR(0) : (L.is1 ? CR(2) : (L.is2 ? CR(4) : CR(6)));
+        const float CRhi = L.is0 ? CR(1) : (L.is1 ? CR(3) : (L.is2 ? CR(5) : CR(7)));
+        auto resample = [&](float cv, float u0, float u1, float u2) {            // legged_robot.py:317-334
+            const float u = L.is0 ? u0 : (L.is1 ? u1 : u2);
+            const bool upd = heading ? !L.is2 : !L.is3;                          // heading mode draws the heading, not the yaw rate
+            cv = upd ? (CRhi - CRlo) * u + CRlo : cv;
+            const float keep = sqrtf(bc<0>(sum3(cv * cv))) > 0.2f ? 1.f : 0.f;
+            return L.is3 ? cv : cv * keep;
+        };
+        // ---- _post_physics_step_callback (legged_robot.py:300-315) ----
+        {
+            const bool need = (ep_len % HOT(resample_steps)) == 0;
+            if (anyl(need)) {
+                const U4 r = philox(0x40000000u + (unsigned)HOT(slots.cb_cmd));
+                const float nc = resample(cmdv, u01(r.x), u01(r.y), u01(r.z));
+                cmdv = need ? nc : cmdv;
+            }
+        }
+        if (heading) {   // forward = quat_apply(base_quat, [1,0,0]) (math_utils.py:34-40): t = 2 xyz x b = (0, 2 qz, -2 qy)
+            const float ty = 2.f * qz, tz = -2.f * qy;
+            const float fx = 1.f + (qy * tz - qz * ty), fy = ty * qw + (0.f - qx * tz);
+            const float hd = atan2f(fy, fx);
+            const float c2 = clampf(0.5f * wrap_to_pi(bc<3>(cmdv) - hd), HOT(yaw_clip[0]), HOT(yaw_clip[1]));
+            cmdv = L.is2 ? c2 : cmdv;
+        }
+        {
+            const int pi_ = HOT(push_interval);
+            if (pi_ > 0 && (p.counter % pi_) == 0) {   // genesis_simulator.py:150-158; lanes 0 / 1 evaluate the two draws' blocks side by side
+                const int slot = HOT(slots.push) + (L.is1 ? 1 : 0);
+                const U4 r = philox((unsigned)(slot >> 2));
+                const float m = HOT(max_push_vel_xy);
+                const float pv = (m + m) * u01(pick(r, slot & 3)) - m;
+                const bool xy = L.c < 2;
+                vw = xy ? vw + pv : vw;
+                if (live && leg == 0 && xy) { B.rand_push_vels[3 * e + L.c] = pv; B.base_lin_vel_w[3 * e + L.c] = vw; }
+            }
+        }
+        const float cmd0 = bc<0>(cmdv), cmd1 = bc<1>(cmdv), cmd2 = bc<2>(cmdv);
+        // ---- check_termination (legged_robot.py:78-92) ----
+        const unsigned tmask = M->term_link_mask, pmask = M->pen_link_mask;
+        const int l0 = foot_link - 3;
+        float n2[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) n2[k] = vnorm2(f_link[k]);
+        const float nb2 = vnorm2(f_base);
+        const float pgz = bc<2>(pg);
+        int fail = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) fail |= (((tmask >> (l0 + k)) & 1u) && n2[k] > 100.0f) ? 1 : 0;
+        fail = __builtin_amdgcn_update_dpp(0, fail, 0x124, 0xF, 0xF, true) | fail;
+        fail = __builtin_amdgcn_update_dpp(0, fail, 0x128, 0xF, 0xF, true) | fail;
+        fail |= ((tmask & 1u) && nb2 > 100.0f) ? 1 : 0;
+        fail |= pgz > HOT(max_projected_gravity) ? 1 : 0;
+        failb += fail;
+        const bool time_out = (float)ep_len > HOT(max_episode_length);
+        const bool reset = ((float)failb > HOT(fail_threshold)) || time_out;
+
+        // ---- compute_reward (legged_robot.py:150-168): every term replicated over the env's lanes, summed in alphabetical order ----
+        float scl[LG_R_COUNT];
+#pragma unroll
+        for (int k = 0; k < LG_R_COUNT; k++) scl[k] = HOT(reward_scales[k]);
+        float total = 0.f;
+        auto add = [&](int id, float r) {
+            const float rew = r * scl[id];
+            total += rew;
+            if (id < 16) es0 = ei == id ? es0 + rew : es0;
+            else es1 = ei == id - 16 ? es1 + rew : es1;
+        };
+        const float cmd_xy = sqrtf(cmd0 * cmd0 + cmd1 * cmd1);
+        const float cmd_xyz = sqrtf(cmd0 * cmd0 + cmd1 * cmd1 + cmd2 * cmd2);
+        const float dq0 = q - q0;
+        const float fz = bc<2>(f_link[3]);                          // vertical foot force of this leg
+        const float fpz = bc<2>(foot_p), fvx = bc<0>(foot_v), fvy = bc<1>(foot_v), fvz = bc<2>(foot_v);
+        if (RON(LG_R_ACTION_RATE)) { const float d = last_act - act; add(LG_R_ACTION_RATE, jsum(d * d)); }                     // :495-497
+        if (RON(LG_R_ACTION_SMOOTHNESS)) { const float d = act - 2.f * last_act + llast_act; add(LG_R_ACTION_SMOOTHNESS, jsum(d * d)); }   // :499-503
+        if (RON(LG_R_ANG_VEL_XY)) { const float bx = bc<0>(bav), by = bc<1>(bav); add(LG_R_ANG_VEL_XY, bx * bx + by * by); }    // :462-464
+        if (RON(LG_R_BASE_HEIGHT)) { const float d = bc<2>(pos) - HOT(base_height_target); add(LG_R_BASE_HEIGHT, d * d); }     // :470-476 (plane)
+        if (RON(LG_R_COLLISION)) {                                                                                               // :505-512
+            float sc_ = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) sc_ += (((pmask >> (l0 + k)) & 1u) && n2[k] > 0.1f * 0.1f) ? 1.f : 0.f;
+            sc_ = legsum<LEGS>(sc_);
+            sc_ += ((pmask & 1u) && nb2 > 0.1f * 0.1f) ? 1.f : 0.f;
+            add(LG_R_COLLISION, sc_);
+        }
+        if (RON(LG_R_DOF_ACC)) { const float d = (qd_start - qd) / cdt; add(LG_R_DOF_ACC, jsum(d * d)); }                       // :490-493
+        if (RON(LG_R_DOF_CLOSE_TO_DEFAULT)) add(LG_R_DOF_CLOSE_TO_DEFAULT, jsum(dq0 * dq0));                                     // :571-573
+        if (RON(LG_R_DOF_POS_LIMITS)) add(LG_R_DOF_POS_LIMITS, jsum(-fminf(q - m_slo, 0.f) + fmaxf(q - m_shi, 0.f)));            // :518-522
+        if (RON(LG_R_DOF_POS_STAND_STILL)) add(LG_R_DOF_POS_STAND_STILL, jsum(dq0 * dq0) * (cmd_xyz < 0.1f ? 1.f : 0.f));        // :561-563
+        if (RON(LG_R_DOF_POWER)) add(LG_R_DOF_POWER, jsum(fabsf(torque * qd)));                                                  // :486-488
+        if (RON(LG_R_DOF_VEL)) add(LG_R_DOF_VEL, jsum(qd * qd));                                                                 // :482-484
+        if (RON(LG_R_DOF_VEL_STAND_STILL)) add(LG_R_DOF_VEL_STAND_STILL, jsum(fabsf(qd)) * (cmd_xyz < 0.1f ? 1.f : 0.f));        // :557-559
+        if (RON(LG_R_FEET_AIR_TIME)) {                                                                                           // :545-555 (stateful)
+            const int contact = fz > 1.0f ? 1 : 0;
+            const int filt = contact | last_contact;
+            last_contact = contact;
+            const float first = (air > 0.f ? 1.f : 0.f) * (float)filt;
+            air += cdt;
+            float r = legsum<LEGS>((air - HOT(feet_air_time_threshold)) * first);
+            r *= cmd_xy > 0.1f ? 1.f : 0.f;
+            air *= filt ? 0.f : 1.f;
+            add(LG_R_FEET_AIR_TIME, r);
+        }
+        if (RON(LG_R_FEET_CONTACT_STAND_STILL)) {                                                                                // :565-569
+            const float cnt = legsum<LEGS>(fz > 0.1f ? 1.f : 0.f);
+            add(LG_R_FEET_CONTACT_STAND_STILL, (cnt == (float)LEGS ? 1.f : 0.f) * (cmd_xyz < 0.1f ? 1.f : 0.f));
+        }
+        if (RON(LG_R_FOOT_ACC)) { const float a = (foot_v - last_foot_v) * (1.f / cdt); add(LG_R_FOOT_ACC, legsum<LEGS>(vnorm2(a))); }    // :605-608
+        if (RON(LG_R_FOOT_CLEARANCE)) {                                                                                          // :575-588
+            const float vxy = sqrtf(fvx * fvx + fvy * fvy);
+            const float d = fpz - 0.f - HOT(foot_clearance_target) - HOT(foot_height_offset);
+            add(LG_R_FOOT_CLEARANCE, __expf(-legsum<LEGS>(vxy * (d * d)) / HOT(foot_clearance_sigma)));
+        }
+        if (RON(LG_R_FOOT_LANDING_VEL)) {                                                                                        // :590-599
+            const bool land = ((fpz - HOT(foot_height_offset)) < HOT(about_landing_threshold)) && !(fz > 0.1f) && (fvz < 0.f);
+            const float vz = land ? fvz : 0.f;
+            add(LG_R_FOOT_LANDING_VEL, legsum<LEGS>(vz * vz));
+        }
+        if (RON(LG_R_HIP_POS)) { const float h = bc<0>(dq0); add(LG_R_HIP_POS, legsum<LEGS>(h * h)); }                           // go2_ee.py:152-159
+        if (RON(LG_R_KEEP_BALANCE)) add(LG_R_KEEP_BALANCE, 1.f);                                                                 // :601-603
+        if (RON(LG_R_LIN_VEL_Z)) { const float z = bc<2>(blv); add(LG_R_LIN_VEL_Z, z * z); }                                     // :458-460
+        if (RON(LG_R_NO_FLY)) add(LG_R_NO_FLY, legsum<LEGS>(fz > 0.1f ? 1.f : 0.f) == 1.f ? 1.f : 0.f);                         // tron1_pf.py:151-154
+        if (RON(LG_R_ORIENTATION)) { const float x = bc<0>(pg), y = bc<1>(pg); add(LG_R_ORIENTATION, x * x + y * y); }           // :466-468
+        if (RON(LG_R_TORQUES)) add(LG_R_TORQUES, jsum(torque * torque));                                                         // :478-480
+        if (RON(LG_R_TRACKING_ANG_VEL)) { const float d = cmd2 - bc<2>(bav); add(LG_R_TRACKING_ANG_VEL, __expf(-(d * d) / HOT(tracking_sigma))); }   // :539-543
+        if (RON(LG_R_TRACKING_LIN_VEL)) {                                                                                        // :533-537
+            const float dx = cmd0 - bc<0>(blv), dy = cmd1 - bc<1>(blv);
+            add(LG_R_TRACKING_LIN_VEL, __expf(-(dx * dx + dy * dy) / HOT(tracking_sigma)));
+        }
+        if (HOT(only_positive_rewards)) total = fmaxf(total, 0.f);                                                               // :161-162
+        if (RON(LG_R_TERMINATION)) add(LG_R_TERMINATION, (reset && !time_out) ? 1.f : 0.f);                                      // :163-168
+
+        // ---- reset_idx (legged_robot.py:94-148, go2.py:17-37, 119-134) + simulator.reset_idx (genesis_simulator.py:62-82) ----
+        if (anyl(reset)) {
+            // env-level uniforms: block 0x200 + leg in the lanes of quad `leg` (all four blocks in one pass), then the element
+            // each lane needs is fetched from the quad that holds it: v0 = (cmd u0 u1 u2 | friction), v1 = (CoM xyz | mass),
+            // v2 = root linear velocity, v3 = root angular velocity (slots of env_step_body's eu[])
+            const U4 rb = philox(0x80000000u + 0x200u + (unsigned)leg);
+            const float rc = u01(pick(rb, L.c));
+            const float v0 = fetch(rc, L.c), v1 = fetch(rc, 4 + L.c), v2 = fetch(rc, 8 + L.c), v3 = fetch(rc, 12 + L.c);
+            const float ncmd = resample(cmdv, bc<0>(v0), bc<1>(v0), bc<2>(v0));
+            const U4 rd = philox(0x40000000u + (unsigned)(HOT(slots.reset_dof) + d0));      // _reset_dofs: one block per leg
+            const float ud = u01(pick(rd, cj));
+            float kp_new = 1.f, kd_new = 1.f;
+            const bool pd = HOT(dr_pd_on) != 0;
+            if (pd) {                                                                       // genesis_simulator.py:735-739
+                const U4 ra = philox(0x40000000u + (unsigned)(HOT(slots.dr_kp) + d0)), rb2 = philox(0x40000000u + (unsigned)(HOT(slots.dr_kd) + d0));
+                kp_new = HOT(dr_kp_span) * u01(pick(ra, cj)) + HOT(dr_kp_lo);
+                kd_new = HOT(dr_kd_span) * u01(pick(rb2, cj)) + HOT(dr_kd_lo);
+            }
+            const float ipos = L.sel(HOT(o_base_init_pos[0]), HOT(o_base_init_pos[1]), HOT(o_base_init_pos[2])) + origin;
+            const float iq = L.is3 ? HOT(base_init_quat[3]) : L.sel(HOT(base_init_quat[0]), HOT(base_init_quat[1]), HOT(base_init_quat[2]));
+            const bool rv = HOT(reset_lin_vel_span) != 0.f || HOT(reset_ang_vel_span) != 0.f;   // go2.py:131-133 draws U(0,0): constant
+            const float nvw = rv ? HOT(reset_lin_vel_span) * v2 + HOT(reset_lin_vel_lo) : HOT(reset_lin_vel_lo);
+            const float nww = rv ? HOT(reset_ang_vel_span) * v3 + HOT(reset_ang_vel_lo) : HOT(reset_ang_vel_lo);
+            if (reset) {
+                cmdv = ncmd;
+                q = q0 + (m_rsp * ud + m_rlo); qd = 0.f;
+                act = 0.f; last_act = 0.f; llast_act = 0.f;
+                pos = ipos; quat = iq; vw = nvw; ww = nww;
+                air = 0.f; ep_len = 0; failb = 0;
+            }
+            // the reference stores the commanded reset twist verbatim in the body-frame properties (genesis_simulator.py:128-129)
+            // and refreshes projected gravity (:125)
+            const QM Rr = quat_rows(L, quat);
+            const float npg = -L.sel(bc<2>(Rr.c0), bc<2>(Rr.c1), bc<2>(Rr.c2));
+            if (reset) { blv = vw; bav = ww; pg = npg; }
+            if (reset && st) {
+                B.dof_pos[ja] = q; B.dof_vel[ja] = 0.f; B.last_dof_vel[ja] = 0.f;
+                B.actions[ja] = 0.f; B.last_actions[ja] = 0.f; B.llast_actions[ja] = 0.f;
+                B.last_feet_vel[(e * F + foot_slot) * 3 + cj] = 0.f;
+                if (pd) { B.kp_scale[ja] = kp_new; B.kd_scale[ja] = kd_new; }
+                if (leg == 0) {
+                    B.base_pos[3 * e + cj] = pos; B.base_lin_vel_w[3 * e + cj] = vw; B.base_ang_vel_w[3 * e + cj] = ww;
+                    B.base_lin_vel[3 * e + cj] = blv; B.base_ang_vel[3 * e + cj] = bav; B.projected_gravity[3 * e + cj] = pg;
+                    B.last_base_lin_vel[3 * e + cj] = 0.f; B.last_base_ang_vel[3 * e + cj] = 0.f;
+                    if (HOT(dr_com_on)) B.base_com_bias[3 * e + cj] = L.sel(HOT(dr_com_span[0]), HOT(dr_com_span[1]), HOT(dr_com_span[2])) * v1 +
+                                                                       L.sel(HOT(dr_com_lo[0]), HOT(dr_com_lo[1]), HOT(dr_com_lo[2]));
+                }
+            }
+            if (reset && live && leg == 0) {
+                B.base_quat[4 * e + L.c] = quat;
+                if (L.is3) {   // the lane holding the fourth element of blocks 0 / 1: friction and mass draws
+                    if (HOT(dr_friction_on)) B.friction_values[e] = HOT(dr_friction_span) * v0 + HOT(dr_friction_lo);
+                    if (HOT(dr_mass_on)) B.added_base_mass[e] = HOT(dr_mass_span) * v1 + HOT(dr_mass_lo);
+                    B.episode_done_step[e] = (int)p.counter;
+                }
+            }
+            if (reset && live) {    // extras["episode"] snapshot (legged_robot.py:128-132), then the sums restart
+                if ((rmask >> ei) & 1u) { B.episode_done_sums[(size_t)ei * N + e] = es0; es0 = 0.f; }
+                if (ei + 16 < LG_R_COUNT && ((rmask >> (ei + 16)) & 1u)) { B.episode_done_sums[(size_t)(ei + 16) * N + e] = es1; es1 = 0.f; }
+            }
+        }
+        // ---- compute_observations + clip (go2.py:40-64, legged_robot.py:48-49) ----
+        {
+            const float co = HOT(clip_obs);
+            const bool nz = HOT(add_noise) != 0;
+            float uq = 0.5f, uqd = 0.5f, ug = 0.5f, ua = 0.5f;
+            if (nz) {
+                // blocks 2 leg and 2 leg + 1 of env_step_body in lanes 0 and 1 of the quad, side by side: (x, y, z) = the three joints'
+                // uniforms (positions / velocities), w = one of the base's six
+                const U4 rn = philox(0x80000000u + (unsigned)(2 * leg) + (L.is1 ? 1u : 0u));
+                const float ux = u01(rn.x), uy = u01(rn.y), uz = u01(rn.z), uw = u01(rn.w);
+                uq = L.sel(bc<0>(ux), bc<0>(uy), bc<0>(uz));
+                uqd = L.sel(bc<1>(ux), bc<1>(uy), bc<1>(uz));
+                // base uniform k sits in quad k / 2, lane k % 2: gravity component c takes k = c, angular velocity k = 3 + c
+                ug = fetch(uw, 4 * (cj >> 1) + (cj & 1));
+                ua = fetch(uw, 4 * ((3 + cj) >> 1) + ((3 + cj) & 1));
+            }
+            float *o = B.obs_buf + ((size_t)(HOT(obs_sets) > 1 ? p.obs_set : 0) * N + e) * (size_t)(9 + 3 * A);
+            auto noisy = [&](float v, float u, float ns) { if (nz) v += (2.f * u - 1.f) * ns; return clampf(v, -co, co); };
+            if (st) {
+                o[9 + d0 + cj] = noisy((q - q0) * HOT(obs_scale_dof_pos), uq, m_nq);
+                o[9 + A + d0 + cj] = noisy(qd * HOT(obs_scale_dof_vel), uqd, m_nqd);
+                o[9 + 2 * A + d0 + cj] = clampf(act, -co, co);
+                if (leg == 0) {
+                    const float cs_ = L.is2 ? HOT(obs_scale_ang_vel) : HOT(obs_scale_lin_vel);
+                    o[cj] = clampf(cmdv * cs_, -co, co);
+                    o[3 + cj] = noisy(pg, ug, L.sel(HOT(noise_lead[0]), HOT(noise_lead[1]), HOT(noise_lead[2])));
+                    o[6 + cj] = noisy(bav * HOT(obs_scale_ang_vel), ua, L.sel(HOT(noise_lead[3]), HOT(noise_lead[4]), HOT(noise_lead[5])));
+                }
+            }
+        }
+        // ---- persistent MDP state ----
+        if (live) {
+            if ((rmask >> ei) & 1u) B.episode_sums[(size_t)ei * N + e] = es0;
+            if (ei + 16 < LG_R_COUNT && ((rmask >> (ei + 16)) & 1u)) B.episode_sums[(size_t)(ei + 16) * N + e] = es1;
+            if (L.is0) { B.feet_air_time[e * F + foot_slot] = air; B.last_contacts[e * F + foot_slot] = (uint8_t)last_contact; }
+            if (leg == 0) {
+                B.commands[4 * e + L.c] = cmdv;
+                if (L.is0) {
+                    B.episode_length_buf[e] = ep_len; B.fail_buf[e] = (long long)failb;
+                    B.reset_buf[e] = reset ? 1 : 0; B.time_out_buf[e] = time_out ? 1 : 0; B.rew_buf[e] = total;
+                }
+            }
+        }
+    }
+    // ---------------- MDP phases in the same launch (every other task): leg-per-lane body on the first 16 lanes -----
+    if (MPH != 0 && !QTAIL) {
         // hand the results to the MDP phases through LDS (layout: lg_kernel.hip, XA .. XFB): leg-lane l of the tail is quad l
         // of this wave; a quad lane writes its own component.  Nothing the tail reads then comes from the arrays stored
         // above, so those stores drain in the background instead of being waited for.

@@ -60,25 +60,29 @@ def test_deterministic_and_shard_invariant():
         assert torch.equal(obs, a[t][0][128:]) and torch.equal(rew, a[t][1][128:]) and torch.equal(done, a[t][2][128:])
 
 
-@pytest.mark.parametrize("task", ["go2", "go2_wtw", "go2_ee"])
+@pytest.mark.parametrize("task", ["go2", "go2-push", "go2_wtw", "go2_ee"])
 def test_fused_launch_equals_split_launches(task):
     """Same state in, one control step through (a) the fused launch -- the instantiation bench.py times,
     quad_sim_kernel<4, true, POST|RESET> with the MDP phases in its tail -- and (b) SIM, then PRE|POST|RESET in
     env_step_kernel<4, PRE|POST|RESET>, the very instantiation the golden replays of tests/test_gpu_mdp.py go through:
     identical integers, floats to 1e-5 (the template instantiations may contract FMAs differently; contact dynamics
     would amplify that over many steps, so states are re-synced every step).  Every quadruped task that uses the fused
-    tail is covered: go2 (45-wide frame), go2_wtw (gait state, 5-frame stacks, PD-gain DR), go2_ee (heightfield
-    sampling handed over through measured_heights, 20 / 5-frame stacks, labels)."""
+    tail is covered: go2 (45-wide frame; its fused launch is the FLAT instantiation whose MDP phases run in component
+    layout on all 64 lanes, lg_quad.h), go2_wtw (gait state, 5-frame stacks, PD-gain DR), go2_ee (heightfield sampling handed
+    over through measured_heights, 20 / 5-frame stacks, labels)."""
     import torch
     from hcr_genesis_lr_cl_amd import abi
     from hcr_genesis_lr_cl_amd.envs import make_env
     N = 256
+    start = 480                                                      # crosses the push step (500) for go2_ee
+    if task == "go2-push":                                           # go2 again, larger, across its push step (750)
+        task, N, start = "go2", 1024, 735
     e1, e2 = make_env(task, N, "cuda:0")[0], make_env(task, N, "cuda:0")[0]
     e1.reset(); e2.reset()
     g = torch.Generator(device="cuda"); g.manual_seed(5)
     # spread the episode clocks so that time-outs, command and behaviour resampling fall inside the window
     e1.episode_length_buf[:] = torch.randint(0, 1000, (N,), generator=g, device="cuda", dtype=torch.int32)
-    e1.common_step_counter = e2.common_step_counter = 480          # crosses the push step (500 / 750) for go2_ee
+    e1.common_step_counter = e2.common_step_counter = start
     loose = {"obs_buf": 2e-4, "priv_obs_buf": 2e-4, "labels_buf": 2e-4, "dof_vel": 2e-3, "last_dof_vel": 2e-3, "feet_vel": 2e-3,
              "last_feet_vel": 2e-3, "base_lin_vel": 2e-4, "base_ang_vel": 1e-3, "base_lin_vel_w": 2e-4, "base_ang_vel_w": 1e-3,
              "torques": 2e-3, "link_contact_forces": 0.05, "last_base_lin_vel": 2e-4, "last_base_ang_vel": 1e-3}
