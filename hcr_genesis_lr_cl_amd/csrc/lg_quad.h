@@ -76,6 +76,50 @@ struct Lane {
 
 LG_DEV float dot3(float a, float b) { return sum3(a * b); }
 LG_DEV float cross(float a, float b) { return rot1(a * rot1(b) - rot1(a) * b); }
+// The quad broadcast of an operand rides ON the multiply-add (v_mul_f32_dpp / v_fmac_f32_dpp with quad_perm:[k,k,k,k] on src0).
+// LLVM folds a DPP mov into v_mul / v_add but not into v_fmac, leaving one v_mov_b32_dpp per multiply-add (~20 % of the physics
+// loop's issue slots); these helpers spell the sequences out.  One `s_nop 1` in front of a group covers the DPP read-after-VALU-
+// write hazard of every source in it (2 wait states; the hazard recogniser does not look inside inline asm); inside a group
+// the DPP sources are never written.  LG_NO_DPP_ASM selects the plain C++ forms (same arithmetic, same order).
+#ifndef LG_NO_DPP_ASM
+#define LG_QP0 "quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf"
+#define LG_QP1 "quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf"
+#define LG_QP2 "quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
+// r = m0 * v[0] + m1 * v[1] + m2 * v[2]   (v: component layout, broadcast inside the quad)
+LG_DEV float dpp_mac3(float m0, float m1, float m2, float v) {
+    float r;
+    asm("s_nop 1\n\tv_mul_f32_dpp %0, %4, %1 " LG_QP0 "\n\tv_fmac_f32_dpp %0, %4, %2 " LG_QP1 "\n\tv_fmac_f32_dpp %0, %4, %3 " LG_QP2
+        : "=&v"(r) : "v"(m0), "v"(m1), "v"(m2), "v"(v));
+    return r;
+}
+// r += m0 * v[0] + m1 * v[1] + m2 * v[2]
+LG_DEV float dpp_mac3_acc(float r, float m0, float m1, float m2, float v) {
+    asm("s_nop 1\n\tv_fmac_f32_dpp %0, %4, %1 " LG_QP0 "\n\tv_fmac_f32_dpp %0, %4, %2 " LG_QP1 "\n\tv_fmac_f32_dpp %0, %4, %3 " LG_QP2
+        : "+v"(r) : "v"(m0), "v"(m1), "v"(m2), "v"(v));
+    return r;
+}
+// r = m0 * a[K] + m1 * b[K] + m2 * c[K]   (one fixed lane K of three different vectors: rows of a transposed operand)
+template <int K> LG_DEV float dpp_mac3t(float m0, float m1, float m2, float a, float b, float c) {
+    float r;
+    if (K == 0) asm("s_nop 1\n\tv_mul_f32_dpp %0, %4, %1 " LG_QP0 "\n\tv_fmac_f32_dpp %0, %5, %2 " LG_QP0 "\n\tv_fmac_f32_dpp %0, %6, %3 " LG_QP0
+                    : "=&v"(r) : "v"(m0), "v"(m1), "v"(m2), "v"(a), "v"(b), "v"(c));
+    else if (K == 1) asm("s_nop 1\n\tv_mul_f32_dpp %0, %4, %1 " LG_QP1 "\n\tv_fmac_f32_dpp %0, %5, %2 " LG_QP1 "\n\tv_fmac_f32_dpp %0, %6, %3 " LG_QP1
+                         : "=&v"(r) : "v"(m0), "v"(m1), "v"(m2), "v"(a), "v"(b), "v"(c));
+    else asm("s_nop 1\n\tv_mul_f32_dpp %0, %4, %1 " LG_QP2 "\n\tv_fmac_f32_dpp %0, %5, %2 " LG_QP2 "\n\tv_fmac_f32_dpp %0, %6, %3 " LG_QP2
+             : "=&v"(r) : "v"(m0), "v"(m1), "v"(m2), "v"(a), "v"(b), "v"(c));
+    return r;
+}
+LG_DEV float mulv(const QM &m, float v) { return dpp_mac3(m.c0, m.c1, m.c2, v); }
+LG_DEV QM mulmm(const QM &a, const QM &b) {     // a b
+    QM r = {dpp_mac3(a.c0, a.c1, a.c2, b.c0), dpp_mac3(a.c0, a.c1, a.c2, b.c1), dpp_mac3(a.c0, a.c1, a.c2, b.c2)};
+    return r;
+}
+LG_DEV QM mulmmt(const QM &a, const QM &b) {    // a b^T
+    QM r = {dpp_mac3t<0>(a.c0, a.c1, a.c2, b.c0, b.c1, b.c2), dpp_mac3t<1>(a.c0, a.c1, a.c2, b.c0, b.c1, b.c2),
+            dpp_mac3t<2>(a.c0, a.c1, a.c2, b.c0, b.c1, b.c2)};
+    return r;
+}
+#else
 LG_DEV float mulv(const QM &m, float v) { return m.c0 * bc<0>(v) + m.c1 * bc<1>(v) + m.c2 * bc<2>(v); }
 LG_DEV QM mulmm(const QM &a, const QM &b) {     // a b
     QM r;
@@ -91,6 +135,7 @@ LG_DEV QM mulmmt(const QM &a, const QM &b) {    // a b^T
     r.c2 = a.c0 * bc<2>(b.c0) + a.c1 * bc<2>(b.c1) + a.c2 * bc<2>(b.c2);
     return r;
 }
+#endif
 LG_DEV float multv(const Lane &L, const QM &m, float v) {   // m^T v
     return L.sel(sum3(m.c0 * v), sum3(m.c1 * v), sum3(m.c2 * v));
 }
@@ -121,11 +166,18 @@ LG_DEV QV6 operator-(const QV6 &a, const QV6 &b) { QV6 r = {a.a - b.a, a.l - b.l
 LG_DEV QV6 operator*(const QV6 &a, float s) { QV6 r = {a.a * s, a.l * s}; return r; }
 LG_DEV float dot6(const QV6 &a, const QV6 &b) { return sum3(a.a * b.a + a.l * b.l); }
 LG_DEV QV6 muli6(const QI6 &I, const QV6 &v) {
+#ifndef LG_NO_DPP_ASM
+    QV6 r;
+    r.a = dpp_mac3_acc(dpp_mac3(I.A.c0, I.A.c1, I.A.c2, v.a), I.B.c0, I.B.c1, I.B.c2, v.l);
+    r.l = dpp_mac3_acc(dpp_mac3(I.Bt.c0, I.Bt.c1, I.Bt.c2, v.a), I.C.c0, I.C.c1, I.C.c2, v.l);
+    return r;
+#else
     const float a0 = bc<0>(v.a), a1 = bc<1>(v.a), a2 = bc<2>(v.a), l0 = bc<0>(v.l), l1 = bc<1>(v.l), l2 = bc<2>(v.l);
     QV6 r;
     r.a = I.A.c0 * a0 + I.A.c1 * a1 + I.A.c2 * a2 + I.B.c0 * l0 + I.B.c1 * l1 + I.B.c2 * l2;
     r.l = I.Bt.c0 * a0 + I.Bt.c1 * a1 + I.Bt.c2 * a2 + I.C.c0 * l0 + I.C.c1 * l1 + I.C.c2 * l2;
     return r;
+#endif
 }
 LG_DEV QI6 operator+(const QI6 &a, const QI6 &b) { QI6 r = {a.A + b.A, a.B + b.B, a.Bt + b.Bt, a.C + b.C}; return r; }
 // I - U U^T dinv
@@ -979,12 +1031,83 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     // different lanes (a call is ~800 cycles of quarter-rate multiplies whatever the number of lanes using it).  The random
     // stream is the one of env_step_body (same counters), so both instantiations produce the same rollout.
     if constexpr (QTAIL) {
-        const float cdt = HOT(control_dt);
+        STAMP(5);
+        // hot constants of the MDP phases in ONE burst of LDS reads (a read at the point of use costs an exposed LDS round trip each:
+        // one wave per SIMD, every reward term in its own basic block)
+        const auto h_about_landing_threshold = HOT(about_landing_threshold);
+        const auto h_add_noise = HOT(add_noise);
+        const auto h_base_height_target = HOT(base_height_target);
+        const auto h_base_init_quat_0 = HOT(base_init_quat[0]);
+        const auto h_base_init_quat_1 = HOT(base_init_quat[1]);
+        const auto h_base_init_quat_2 = HOT(base_init_quat[2]);
+        const auto h_base_init_quat_3 = HOT(base_init_quat[3]);
+        const auto h_clip_obs = HOT(clip_obs);
+        const auto h_control_dt = HOT(control_dt);
+        const auto h_dr_com_lo_0 = HOT(dr_com_lo[0]);
+        const auto h_dr_com_lo_1 = HOT(dr_com_lo[1]);
+        const auto h_dr_com_lo_2 = HOT(dr_com_lo[2]);
+        const auto h_dr_com_on = HOT(dr_com_on);
+        const auto h_dr_com_span_0 = HOT(dr_com_span[0]);
+        const auto h_dr_com_span_1 = HOT(dr_com_span[1]);
+        const auto h_dr_com_span_2 = HOT(dr_com_span[2]);
+        const auto h_dr_friction_lo = HOT(dr_friction_lo);
+        const auto h_dr_friction_on = HOT(dr_friction_on);
+        const auto h_dr_friction_span = HOT(dr_friction_span);
+        const auto h_dr_kd_lo = HOT(dr_kd_lo);
+        const auto h_dr_kd_span = HOT(dr_kd_span);
+        const auto h_dr_kp_lo = HOT(dr_kp_lo);
+        const auto h_dr_kp_span = HOT(dr_kp_span);
+        const auto h_dr_mass_lo = HOT(dr_mass_lo);
+        const auto h_dr_mass_on = HOT(dr_mass_on);
+        const auto h_dr_mass_span = HOT(dr_mass_span);
+        const auto h_dr_pd_on = HOT(dr_pd_on);
+        const auto h_env_id_offset = HOT(env_id_offset);
+        const auto h_fail_threshold = HOT(fail_threshold);
+        const auto h_feet_air_time_threshold = HOT(feet_air_time_threshold);
+        const auto h_foot_clearance_sigma = HOT(foot_clearance_sigma);
+        const auto h_foot_clearance_target = HOT(foot_clearance_target);
+        const auto h_foot_height_offset = HOT(foot_height_offset);
+        const auto h_heading_command = HOT(heading_command);
+        const auto h_max_episode_length = HOT(max_episode_length);
+        const auto h_max_projected_gravity = HOT(max_projected_gravity);
+        const auto h_max_push_vel_xy = HOT(max_push_vel_xy);
+        const auto h_noise_lead_0 = HOT(noise_lead[0]);
+        const auto h_noise_lead_1 = HOT(noise_lead[1]);
+        const auto h_noise_lead_2 = HOT(noise_lead[2]);
+        const auto h_noise_lead_3 = HOT(noise_lead[3]);
+        const auto h_noise_lead_4 = HOT(noise_lead[4]);
+        const auto h_noise_lead_5 = HOT(noise_lead[5]);
+        const auto h_o_base_init_pos_0 = HOT(o_base_init_pos[0]);
+        const auto h_o_base_init_pos_1 = HOT(o_base_init_pos[1]);
+        const auto h_o_base_init_pos_2 = HOT(o_base_init_pos[2]);
+        const auto h_obs_scale_ang_vel = HOT(obs_scale_ang_vel);
+        const auto h_obs_scale_dof_pos = HOT(obs_scale_dof_pos);
+        const auto h_obs_scale_dof_vel = HOT(obs_scale_dof_vel);
+        const auto h_obs_scale_lin_vel = HOT(obs_scale_lin_vel);
+        const auto h_obs_sets = HOT(obs_sets);
+        const auto h_only_positive_rewards = HOT(only_positive_rewards);
+        const auto h_push_interval = HOT(push_interval);
+        const auto h_resample_steps = HOT(resample_steps);
+        const auto h_reset_ang_vel_lo = HOT(reset_ang_vel_lo);
+        const auto h_reset_ang_vel_span = HOT(reset_ang_vel_span);
+        const auto h_reset_lin_vel_lo = HOT(reset_lin_vel_lo);
+        const auto h_reset_lin_vel_span = HOT(reset_lin_vel_span);
+        const auto h_seed = HOT(seed);
+        const auto h_slots_cb_cmd = HOT(slots.cb_cmd);
+        const auto h_slots_dr_kd = HOT(slots.dr_kd);
+        const auto h_slots_dr_kp = HOT(slots.dr_kp);
+        const auto h_slots_push = HOT(slots.push);
+        const auto h_slots_reset_dof = HOT(slots.reset_dof);
+        const auto h_tracking_sigma = HOT(tracking_sigma);
+        const auto h_yaw_clip_0 = HOT(yaw_clip[0]);
+        const auto h_yaw_clip_1 = HOT(yaw_clip[1]);
+        asm volatile("" ::: "memory");
+        const float cdt = h_control_dt;
         const unsigned rmask = (unsigned)p.k.reward_mask;
-        const bool heading = HOT(heading_command) != 0;
+        const bool heading = h_heading_command != 0;
         unsigned k0, k1, e_lo, e_hi;
         {
-            const unsigned long long seed = HOT(seed), gid = (unsigned long long)(HOT(env_id_offset) + e);
+            const unsigned long long seed = h_seed, gid = (unsigned long long)(h_env_id_offset + e);
             k0 = (unsigned)(seed & 0xFFFFFFFFu); k1 = (unsigned)(seed >> 32);
             e_lo = (unsigned)(gid & 0xFFFFFFFFu); e_hi = (unsigned)(gid >> 32);
         }
@@ -1010,9 +1133,9 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         };
         // ---- _post_physics_step_callback (legged_robot.py:300-315) ----
         {
-            const bool need = (ep_len % HOT(resample_steps)) == 0;
+            const bool need = (ep_len % h_resample_steps) == 0;
             if (anyl(need)) {
-                const U4 r = philox(0x40000000u + (unsigned)HOT(slots.cb_cmd));
+                const U4 r = philox(0x40000000u + (unsigned)h_slots_cb_cmd);
                 const float nc = resample(cmdv, u01(r.x), u01(r.y), u01(r.z));
                 cmdv = need ? nc : cmdv;
             }
@@ -1021,15 +1144,15 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const float ty = 2.f * qz, tz = -2.f * qy;
             const float fx = 1.f + (qy * tz - qz * ty), fy = ty * qw + (0.f - qx * tz);
             const float hd = atan2f(fy, fx);
-            const float c2 = clampf(0.5f * wrap_to_pi(bc<3>(cmdv) - hd), HOT(yaw_clip[0]), HOT(yaw_clip[1]));
+            const float c2 = clampf(0.5f * wrap_to_pi(bc<3>(cmdv) - hd), h_yaw_clip_0, h_yaw_clip_1);
             cmdv = L.is2 ? c2 : cmdv;
         }
         {
-            const int pi_ = HOT(push_interval);
+            const int pi_ = h_push_interval;
             if (pi_ > 0 && (p.counter % pi_) == 0) {   // genesis_simulator.py:150-158; lanes 0 / 1 evaluate the two draws' blocks side by side
-                const int slot = HOT(slots.push) + (L.is1 ? 1 : 0);
+                const int slot = h_slots_push + (L.is1 ? 1 : 0);
                 const U4 r = philox((unsigned)(slot >> 2));
-                const float m = HOT(max_push_vel_xy);
+                const float m = h_max_push_vel_xy;
                 const float pv = (m + m) * u01(pick(r, slot & 3)) - m;
                 const bool xy = L.c < 2;
                 vw = xy ? vw + pv : vw;
@@ -1037,6 +1160,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             }
         }
         const float cmd0 = bc<0>(cmdv), cmd1 = bc<1>(cmdv), cmd2 = bc<2>(cmdv);
+        STAMP(6);
         // ---- check_termination (legged_robot.py:78-92) ----
         const unsigned tmask = M->term_link_mask, pmask = M->pen_link_mask;
         const int l0 = foot_link - 3;
@@ -1051,10 +1175,10 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         fail = __builtin_amdgcn_update_dpp(0, fail, 0x124, 0xF, 0xF, true) | fail;
         fail = __builtin_amdgcn_update_dpp(0, fail, 0x128, 0xF, 0xF, true) | fail;
         fail |= ((tmask & 1u) && nb2 > 100.0f) ? 1 : 0;
-        fail |= pgz > HOT(max_projected_gravity) ? 1 : 0;
+        fail |= pgz > h_max_projected_gravity ? 1 : 0;
         failb += fail;
-        const bool time_out = (float)ep_len > HOT(max_episode_length);
-        const bool reset = ((float)failb > HOT(fail_threshold)) || time_out;
+        const bool time_out = (float)ep_len > h_max_episode_length;
+        const bool reset = ((float)failb > h_fail_threshold) || time_out;
 
         // ---- compute_reward (legged_robot.py:150-168): every term replicated over the env's lanes, summed in alphabetical order ----
         float scl[LG_R_COUNT];
@@ -1075,7 +1199,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         if (RON(LG_R_ACTION_RATE)) { const float d = last_act - act; add(LG_R_ACTION_RATE, jsum(d * d)); }                     // :495-497
         if (RON(LG_R_ACTION_SMOOTHNESS)) { const float d = act - 2.f * last_act + llast_act; add(LG_R_ACTION_SMOOTHNESS, jsum(d * d)); }   // :499-503
         if (RON(LG_R_ANG_VEL_XY)) { const float bx = bc<0>(bav), by = bc<1>(bav); add(LG_R_ANG_VEL_XY, bx * bx + by * by); }    // :462-464
-        if (RON(LG_R_BASE_HEIGHT)) { const float d = bc<2>(pos) - HOT(base_height_target); add(LG_R_BASE_HEIGHT, d * d); }     // :470-476 (plane)
+        if (RON(LG_R_BASE_HEIGHT)) { const float d = bc<2>(pos) - h_base_height_target; add(LG_R_BASE_HEIGHT, d * d); }     // :470-476 (plane)
         if (RON(LG_R_COLLISION)) {                                                                                               // :505-512
             float sc_ = 0.f;
 #pragma unroll
@@ -1097,7 +1221,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             last_contact = contact;
             const float first = (air > 0.f ? 1.f : 0.f) * (float)filt;
             air += cdt;
-            float r = legsum<LEGS>((air - HOT(feet_air_time_threshold)) * first);
+            float r = legsum<LEGS>((air - h_feet_air_time_threshold) * first);
             r *= cmd_xy > 0.1f ? 1.f : 0.f;
             air *= filt ? 0.f : 1.f;
             add(LG_R_FEET_AIR_TIME, r);
@@ -1109,11 +1233,11 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         if (RON(LG_R_FOOT_ACC)) { const float a = (foot_v - last_foot_v) * (1.f / cdt); add(LG_R_FOOT_ACC, legsum<LEGS>(vnorm2(a))); }    // :605-608
         if (RON(LG_R_FOOT_CLEARANCE)) {                                                                                          // :575-588
             const float vxy = sqrtf(fvx * fvx + fvy * fvy);
-            const float d = fpz - 0.f - HOT(foot_clearance_target) - HOT(foot_height_offset);
-            add(LG_R_FOOT_CLEARANCE, __expf(-legsum<LEGS>(vxy * (d * d)) / HOT(foot_clearance_sigma)));
+            const float d = fpz - 0.f - h_foot_clearance_target - h_foot_height_offset;
+            add(LG_R_FOOT_CLEARANCE, __expf(-legsum<LEGS>(vxy * (d * d)) / h_foot_clearance_sigma));
         }
         if (RON(LG_R_FOOT_LANDING_VEL)) {                                                                                        // :590-599
-            const bool land = ((fpz - HOT(foot_height_offset)) < HOT(about_landing_threshold)) && !(fz > 0.1f) && (fvz < 0.f);
+            const bool land = ((fpz - h_foot_height_offset) < h_about_landing_threshold) && !(fz > 0.1f) && (fvz < 0.f);
             const float vz = land ? fvz : 0.f;
             add(LG_R_FOOT_LANDING_VEL, legsum<LEGS>(vz * vz));
         }
@@ -1123,14 +1247,15 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         if (RON(LG_R_NO_FLY)) add(LG_R_NO_FLY, legsum<LEGS>(fz > 0.1f ? 1.f : 0.f) == 1.f ? 1.f : 0.f);                         // tron1_pf.py:151-154
         if (RON(LG_R_ORIENTATION)) { const float x = bc<0>(pg), y = bc<1>(pg); add(LG_R_ORIENTATION, x * x + y * y); }           // :466-468
         if (RON(LG_R_TORQUES)) add(LG_R_TORQUES, jsum(torque * torque));                                                         // :478-480
-        if (RON(LG_R_TRACKING_ANG_VEL)) { const float d = cmd2 - bc<2>(bav); add(LG_R_TRACKING_ANG_VEL, __expf(-(d * d) / HOT(tracking_sigma))); }   // :539-543
+        if (RON(LG_R_TRACKING_ANG_VEL)) { const float d = cmd2 - bc<2>(bav); add(LG_R_TRACKING_ANG_VEL, __expf(-(d * d) / h_tracking_sigma)); }   // :539-543
         if (RON(LG_R_TRACKING_LIN_VEL)) {                                                                                        // :533-537
             const float dx = cmd0 - bc<0>(blv), dy = cmd1 - bc<1>(blv);
-            add(LG_R_TRACKING_LIN_VEL, __expf(-(dx * dx + dy * dy) / HOT(tracking_sigma)));
+            add(LG_R_TRACKING_LIN_VEL, __expf(-(dx * dx + dy * dy) / h_tracking_sigma));
         }
-        if (HOT(only_positive_rewards)) total = fmaxf(total, 0.f);                                                               // :161-162
+        if (h_only_positive_rewards) total = fmaxf(total, 0.f);                                                               // :161-162
         if (RON(LG_R_TERMINATION)) add(LG_R_TERMINATION, (reset && !time_out) ? 1.f : 0.f);                                      // :163-168
 
+        STAMP(7);
         // ---- reset_idx (legged_robot.py:94-148, go2.py:17-37, 119-134) + simulator.reset_idx (genesis_simulator.py:62-82) ----
         if (anyl(reset)) {
             // env-level uniforms: block 0x200 + leg in the lanes of quad `leg` (all four blocks in one pass), then the element
@@ -1140,20 +1265,20 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const float rc = u01(pick(rb, L.c));
             const float v0 = fetch(rc, L.c), v1 = fetch(rc, 4 + L.c), v2 = fetch(rc, 8 + L.c), v3 = fetch(rc, 12 + L.c);
             const float ncmd = resample(cmdv, bc<0>(v0), bc<1>(v0), bc<2>(v0));
-            const U4 rd = philox(0x40000000u + (unsigned)(HOT(slots.reset_dof) + d0));      // _reset_dofs: one block per leg
+            const U4 rd = philox(0x40000000u + (unsigned)(h_slots_reset_dof + d0));      // _reset_dofs: one block per leg
             const float ud = u01(pick(rd, cj));
             float kp_new = 1.f, kd_new = 1.f;
-            const bool pd = HOT(dr_pd_on) != 0;
+            const bool pd = h_dr_pd_on != 0;
             if (pd) {                                                                       // genesis_simulator.py:735-739
-                const U4 ra = philox(0x40000000u + (unsigned)(HOT(slots.dr_kp) + d0)), rb2 = philox(0x40000000u + (unsigned)(HOT(slots.dr_kd) + d0));
-                kp_new = HOT(dr_kp_span) * u01(pick(ra, cj)) + HOT(dr_kp_lo);
-                kd_new = HOT(dr_kd_span) * u01(pick(rb2, cj)) + HOT(dr_kd_lo);
+                const U4 ra = philox(0x40000000u + (unsigned)(h_slots_dr_kp + d0)), rb2 = philox(0x40000000u + (unsigned)(h_slots_dr_kd + d0));
+                kp_new = h_dr_kp_span * u01(pick(ra, cj)) + h_dr_kp_lo;
+                kd_new = h_dr_kd_span * u01(pick(rb2, cj)) + h_dr_kd_lo;
             }
-            const float ipos = L.sel(HOT(o_base_init_pos[0]), HOT(o_base_init_pos[1]), HOT(o_base_init_pos[2])) + origin;
-            const float iq = L.is3 ? HOT(base_init_quat[3]) : L.sel(HOT(base_init_quat[0]), HOT(base_init_quat[1]), HOT(base_init_quat[2]));
-            const bool rv = HOT(reset_lin_vel_span) != 0.f || HOT(reset_ang_vel_span) != 0.f;   // go2.py:131-133 draws U(0,0): constant
-            const float nvw = rv ? HOT(reset_lin_vel_span) * v2 + HOT(reset_lin_vel_lo) : HOT(reset_lin_vel_lo);
-            const float nww = rv ? HOT(reset_ang_vel_span) * v3 + HOT(reset_ang_vel_lo) : HOT(reset_ang_vel_lo);
+            const float ipos = L.sel(h_o_base_init_pos_0, h_o_base_init_pos_1, h_o_base_init_pos_2) + origin;
+            const float iq = L.is3 ? h_base_init_quat_3 : L.sel(h_base_init_quat_0, h_base_init_quat_1, h_base_init_quat_2);
+            const bool rv = h_reset_lin_vel_span != 0.f || h_reset_ang_vel_span != 0.f;   // go2.py:131-133 draws U(0,0): constant
+            const float nvw = rv ? h_reset_lin_vel_span * v2 + h_reset_lin_vel_lo : h_reset_lin_vel_lo;
+            const float nww = rv ? h_reset_ang_vel_span * v3 + h_reset_ang_vel_lo : h_reset_ang_vel_lo;
             if (reset) {
                 cmdv = ncmd;
                 q = q0 + (m_rsp * ud + m_rlo); qd = 0.f;
@@ -1175,15 +1300,15 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                     B.base_pos[3 * e + cj] = pos; B.base_lin_vel_w[3 * e + cj] = vw; B.base_ang_vel_w[3 * e + cj] = ww;
                     B.base_lin_vel[3 * e + cj] = blv; B.base_ang_vel[3 * e + cj] = bav; B.projected_gravity[3 * e + cj] = pg;
                     B.last_base_lin_vel[3 * e + cj] = 0.f; B.last_base_ang_vel[3 * e + cj] = 0.f;
-                    if (HOT(dr_com_on)) B.base_com_bias[3 * e + cj] = L.sel(HOT(dr_com_span[0]), HOT(dr_com_span[1]), HOT(dr_com_span[2])) * v1 +
-                                                                       L.sel(HOT(dr_com_lo[0]), HOT(dr_com_lo[1]), HOT(dr_com_lo[2]));
+                    if (h_dr_com_on) B.base_com_bias[3 * e + cj] = L.sel(h_dr_com_span_0, h_dr_com_span_1, h_dr_com_span_2) * v1 +
+                                                                       L.sel(h_dr_com_lo_0, h_dr_com_lo_1, h_dr_com_lo_2);
                 }
             }
             if (reset && live && leg == 0) {
                 B.base_quat[4 * e + L.c] = quat;
                 if (L.is3) {   // the lane holding the fourth element of blocks 0 / 1: friction and mass draws
-                    if (HOT(dr_friction_on)) B.friction_values[e] = HOT(dr_friction_span) * v0 + HOT(dr_friction_lo);
-                    if (HOT(dr_mass_on)) B.added_base_mass[e] = HOT(dr_mass_span) * v1 + HOT(dr_mass_lo);
+                    if (h_dr_friction_on) B.friction_values[e] = h_dr_friction_span * v0 + h_dr_friction_lo;
+                    if (h_dr_mass_on) B.added_base_mass[e] = h_dr_mass_span * v1 + h_dr_mass_lo;
                     B.episode_done_step[e] = (int)p.counter;
                 }
             }
@@ -1192,10 +1317,11 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 if (ei + 16 < LG_R_COUNT && ((rmask >> (ei + 16)) & 1u)) { B.episode_done_sums[(size_t)(ei + 16) * N + e] = es1; es1 = 0.f; }
             }
         }
+        STAMP(9);
         // ---- compute_observations + clip (go2.py:40-64, legged_robot.py:48-49) ----
         {
-            const float co = HOT(clip_obs);
-            const bool nz = HOT(add_noise) != 0;
+            const float co = h_clip_obs;
+            const bool nz = h_add_noise != 0;
             float uq = 0.5f, uqd = 0.5f, ug = 0.5f, ua = 0.5f;
             if (nz) {
                 // blocks 2 leg and 2 leg + 1 of env_step_body in lanes 0 and 1 of the quad, side by side: (x, y, z) = the three joints'
@@ -1208,20 +1334,21 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 ug = fetch(uw, 4 * (cj >> 1) + (cj & 1));
                 ua = fetch(uw, 4 * ((3 + cj) >> 1) + ((3 + cj) & 1));
             }
-            float *o = B.obs_buf + ((size_t)(HOT(obs_sets) > 1 ? p.obs_set : 0) * N + e) * (size_t)(9 + 3 * A);
+            float *o = B.obs_buf + ((size_t)(h_obs_sets > 1 ? p.obs_set : 0) * N + e) * (size_t)(9 + 3 * A);
             auto noisy = [&](float v, float u, float ns) { if (nz) v += (2.f * u - 1.f) * ns; return clampf(v, -co, co); };
             if (st) {
-                o[9 + d0 + cj] = noisy((q - q0) * HOT(obs_scale_dof_pos), uq, m_nq);
-                o[9 + A + d0 + cj] = noisy(qd * HOT(obs_scale_dof_vel), uqd, m_nqd);
+                o[9 + d0 + cj] = noisy((q - q0) * h_obs_scale_dof_pos, uq, m_nq);
+                o[9 + A + d0 + cj] = noisy(qd * h_obs_scale_dof_vel, uqd, m_nqd);
                 o[9 + 2 * A + d0 + cj] = clampf(act, -co, co);
                 if (leg == 0) {
-                    const float cs_ = L.is2 ? HOT(obs_scale_ang_vel) : HOT(obs_scale_lin_vel);
+                    const float cs_ = L.is2 ? h_obs_scale_ang_vel : h_obs_scale_lin_vel;
                     o[cj] = clampf(cmdv * cs_, -co, co);
-                    o[3 + cj] = noisy(pg, ug, L.sel(HOT(noise_lead[0]), HOT(noise_lead[1]), HOT(noise_lead[2])));
-                    o[6 + cj] = noisy(bav * HOT(obs_scale_ang_vel), ua, L.sel(HOT(noise_lead[3]), HOT(noise_lead[4]), HOT(noise_lead[5])));
+                    o[3 + cj] = noisy(pg, ug, L.sel(h_noise_lead_0, h_noise_lead_1, h_noise_lead_2));
+                    o[6 + cj] = noisy(bav * h_obs_scale_ang_vel, ua, L.sel(h_noise_lead_3, h_noise_lead_4, h_noise_lead_5));
                 }
             }
         }
+        STAMP(10);
         // ---- persistent MDP state ----
         if (live) {
             if ((rmask >> ei) & 1u) B.episode_sums[(size_t)ei * N + e] = es0;
@@ -1235,6 +1362,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 }
             }
         }
+        STAMP(11);
     }
     // ---------------- MDP phases in the same launch (every other task): leg-per-lane body on the first 16 lanes -----
     if (MPH != 0 && !QTAIL) {

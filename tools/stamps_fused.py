@@ -16,8 +16,8 @@ for i in range(800):
         torch.cuda.synchronize()
         acc += env._engine.buf["episode_done_sums"].flatten()[:32].cpu(); n += 1
 acc /= n
-order = [(23, "quad: load burst + LDS staging"), (24, "quad: lane constants"), (12, "quad: rest of prologue"), (21, "4 sub-steps (to read-back)"), (22, "read-back + stores"), (2, "mdp: fence + prologue"), (5, "mdp: state from HBM/LDS"),
-         (6, "mdp: callback"), (7, "mdp: rewards"), (8, "mdp: post end"), (9, "mdp: reset blk"), (10, "mdp: obs"), (11, "mdp: end")]
+order = [(23, "quad: load burst + LDS staging"), (24, "quad: lane constants"), (12, "quad: rest of prologue"), (21, "4 sub-steps (to read-back)"), (22, "read-back + stores"),
+         (5, "mdp: start"), (6, "mdp: callback"), (7, "mdp: termination + rewards"), (9, "mdp: reset blk"), (10, "mdp: obs"), (11, "mdp: state stores")]
 prev = 0.0
 for k, name in order:
     print(f"{name:30s} +{acc[k]-prev:8.0f} cycles (cum {acc[k]:8.0f})")
