@@ -817,7 +817,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 const V3 r = P + mul(R, sp.p);
                 const float rad = sp.r;
                 float h; V3 n;
-                terrain_at(O, p.hf, pos.x + r.x, pos.y + r.y, h, n);
+                if (FLAT) { h = 0.f; n = v3(0.f, 0.f, 1.f); } else terrain_at(O, p.hf, pos.x + r.x, pos.y + r.y, h, n);
                 const float depth = rad - (pos.z + r.z - h) * n.z;
                 if (depth > -margin) {
                     const V3 v = V.l + cross(V.a, r);
@@ -941,7 +941,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             {
                 const V3 r = K[2].P + mul(K[2].R, foot_c_loc);
                 float h;
-                terrain_at(O, p.hf, pos.x + r.x, pos.y + r.y, h, cn);
+                if (FLAT) { h = 0.f; cn = v3(0.f, 0.f, 1.f); } else terrain_at(O, p.hf, pos.x + r.x, pos.y + r.y, h, cn);
                 depth = foot_r - (pos.z + r.z - h) * cn.z;
                 fact = depth > -margin;
                 cp = r - cn * foot_r;
@@ -2239,11 +2239,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     STAMP(11);
 }
 
-template <int LEGS, unsigned PH>
+template <int LEGS, unsigned PH, bool FLAT = false>
 __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_STG * BLOCK];
     __shared__ int sHot[256 + BLOCK];
-    env_step_body<LEGS, PH, false>(p, sMraw, sHot, nullptr, nullptr, blockIdx.x * BLOCK + threadIdx.x, threadIdx.x & 63);
+    env_step_body<LEGS, PH, false, FLAT>(p, sMraw, sHot, nullptr, nullptr, blockIdx.x * BLOCK + threadIdx.x, threadIdx.x & 63);
 }
 
 #include "lg_quad.h"
@@ -2513,7 +2513,10 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
     }
     const int pi = (ph & LG_PHASE_SIM) ? prof_begin(h, st) : -1;
     switch (ph) {
-    case LG_PHASE_ALL: LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_ALL>), grid); break;
+    case LG_PHASE_ALL:
+        if (flat_profile(h)) LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_ALL, true>), grid);     // large go2 batches: same FLAT constants
+        else LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_ALL>), grid);
+        break;
     case LG_PHASE_SIM: LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_SIM>), grid); break;
     case LG_PHASE_PRE | LG_PHASE_POST | LG_PHASE_RESET:
         hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_PRE | LG_PHASE_POST | LG_PHASE_RESET>), grid, block, 0, st, p); break;
