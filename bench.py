@@ -315,6 +315,9 @@ def main():
     ap.add_argument("--ppo-rollout", type=int, default=0, metavar="ITERS",
                     help="also time ITERS rollouts of 24 steps with the go2 actor/critic MLPs (45-512-256-128-12 / -1, ELU) "
                          "run between the steps (SURVEY 8d ii); reported under 'ppo_rollout', never as 'value'")
+    ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"],
+                    help="process-group backend at N > 1: nccl (= RCCL over xGMI, one GPU per rank; the measurement) or gloo (ranks may "
+                         "share a GPU: rehearsal of the N > 1 path on a one-GPU box, never a reported number)")
     ap.add_argument("--launcher-dry-run", action="store_true",
                     help="rank plumbing only (spawn, rendezvous, gather, max-over-ranks timing, one JSON line) on the CPU with the "
                          "gloo backend and a stand-in for the env step: the world-2 test of this file's N > 1 path")
@@ -333,13 +336,17 @@ def main():
 
     import torch
     dist = None
+    dev_index = local_rank % max(torch.cuda.device_count(), 1) if args.backend == "gloo" else local_rank
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        torch.cuda.set_device(local_rank)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local_rank}"))
+        torch.cuda.set_device(dev_index)
+        if args.backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{dev_index}"))
+        else:
+            dist.init_process_group("gloo")
     n_gpus = world
-    dev = f"cuda:{local_rank}"
+    dev = f"cuda:{dev_index}"
     torch.cuda.set_device(dev)
 
     from hcr_genesis_lr_cl_amd.envs import make_env
@@ -411,7 +418,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{WORKLOADS[args.task]}, {n_local} envs per GPU, fused LeggedRobot.step "
                                    f"(4 sub-steps dt=0.005) with synthetic N(0,1) actions",
-                       "envs_total": total_envs, "parallelism": f"env-shard x{world}" + ((" + all-gather(obs,rew,done) per step" + ("" if args.sync_gather else ", overlapped with the next step")) if world > 1 and not args.no_gather else "")},
+                       "envs_total": total_envs, "parallelism": f"env-shard x{world}" + (" [gloo rehearsal, ranks may share a GPU]" if world > 1 and args.backend == "gloo" else "") + ((" + all-gather(obs,rew,done) per step" + ("" if args.sync_gather else ", overlapped with the next step")) if world > 1 and not args.no_gather else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": hbm_traffic(wkey),
                          "kernel": layout, "launch_us": launch_s * 1e6, "samples": kern_n,

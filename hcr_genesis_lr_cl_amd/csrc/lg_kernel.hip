@@ -1001,7 +1001,10 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                             const float ftn = sqrtf(fsol.y * fsol.y + fsol.z * fsol.z);
                             if (ftn > mu * fsol.x) {
                                 const float iftn = rcp(ftn), e1 = fsol.y * iftn, e2 = fsol.z * iftn;
-                                const float fn = rn * rcp(1.f + kappa * (Ac.xx + mu * (Ac.xy * e1 + Ac.xz * e2)));
+                                // friction coupling limited to 3/4 of A_nn: frictional jamming otherwise lets f_n = rn / (1 + kappa a_eff) grow
+                                // without bound (a_eff -> 0 for large mu on a stretched leg; see oracle/lg_oracle.c)
+                                const float aeff = fmaxf(Ac.xx + mu * (Ac.xy * e1 + Ac.xz * e2), 0.25f * Ac.xx);
+                                const float fn = rn * rcp(1.f + kappa * aeff);
                                 fsol = fn > 0.f ? v3(fn, mu * fn * e1, mu * fn * e2) : v3(0, 0, 0);
                             }
                             fnew = fsol;

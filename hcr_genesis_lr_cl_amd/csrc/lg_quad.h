@@ -823,7 +823,9 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                     const float A00 = bc<0>(Ac.c0), A01 = bc<0>(Ac.c1), A02 = bc<0>(Ac.c2);   // DPP stays outside the branch
                     const float ft2 = f1 * f1 + f2 * f2, iftn = rsqrtf(ft2), ftn = ft2 * iftn;
                     const float e1 = f1 * iftn, e2 = f2 * iftn;
-                    const float fn = rn * rcp(1.f + kappa * (A00 + mu * (A01 * e1 + A02 * e2)));
+                    // friction coupling limited to 3/4 of A_nn (frictional jamming; see lg_kernel.hip / oracle/lg_oracle.c)
+                    const float aeff = fmaxf(A00 + mu * (A01 * e1 + A02 * e2), 0.25f * A00);
+                    const float fn = rn * rcp(1.f + kappa * aeff);
                     if (ftn > mu * f0) { ok = ok && fn > 0.f; f0 = fn; f1 = mu * fn * e1; f2 = mu * fn * e2; }
                     fc = ok ? L.sel(f0, f1, f2) : 0.f;
                 }

@@ -558,7 +558,13 @@ static void env_step(const LgModelDesc *m, const LgSimOptions *o, const int16_t 
                     real ftn = sqrt(fsol[1] * fsol[1] + fsol[2] * fsol[2]);
                     if (ftn > mu * fsol[0]) {
                         real e1 = fsol[1] / ftn, e2 = fsol[2] / ftn;
-                        real fn = (kc * dep[l] - kappa * vo[0]) / (1 + kappa * (A[0] + mu * (A[1] * e1 + A[2] * e2)));
+                        /* sliding: v_n,end = vo_n + a_eff f_n with a_eff = A_nn + mu (A_n1 e1 + A_n2 e2).  For mu large and a stretched leg
+                         * the friction coupling can cancel A_nn (frictional jamming, Painleve): a_eff -> 0 or below and the penalty
+                         * law's f_n = rn / (1 + kappa a_eff) grows without bound (observed: 39 kN on a foot, robot thrown 100 m).
+                         * The coupling is therefore limited to three quarters of A_nn. */
+                        real aeff = A[0] + mu * (A[1] * e1 + A[2] * e2);
+                        if (aeff < (real)0.25 * A[0]) aeff = (real)0.25 * A[0];
+                        real fn = (kc * dep[l] - kappa * vo[0]) / (1 + kappa * aeff);
                         if (fn <= 0) continue;
                         fsol[0] = fn; fsol[1] = mu * fn * e1; fsol[2] = mu * fn * e2;
                     }

@@ -379,3 +379,42 @@ def test_checkpoint_resume_is_bit_exact(task, tmp_path):
     assert {k: list(v) for k, v in env2.command_ranges.items()} == {k: list(v) for k, v in ranges.items()}
     with pytest.raises(ValueError):
         make_env("go2" if task != "go2" else "go2_wtw", N, "cuda:0")[0].load_checkpoint(path)
+
+
+# ---- BASELINE.json configs at their full sizes: size-independent properties (determinism, shard invariance) ----
+FULL = [("go2", 4096, 4096, 0), ("go2_ee", 4096, 4096, 0), ("go2_wtw", 4096, 8192, 4096), ("tron1_pf_ee", 4096, 32768, 28672)]
+
+
+@pytest.mark.parametrize("task,n_local,n_global,offset", FULL, ids=[f"{t}-{g}" for t, _, g, _ in FULL])
+def test_baseline_config_full_size_properties(task, n_local, n_global, offset):
+    """configs[1..4] of BASELINE.json at 4096 envs per GPU: 40 control steps of N(0,1) actions stay finite and inside the physical
+    envelope; resets happen; a second construction reproduces the rollout bit for bit.  For the sharded configs (go2_wtw 8192 over 2
+    GPUs, tron1_pf_ee 32768 over 8) the rank owning the LAST block of the global env range is run: its terrain columns, initial
+    terrain levels and random streams are keyed on the global index."""
+    import torch
+    from hcr_genesis_lr_cl_amd.envs import make_env
+
+    def run():
+        env, cfg = make_env(task, n_local, "cuda:0", env_id_offset=offset, global_num_envs=n_global)
+        env.reset()
+        g = torch.Generator(device="cuda"); g.manual_seed(11)
+        env.episode_length_buf = torch.randint(0, 1000, (n_local,), generator=g, device="cuda", dtype=torch.int32)
+        n_reset, outs = 0, None
+        for t in range(40):
+            out = env.step(torch.randn(n_local, env.num_actions, generator=g, device="cuda"))
+            n_reset += int(out[-2].sum())
+        torch.cuda.synchronize()
+        outs = [o.clone() for o in out[:-1] if torch.is_tensor(o)]
+        s = env.simulator
+        assert all(torch.isfinite(o.float()).all() for o in outs)
+        rel = s.base_pos[:, 2] - s.env_origins[:, 2]              # height above the env's own tile centre (slopes / stairs: a few metres)
+        assert float(rel.max()) < 6.0 and float(rel.min()) > -6.0, (float(rel.min()), float(rel.max()))
+        assert float(s.dof_vel.abs().max()) < 70.0
+        assert n_reset > n_local // 50
+        if cfg.terrain.mesh_type == "heightfield":
+            tt = s.terrain_types.long()
+            gid = torch.arange(n_local, device="cuda") + offset
+            assert torch.equal(tt, torch.div(gid, n_global / cfg.terrain.num_cols, rounding_mode="floor").long())
+        return outs
+    a, b = run(), run()
+    assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))

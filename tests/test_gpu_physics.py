@@ -199,3 +199,26 @@ def test_other_sweep_counts_match_oracle(go2, layout, iters):
         np.testing.assert_allclose(got[k], st.arr[k].reshape(256, -1), atol=TOL[k], rtol=1e-4, err_msg=k)
     err = np.abs(got["link_contact_forces"] - st.arr["link_contact_forces"].reshape(256, -1))
     assert np.all(err <= 0.3 + 0.01 * np.abs(st.arr["link_contact_forces"].reshape(256, -1))), err.max()
+
+
+@pytest.mark.parametrize("task", ["go2_ee", "tron1_pf_ee"])
+def test_no_robot_is_thrown_by_the_contact_solver(task):
+    """Regression (round 2): with friction ratios up to 1.7 the sliding branch of the foot contact could jam -- friction coupling
+    cancelling the normal compliance, f_n = rn / (1 + kappa a_eff) with a_eff -> 0 -- and throw a robot (39 kN on one foot, 47 m/s,
+    110 m high; 0.025 % of env-steps of a random go2_ee rollout, reproduced by the f64 CPU oracle on the same state).  The coupling
+    is now limited to 3/4 of A_nn in both kernels and the oracle.  Same seeds as the rollout that showed it at step 3."""
+    import torch
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    n = 4096
+    env, cfg = make_env(task, n)
+    env.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    env.episode_length_buf = torch.randint(0, 1000, (n,), generator=g, device="cuda", dtype=torch.int32)
+    s = env.simulator
+    worst_v = worst_h = worst_f = 0.0
+    for t in range(120):
+        env.step(torch.randn(n, env.num_actions, generator=g, device="cuda"))
+        worst_v = max(worst_v, float(s._base_lin_vel_w[:, 2].abs().max()))
+        worst_h = max(worst_h, float((s.base_pos[:, 2] - s.env_origins[:, 2]).max()))
+        worst_f = max(worst_f, float(s.link_contact_forces.norm(dim=-1).max()))
+    assert worst_v < 6.0 and worst_h < 3.0 and worst_f < 6000.0, (worst_v, worst_h, worst_f)
