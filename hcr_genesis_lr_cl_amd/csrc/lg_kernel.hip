@@ -2424,7 +2424,7 @@ static bool flat_profile(const LgEngine *h) {
            t.priv_stack <= 1 && t.num_priv_obs == 0 && t.terrain_curriculum == 0 && t.custom_origins == 0 && t.sit_percent == 0.f &&
            t.behavior_resample_steps == 0 && t.num_labels == 0 && t.cat_enable == 0 && t.noise_vec[9 + 6 * h->model.n_legs] == 0.f &&
            o.n_height_points == 0 && o.terrain_rows == 0 && o.feet_terrain_info == 0 && !b.link_contact_states && !b.task_state && !h->hf &&
-           !b.rand_in && !b.joint_armature && !t.dr_joint_on && flat_noise_ok(h) &&
+           !b.rand_in && !b.joint_armature && !t.dr_joint_on && !t.dr_pd_on && t.reset_lin_vel_span == 0.f && t.reset_ang_vel_span == 0.f && flat_noise_ok(h) &&
            // reward terms the component-layout tail (lg_quad.h) does not carry: gait clocks, biped and wtw-only terms
            ((unsigned)h->hot.reward_mask & ((1u << LG_R_BIPED_PERIODIC_GAIT) | (1u << LG_R_QUAD_PERIODIC_GAIT) | (1u << LG_R_FEET_DISTANCE) |
                                             (1u << LG_R_TRACKING_BASE_HEIGHT) | (1u << LG_R_TRACKING_FOOT_CLEARANCE) |

@@ -1055,14 +1055,9 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         const auto h_dr_friction_lo = HOT(dr_friction_lo);
         const auto h_dr_friction_on = HOT(dr_friction_on);
         const auto h_dr_friction_span = HOT(dr_friction_span);
-        const auto h_dr_kd_lo = HOT(dr_kd_lo);
-        const auto h_dr_kd_span = HOT(dr_kd_span);
-        const auto h_dr_kp_lo = HOT(dr_kp_lo);
-        const auto h_dr_kp_span = HOT(dr_kp_span);
         const auto h_dr_mass_lo = HOT(dr_mass_lo);
         const auto h_dr_mass_on = HOT(dr_mass_on);
         const auto h_dr_mass_span = HOT(dr_mass_span);
-        const auto h_dr_pd_on = HOT(dr_pd_on);
         const auto h_env_id_offset = HOT(env_id_offset);
         const auto h_fail_threshold = HOT(fail_threshold);
         const auto h_feet_air_time_threshold = HOT(feet_air_time_threshold);
@@ -1091,13 +1086,9 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         const auto h_push_interval = HOT(push_interval);
         const auto h_resample_steps = HOT(resample_steps);
         const auto h_reset_ang_vel_lo = HOT(reset_ang_vel_lo);
-        const auto h_reset_ang_vel_span = HOT(reset_ang_vel_span);
         const auto h_reset_lin_vel_lo = HOT(reset_lin_vel_lo);
-        const auto h_reset_lin_vel_span = HOT(reset_lin_vel_span);
         const auto h_seed = HOT(seed);
         const auto h_slots_cb_cmd = HOT(slots.cb_cmd);
-        const auto h_slots_dr_kd = HOT(slots.dr_kd);
-        const auto h_slots_dr_kp = HOT(slots.dr_kp);
         const auto h_slots_push = HOT(slots.push);
         const auto h_slots_reset_dof = HOT(slots.reset_dof);
         const auto h_tracking_sigma = HOT(tracking_sigma);
@@ -1261,26 +1252,17 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         // ---- reset_idx (legged_robot.py:94-148, go2.py:17-37, 119-134) + simulator.reset_idx (genesis_simulator.py:62-82) ----
         if (anyl(reset)) {
             // env-level uniforms: block 0x200 + leg in the lanes of quad `leg` (all four blocks in one pass), then the element
-            // each lane needs is fetched from the quad that holds it: v0 = (cmd u0 u1 u2 | friction), v1 = (CoM xyz | mass),
-            // v2 = root linear velocity, v3 = root angular velocity (slots of env_step_body's eu[])
+            // each lane needs is fetched from the quad that holds it: v0 = (cmd u0 u1 u2 | friction), v1 = (CoM xyz | mass)
+            // (slots of env_step_body's eu[]; the root twist draws are not needed: flat_profile demands zero spans)
             const U4 rb = philox(0x80000000u + 0x200u + (unsigned)leg);
             const float rc = u01(pick(rb, L.c));
-            const float v0 = fetch(rc, L.c), v1 = fetch(rc, 4 + L.c), v2 = fetch(rc, 8 + L.c), v3 = fetch(rc, 12 + L.c);
+            const float v0 = fetch(rc, L.c), v1 = fetch(rc, 4 + L.c);
             const float ncmd = resample(cmdv, bc<0>(v0), bc<1>(v0), bc<2>(v0));
             const U4 rd = philox(0x40000000u + (unsigned)(h_slots_reset_dof + d0));      // _reset_dofs: one block per leg
             const float ud = u01(pick(rd, cj));
-            float kp_new = 1.f, kd_new = 1.f;
-            const bool pd = h_dr_pd_on != 0;
-            if (pd) {                                                                       // genesis_simulator.py:735-739
-                const U4 ra = philox(0x40000000u + (unsigned)(h_slots_dr_kp + d0)), rb2 = philox(0x40000000u + (unsigned)(h_slots_dr_kd + d0));
-                kp_new = h_dr_kp_span * u01(pick(ra, cj)) + h_dr_kp_lo;
-                kd_new = h_dr_kd_span * u01(pick(rb2, cj)) + h_dr_kd_lo;
-            }
             const float ipos = L.sel(h_o_base_init_pos_0, h_o_base_init_pos_1, h_o_base_init_pos_2) + origin;
             const float iq = L.is3 ? h_base_init_quat_3 : L.sel(h_base_init_quat_0, h_base_init_quat_1, h_base_init_quat_2);
-            const bool rv = h_reset_lin_vel_span != 0.f || h_reset_ang_vel_span != 0.f;   // go2.py:131-133 draws U(0,0): constant
-            const float nvw = rv ? h_reset_lin_vel_span * v2 + h_reset_lin_vel_lo : h_reset_lin_vel_lo;
-            const float nww = rv ? h_reset_ang_vel_span * v3 + h_reset_ang_vel_lo : h_reset_ang_vel_lo;
+            const float nvw = h_reset_lin_vel_lo, nww = h_reset_ang_vel_lo;      // go2.py:131-133 draws U(0, 0) (flat_profile: zero spans)
             if (reset) {
                 cmdv = ncmd;
                 q = q0 + (m_rsp * ud + m_rlo); qd = 0.f;
@@ -1297,7 +1279,6 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 B.dof_pos[ja] = q; B.dof_vel[ja] = 0.f; B.last_dof_vel[ja] = 0.f;
                 B.actions[ja] = 0.f; B.last_actions[ja] = 0.f; B.llast_actions[ja] = 0.f;
                 B.last_feet_vel[(e * F + foot_slot) * 3 + cj] = 0.f;
-                if (pd) { B.kp_scale[ja] = kp_new; B.kd_scale[ja] = kd_new; }
                 if (leg == 0) {
                     B.base_pos[3 * e + cj] = pos; B.base_lin_vel_w[3 * e + cj] = vw; B.base_ang_vel_w[3 * e + cj] = ww;
                     B.base_lin_vel[3 * e + cj] = blv; B.base_ang_vel[3 * e + cj] = bav; B.projected_gravity[3 * e + cj] = pg;

@@ -60,7 +60,22 @@ def test_deterministic_and_shard_invariant():
         assert torch.equal(obs, a[t][0][128:]) and torch.equal(rew, a[t][1][128:]) and torch.equal(done, a[t][2][128:])
 
 
-@pytest.mark.parametrize("task", ["go2", "go2-push", "go2_wtw", "go2_ee"])
+def _go2_all_terms_cfg():
+    """go2 on the plane with EVERY reward term the component-layout tail implements switched on (the stock config uses 15 of them),
+    the termination term and yaw-rate (non-heading) commands: still inside flat_profile, so the fused launch runs the FLAT tail."""
+    from hcr_genesis_lr_cl_amd.config import GO2Cfg
+    cfg = GO2Cfg()
+    sc = cfg.rewards.scales
+    for name, v in (("dof_close_to_default", -0.02), ("dof_pos_stand_still", -0.5), ("dof_power", -2e-4), ("dof_vel_stand_still", -0.1),
+                    ("feet_contact_stand_still", 0.5), ("foot_acc", -1e-5), ("foot_landing_vel", -0.1), ("hip_pos", -0.05),
+                    ("keep_balance", 0.3), ("no_fly", 0.2), ("termination", -1.0)):
+        setattr(sc, name, v)
+    cfg.rewards.about_landing_threshold = 0.05
+    cfg.rewards.only_positive_rewards = False
+    return cfg
+
+
+@pytest.mark.parametrize("task", ["go2", "go2-push", "go2-allterms", "go2-yawcmd", "go2_wtw", "go2_ee"])
 def test_fused_launch_equals_split_launches(task):
     """Same state in, one control step through (a) the fused launch -- the instantiation bench.py times,
     quad_sim_kernel<4, true, POST|RESET> with the MDP phases in its tail -- and (b) SIM, then PRE|POST|RESET in
@@ -77,7 +92,20 @@ def test_fused_launch_equals_split_launches(task):
     start = 480                                                      # crosses the push step (500) for go2_ee
     if task == "go2-push":                                           # go2 again, larger, across its push step (750)
         task, N, start = "go2", 1024, 735
-    e1, e2 = make_env(task, N, "cuda:0")[0], make_env(task, N, "cuda:0")[0]
+    if task in ("go2-allterms", "go2-yawcmd"):
+        from hcr_genesis_lr_cl_amd.envs import GO2, set_seed
+
+        def mk():
+            cfg = _go2_all_terms_cfg()
+            cfg.env.num_envs = N
+            if task == "go2-yawcmd":
+                cfg.commands.heading_command = False
+            set_seed(1)
+            return GO2(cfg, None, "cuda:0", True)
+        e1, e2 = mk(), mk()
+        assert len(e1.reward_scales) >= 26
+    else:
+        e1, e2 = make_env(task, N, "cuda:0")[0], make_env(task, N, "cuda:0")[0]
     e1.reset(); e2.reset()
     g = torch.Generator(device="cuda"); g.manual_seed(5)
     # spread the episode clocks so that time-outs, command and behaviour resampling fall inside the window
