@@ -487,8 +487,11 @@ enum { XA = 0, XLA = 3, XLLA = 6, XQ = 9, XQD = 12, XLQD = 15, XTQ = 18, XFL = 2
 // FLAT: the launch is known (host-checked, `flat_profile`) to be the plain go2-on-a-plane task -- one unstacked 45-wide
 // observation, no privileged output, no gait clock, no terrain, no task extras: those switches become compile-time constants
 // and every other task's code drops out of the instantiation (fewer scalar registers, a shorter tail).
-template <int LEGS, unsigned PH, bool FUSED, bool FLAT = false>
+// PROF 2 (host-checked, `wtw_profile`): the go2_wtw task on the plane -- gait clock and 5-frame stacks stay, terrain and the other
+// tasks' packaging drop out.
+template <int LEGS, unsigned PH, bool FUSED, int PROF = 0>
 LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF, const float *sX, const int vtid, const int vlane) {
+    constexpr bool FLAT = PROF == 1, WTWP = PROF == 2, PLANE = FLAT || WTWP, EEP = PROF == 3, PRGP = PROF == 4, ROUGHQ = EEP || PRGP;
     constexpr bool DO_PRE = (PH & LG_PHASE_PRE) != 0, DO_SIM = (PH & LG_PHASE_SIM) != 0;
     constexpr bool DO_POST = (PH & LG_PHASE_POST) != 0, DO_RESET = (PH & LG_PHASE_RESET) != 0;
     constexpr int A = LEGS * 3;
@@ -611,7 +614,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             rdof_lo[j] = T->reset_dof_lo[d0 + j]; rdof_span[j] = T->reset_dof_span[d0 + j];
             nv_q[j] = T->noise_vec[9 + d0 + j]; nv_qd[j] = T->noise_vec[9 + A + d0 + j]; nv_act[j] = T->noise_vec[9 + 2 * A + d0 + j];
         }
-        if (!FLAT && p.k.obs_layout == LG_OBS_TRON1_EE) { nv_clk[0] = T->noise_vec[9 + 3 * A + foot_slot]; nv_clk[1] = T->noise_vec[9 + 3 * A + LEGS + foot_slot]; }
+        if (!PLANE && !ROUGHQ && p.k.obs_layout == LG_OBS_TRON1_EE) { nv_clk[0] = T->noise_vec[9 + 3 * A + foot_slot]; nv_clk[1] = T->noise_vec[9 + 3 * A + LEGS + foot_slot]; }
         cmd0 = B.commands[4 * e]; cmd1 = B.commands[4 * e + 1]; cmd2 = B.commands[4 * e + 2]; cmd3 = B.commands[4 * e + 3];
         ep_len = B.episode_length_buf[e];
         fail_buf = B.fail_buf[e];
@@ -639,7 +642,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     float hts[HMAX];
 #pragma unroll
     for (int i = 0; i < HMAX; i++) hts[i] = 0.f;
-    const int P = FLAT ? 0 : p.k.o_n_height_points;
+    const int P = PLANE ? 0 : p.k.o_n_height_points;
     const bool hreg = P <= HMAX * LEGS;
     float foot_hmean = 0.f, foot_hmax = 0.f;  // mean / max of the 9 terrain heights around this lane's foot (a8)
     float mean_height = 0.f;         // mean over the height-sample grid of (base_z - h) is formed from this (a7)
@@ -817,7 +820,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 const V3 r = P + mul(R, sp.p);
                 const float rad = sp.r;
                 float h; V3 n;
-                if (FLAT) { h = 0.f; n = v3(0.f, 0.f, 1.f); } else terrain_at(O, p.hf, pos.x + r.x, pos.y + r.y, h, n);
+                if (PLANE) { h = 0.f; n = v3(0.f, 0.f, 1.f); } else terrain_at(O, p.hf, pos.x + r.x, pos.y + r.y, h, n);
                 const float depth = rad - (pos.z + r.z - h) * n.z;
                 if (depth > -margin) {
                     const V3 v = V.l + cross(V.a, r);
@@ -941,7 +944,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             {
                 const V3 r = K[2].P + mul(K[2].R, foot_c_loc);
                 float h;
-                if (FLAT) { h = 0.f; cn = v3(0.f, 0.f, 1.f); } else terrain_at(O, p.hf, pos.x + r.x, pos.y + r.y, h, cn);
+                if (PLANE) { h = 0.f; cn = v3(0.f, 0.f, 1.f); } else terrain_at(O, p.hf, pos.x + r.x, pos.y + r.y, h, cn);
                 depth = foot_r - (pos.z + r.z - h) * cn.z;
                 fact = depth > -margin;
                 cp = r - cn * foot_r;
@@ -1278,10 +1281,10 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     const auto hc_resample_steps = HOT(resample_steps);
     const auto hc_heading_command = HOT(heading_command);
     const auto hc_push_interval = HOT(push_interval);
-    const auto hc_obs_layout = FLAT ? (HOT_T(obs_layout))(LG_OBS_GO2) : HOT(obs_layout);
-    const auto hc_gait_mode = FLAT ? (HOT_T(gait_mode))(0) : HOT(gait_mode);
+    const auto hc_obs_layout = FLAT ? (HOT_T(obs_layout))(LG_OBS_GO2) : (WTWP ? (HOT_T(obs_layout))(LG_OBS_GO2_WTW) : (EEP ? (HOT_T(obs_layout))(LG_OBS_GO2_EE) : (PRGP ? (HOT_T(obs_layout))(LG_OBS_PROGRAM) : HOT(obs_layout))));
+    const auto hc_gait_mode = (FLAT || ROUGHQ) ? (HOT_T(gait_mode))(0) : (WTWP ? (HOT_T(gait_mode))(1) : HOT(gait_mode));
     const auto hc_add_noise = HOT(add_noise);
-    const auto hc_double_shift = FLAT ? (HOT_T(double_shift))(0) : HOT(double_shift);
+    const auto hc_double_shift = (FLAT || EEP) ? (HOT_T(double_shift))(0) : (WTWP ? (HOT_T(double_shift))(1) : HOT(double_shift));
     const auto hc_obs_frame = HOT(obs_frame);
     const auto hc_obs_stack = FLAT ? (HOT_T(obs_stack))(1) : HOT(obs_stack);
     const auto hc_obs_slack = FLAT ? (HOT_T(obs_slack))(0) : HOT(obs_slack);
@@ -1296,14 +1299,14 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     const auto hc_env_id_offset = HOT(env_id_offset);
     const auto hc_heights_offset = HOT(heights_offset);
     const auto hc_obs_scale_height = HOT(obs_scale_height);
-    const auto hc_noise_act0 = FLAT ? (HOT_T(noise_act0))(0) : HOT(noise_act0);
+    const auto hc_noise_act0 = (PLANE || ROUGHQ) ? (HOT_T(noise_act0))(0) : HOT(noise_act0);
     const auto hc_about_landing_threshold = HOT(about_landing_threshold);
-    const auto hc_terrain_curriculum = FLAT ? (HOT_T(terrain_curriculum))(0) : HOT(terrain_curriculum);
-    const auto hc_custom_origins = FLAT ? (HOT_T(custom_origins))(0) : HOT(custom_origins);
-    const auto hc_sit_percent = FLAT ? (HOT_T(sit_percent))(0) : HOT(sit_percent);
-    const auto hc_behavior_resample_steps = FLAT ? (HOT_T(behavior_resample_steps))(0) : HOT(behavior_resample_steps);
+    const auto hc_terrain_curriculum = PLANE ? (HOT_T(terrain_curriculum))(0) : HOT(terrain_curriculum);
+    const auto hc_custom_origins = PLANE ? (HOT_T(custom_origins))(0) : HOT(custom_origins);
+    const auto hc_sit_percent = (PLANE || ROUGHQ) ? (HOT_T(sit_percent))(0) : HOT(sit_percent);
+    const auto hc_behavior_resample_steps = (FLAT || ROUGHQ) ? (HOT_T(behavior_resample_steps))(0) : HOT(behavior_resample_steps);
     const auto hc_heights_clip_scale = HOT(heights_clip_scale);
-    const auto hc_num_labels = FLAT ? (HOT_T(num_labels))(0) : HOT(num_labels);
+    const auto hc_num_labels = PLANE ? (HOT_T(num_labels))(0) : HOT(num_labels);
     asm volatile("" ::: "memory");
     if (STASH || FUSED) {   // bring the MDP working set back from LDS (fused: prefetched by quad_sim_kernel's prologue)
         const int t = threadIdx.x;
@@ -1427,7 +1430,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         //      soft_p for a violated soft / style one (constraint_manager.py:25-74 with binary inputs), per-episode violation counts
         float cat_keep = 1.f;     // (1 - p), applied to the reward before the positive clip (go2_cat.py:219-223)
         float cstr_p = 0.f;
-        if (!FLAT && p.k.cat_enable) {
+        if (!PLANE && !EEP && p.k.cat_enable) {
             int c_tq = 0, c_qd = 0, c_ar = 0, lo_any = 0, hi_any = 0, c_fast = 0;
 #pragma unroll
             for (int j = 0; j < 3; j++) {
@@ -2242,11 +2245,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     STAMP(11);
 }
 
-template <int LEGS, unsigned PH, bool FLAT = false>
+template <int LEGS, unsigned PH, int PROF = 0>
 __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_STG * BLOCK];
     __shared__ int sHot[256 + BLOCK];
-    env_step_body<LEGS, PH, false, FLAT>(p, sMraw, sHot, nullptr, nullptr, blockIdx.x * BLOCK + threadIdx.x, threadIdx.x & 63);
+    env_step_body<LEGS, PH, false, PROF>(p, sMraw, sHot, nullptr, nullptr, blockIdx.x * BLOCK + threadIdx.x, threadIdx.x & 63);
 }
 
 #include "lg_quad.h"
@@ -2431,6 +2434,27 @@ static bool flat_profile(const LgEngine *h) {
                                             (1u << LG_R_TRACKING_ORIENTATION))) == 0;
 }
 
+// go2_wtw on the plane (PROF 2)
+static bool wtw_profile(const LgEngine *h) {
+    const LgTaskCfg &t = h->task;
+    const LgSimOptions &o = h->opts;
+    const LgBuffers &b = h->bufs;
+    return t.obs_layout == LG_OBS_GO2_WTW && t.gait_mode == 1 && t.double_shift == 1 && t.terrain_curriculum == 0 && t.custom_origins == 0 &&
+           t.sit_percent == 0.f && t.num_labels == 0 && t.cat_enable == 0 && t.noise_vec[9 + 6 * h->model.n_legs] == 0.f &&
+           o.n_height_points == 0 && o.terrain_rows == 0 && o.feet_terrain_info == 0 && !b.link_contact_states && !h->hf && b.task_state;
+}
+
+// the Go2-rough family (PROF 3: go2_ee packaging, PROF 4: observation programs -- go2_ts / go2_cts / go2_dreamwaq / go2_cat): no gait
+// clock, no sit pose, no noise on actions; terrain, curriculum, stacks and (PROF 4) CaT stay runtime
+static int rough_profile(const LgEngine *h) {
+    const LgTaskCfg &t = h->task;
+    if (t.gait_mode != 0 || t.sit_percent != 0.f || t.behavior_resample_steps != 0 || t.noise_vec[9 + 6 * h->model.n_legs] != 0.f || h->bufs.task_state)
+        return 0;
+    if (t.obs_layout == LG_OBS_GO2_EE && t.double_shift == 0 && t.cat_enable == 0) return 3;
+    if (t.obs_layout == LG_OBS_PROGRAM) return 4;
+    return 0;
+}
+
 template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *actions, int64_t counter, hipStream_t st) {
     KParams p;
     p.M = h->d_model; p.O = h->d_opts; p.T = h->d_task; p.H = h->d_hot; p.hf = h->hf; p.B = h->bufs; p.actions = actions; p.counter = counter;
@@ -2498,7 +2522,10 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
         // MDP phases: in the tail of the same launch for the quadruped (measured 39.5 vs 40.6 us for go2, 69.6 vs 72.5
         // for go2_ee), as a second launch for the biped (84.7 vs 90.6 us for tron1_pf_ee: 8 envs per wave there)
         const bool fuse = LEGS == 4 && pre && rest != 0;
-        if (fuse && rest == (LG_PHASE_POST | LG_PHASE_RESET) && flat_profile(h)) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET, true>), qgrid);
+        if (fuse && rest == (LG_PHASE_POST | LG_PHASE_RESET) && flat_profile(h)) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET, 1>), qgrid);
+        else if (fuse && rest == (LG_PHASE_POST | LG_PHASE_RESET) && wtw_profile(h)) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET, 2>), qgrid);
+        else if (fuse && rest == (LG_PHASE_POST | LG_PHASE_RESET) && rough_profile(h) == 3) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET, 3>), qgrid);
+        else if (fuse && rest == (LG_PHASE_POST | LG_PHASE_RESET) && rough_profile(h) == 4) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET, 4>), qgrid);
         else if (fuse && rest == (LG_PHASE_POST | LG_PHASE_RESET)) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET>), qgrid);
         else if (fuse && rest == LG_PHASE_POST) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST>), qgrid);
         else if (pre && rest) LG_LAUNCH_FIRST(pi, (quad_sim_kernel<LEGS, true, 0u>), qgrid);
@@ -2517,7 +2544,7 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
     const int pi = (ph & LG_PHASE_SIM) ? prof_begin(h, st) : -1;
     switch (ph) {
     case LG_PHASE_ALL:
-        if (flat_profile(h)) LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_ALL, true>), grid);     // large go2 batches: same FLAT constants
+        if (flat_profile(h)) LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_ALL, 1>), grid);     // large go2 batches: same FLAT constants
         else LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_ALL>), grid);
         break;
     case LG_PHASE_SIM: LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_SIM>), grid); break;

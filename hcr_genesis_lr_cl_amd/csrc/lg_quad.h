@@ -293,9 +293,10 @@ LG_DEV QV6 resp_down(const Lane &L, const QJoint (&J)[3], const QV6 &a0, const f
 // MPH: MDP phases (LG_PHASE_POST, LG_PHASE_POST | LG_PHASE_RESET or 0) run in the tail of the same launch by the first
 // 16 lanes of each wave, one per leg of the wave's envs, through env_step_body: one launch per control step, no second
 // ramp-up, tables already in LDS.  The hand-off goes through the state arrays themselves (written above, L2-hot).
-template <int LEGS, bool DO_PRE, unsigned MPH, bool FLAT = false>
+template <int LEGS, bool DO_PRE, unsigned MPH, int PROF = 0>
 __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     using namespace q4;
+    constexpr bool FLAT = PROF == 1, PLANE = PROF == 1 || PROF == 2;   // host-checked task profiles (lg_kernel.hip flat_profile / wtw_profile)
     constexpr int A = 3 * LEGS;
     // The kernel argument block (KParams, ~800 B of pointers) through ONE vector load: lane i holds bytes [16 i, 16 i + 16).
     // Fetched with scalar loads it arrives as a dozen dependent dwordx16 chunks (SGPR pressure), each a device-memory round
@@ -501,9 +502,9 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     const float mu = HOT(o_terrain_friction) * dr_fric;
     const float ascale = HOT(o_action_scale);
     Terr TR;
-    TR.rows = FLAT ? 0 : HOT(o_terrain_rows); TR.cols = HOT(o_terrain_cols); TR.border = HOT(o_border); TR.ihs = 1.f / HOT(o_hscale);
+    TR.rows = PLANE ? 0 : HOT(o_terrain_rows); TR.cols = HOT(o_terrain_cols); TR.border = HOT(o_border); TR.ihs = 1.f / HOT(o_hscale);
     TR.vscale = HOT(o_vscale); TR.hf = p.hf;
-    const bool hfmode = !FLAT && TR.rows > 0;
+    const bool hfmode = !PLANE && TR.rows > 0;
     const float mass0 = M->mass[0] + dr_mass;
     const float com0 = M->com[0][cj] + dr_com;
     auto sym_row = [&](const float *s6) {   // rows of a symmetric 3x3 stored (xx, yy, zz, xy, xz, yz)
@@ -950,7 +951,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     if (live && leg == 0) B.base_quat[4 * e + L.c] = quat;
 
     // ---------------- terrain sampling around the base and the feet (genesis_simulator.py:552-610) ------
-    const int P = FLAT ? 0 : HOT(o_n_height_points);
+    const int P = PLANE ? 0 : HOT(o_n_height_points);
     if (P > 0) {
         const float yn = rcp(fmaxf(fsqrt(qz * qz + qw * qw), 1e-9f));
         const float yz = qz * yn, yw = qw * yn;
@@ -1010,7 +1011,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             }
         }
     }
-    if (!FLAT && B.link_contact_states && live) {   // genesis_simulator.py:53-55
+    if (!PLANE && B.link_contact_states && live) {   // genesis_simulator.py:53-55
         const unsigned mask = M->state_link_mask;
         const int l0 = foot_link - 3, nst = __popc(mask);
 #pragma unroll
@@ -1368,7 +1369,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         if (P > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __syncthreads();
         if (threadIdx.x < 16)
-            env_step_body<LEGS, MPH, true, FLAT>(p, sMraw, sHot, sStF, sX, blockIdx.x * 16 + (int)threadIdx.x, (int)threadIdx.x);
+            env_step_body<LEGS, MPH, true, PROF>(p, sMraw, sHot, sStF, sX, blockIdx.x * 16 + (int)threadIdx.x, (int)threadIdx.x);
     }
     STAMPB(12288);
 }
