@@ -1070,6 +1070,10 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         }  // sub-steps
 
         STAMP(4);
+        if (!PLANE && p.k.cat_enable) {   // go2_cat's job-wide "some joint faster than 4 rad/s" flag (LG_CR_ANY_FAST): every wave that sees one raises it
+            const bool fast = live && (fabsf(qd[0]) > 4.0f || fabsf(qd[1]) > 4.0f || fabsf(qd[2]) > 4.0f);
+            if (__builtin_amdgcn_ballot_w64(fast) != 0ull && threadIdx.x == 0) B.command_ranges[LG_CR_ANY_FAST + (int)(p.counter & 1)] = 1.0f;
+        }
         // ---- read-back (genesis_simulator.py:35-60) ----------------------------------------------
         {   // non-finite guard: re-seat the robot (see oracle for the rationale)
             float chk = pos.x + pos.y + pos.z + qx + qy + qz + qw + vw.x + vw.y + vw.z + ww.x + ww.y + ww.z;
@@ -1454,7 +1458,8 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             if ((bits & (1 << 9)) && (bits & (1 << 10))) bits |= 1 << 6;                 // any(q < lo) * any(q > hi)  (go2_cat.py:170-171)
             if (pg.z > T->cat_max_projected_gravity) bits |= 1 << 7;
             const float cmdn = sqrtf(cmd0 * cmd0 + cmd1 * cmd1 + cmd2 * cmd2);
-            if (CR(LG_CR_ANY_FAST) != 0.f && cmdn < 0.1f) bits |= 1 << 8;               // job-wide motion flag x own zero command
+            if (CR(LG_CR_ANY_FAST + (int)(p.counter & 1)) != 0.f && cmdn < 0.1f) bits |= 1 << 8;   // job-wide motion flag x own zero command
+            if (blockIdx.x == 0 && threadIdx.x == 0) B.command_ranges[LG_CR_ANY_FAST + (int)((p.counter + 1) & 1)] = 0.f;   // next step's slot
             bits &= 0x1FF;
             cstr_p = (bits & 0xF0) ? 1.f : ((bits & 0x10F) ? T->cat_soft_p : 0.f);
             cat_keep = 1.0f - cstr_p;
@@ -2587,6 +2592,8 @@ extern "C" int lg_step(LgHandle h, uint32_t phases, const float *actions, int64_
         return fail("lg_step: actions pointer is NULL");
     if (h->opts.terrain_rows > 0 && !h->hf) return fail("lg_step: heightfield options set but lg_set_terrain was not called");
     if (check_mdp_bufs(h, phases)) return 1;
+    if (h->task.cat_enable && (phases & LG_PHASE_SIM) && (phases & LG_PHASE_POST))
+        return fail("lg_step: with cat_enable the physics and the MDP phases must be separate launches (job-wide constraint flag, LG_CR_ANY_FAST)");
     hipStream_t st = (hipStream_t)stream;
     // Bounded run-ahead.  A host that enqueues thousands of launches ahead of the device (a bench loop without a
     // policy in between) drives the runtime into a slow submission path: measured 90 us per step instead of 42 with

@@ -879,6 +879,9 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     }  // sub-steps
 
     STAMP(21);
+    if (!PLANE && p.k.cat_enable) {   // go2_cat's job-wide "some joint faster than 4 rad/s" flag (LG_CR_ANY_FAST)
+        if (__builtin_amdgcn_ballot_w64(st && fabsf(qd) > 4.0f) != 0ull && threadIdx.x == 0) B.command_ranges[LG_CR_ANY_FAST + (int)(p.counter & 1)] = 1.0f;
+    }
     // ---------------- read-back (genesis_simulator.py:35-60) ---------------------------------------
     {   // non-finite guard: re-seat the robot
         const float chk = quat + (L.is3 ? 0.f : pos + vw + ww + q + qd);

@@ -123,8 +123,9 @@ class Go2CaT(LeggedRobotTS):
     the (1 - p) scaling of the reward and the per-episode violation counters are computed in the kernel's POST phase
     (LgTaskCfg.cat_enable).  One input is job-wide: the reference's style constraint multiplies a (N,) flag with a (N,1) flag
     (go2_cat.py:179-180), which makes an env violate it when its own command is ~0 and ANY env moves a joint faster than
-    4 rad/s.  That flag has to exist before the rewards are computed, so the step is two launches here -- physics, then the MDP
-    phases -- with one small reduction in between (all-reduced over the ranks of a sharded job); no host sync."""
+    4 rad/s.  That flag has to exist before the rewards are computed, so the step is two launches here -- physics, which raises
+    the flag in `command_ranges`, then the MDP phases -- with a one-float max-reduction over the ranks of a sharded job in between;
+    no host sync."""
 
     def _prepare_reward_function(self):
         super()._prepare_reward_function()
@@ -133,17 +134,13 @@ class Go2CaT(LeggedRobotTS):
         for k, n in enumerate(abi.CSTR_NAMES):                     # constraint_manager.py:91-97 logs them into episode_sums
             self.episode_sums["cstr_" + n] = b["cstr_sums"][k]
 
-    def _any_fast(self):
-        flag = (self.simulator.dof_vel.abs() > 4.0).any().to(torch.float32)
-        import torch.distributed as dist
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(flag, op=dist.ReduceOp.MAX)
-        self._engine.buf["command_ranges"][abi.CR_ANY_FAST] = flag
-
     def _engine_step(self, actions, c):
         e = self._engine
-        e.step(abi.PHASE_PRE | abi.PHASE_SIM, actions, c)
-        self._any_fast()
+        e.step(abi.PHASE_PRE | abi.PHASE_SIM, actions, c)         # raises command_ranges[CR_ANY_FAST + (c & 1)] in-kernel
+        import torch.distributed as dist
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            k = abi.CR_ANY_FAST + (int(c) & 1)
+            dist.all_reduce(e.buf["command_ranges"][k:k + 1], op=dist.ReduceOp.MAX)
         if self.cfg.commands.curriculum and (c % self.max_episode_length == 0):
             e.step(abi.PHASE_POST, None, c)
             self._command_curriculum_gate()

@@ -39,8 +39,9 @@ extern "C" {
 #define LG_TASK_STATE_WTW 22   /* gait_time, phi, gait_period, base_h_tgt, clr_tgt, pitch_tgt, theta[4], clock[8], exp_C_frc[4] */
 #define LG_NUM_CSTR 9          /* go2_cat.py:143-205: torque, dof_vel, action_rate, base_height | collision, feet_stumble, dof_pos,
                                  base_orientation | stand_still (soft | hard | style) */
-#define LG_CR_ANY_FAST 17      /* command_ranges[17]: 1 when SOME env of the whole job moves a joint faster than 4 rad/s (set by the
-                                 host between the physics and the MDP launch; see LgTaskCfg.cat_enable) */
+#define LG_CR_ANY_FAST 17      /* command_ranges[17 + (step counter & 1)]: 1 when SOME env of the whole job moves a joint faster than 4 rad/s.
+                                 Set by the physics launch of a step (LgTaskCfg.cat_enable), read by its MDP launch, which also clears the
+                                 other slot for the next step; a sharded job max-reduces the slot over its ranks between the two launches */
 #define LG_TASK_STATE_BIPED 12 /* gait_time, phi, gait_period(unused), pad, theta[2], clock[4], exp_C_frc[2] */
 
 /* ---- robot model (output of hcr_genesis_lr_cl_amd/model_compiler.py) -------------------
@@ -253,8 +254,8 @@ typedef struct LgTaskCfg {
      * 0/1 violation flag, so the manager's running-max normalisation clamps to 1 and the termination probability of an env is
      * max_p of its worst violated constraint: 1 for a hard one, cat_soft_p for a soft / style one, else 0.  The reward is
      * clip(rew * (1 - p), 0).  The style constraint multiplies a (N,) flag with a (N,1) flag (go2_cat.py:179-180): env e violates
-     * it when ITS command is ~0 and ANY env moves a joint faster than 4 rad/s -- reproduced, the job-wide flag comes in through
-     * command_ranges[LG_CR_ANY_FAST]. */
+     * it when ITS command is ~0 and ANY env moves a joint faster than 4 rad/s -- reproduced through the job-wide flag in
+     * command_ranges[LG_CR_ANY_FAST ..]; the physics and the MDP phases of a CaT step therefore have to be separate launches. */
     int32_t cat_enable;
     float cat_soft_p, cat_action_rate, cat_min_base_height, cat_max_projected_gravity;
     float dof_vel_limits[LG_MAX_DOF];   /* cfg.asset.dof_vel_limits (Simulator.dof_vel_limits) */

@@ -262,7 +262,7 @@ class EEKernelStepper:
         put(eng, "normal_vector_around_feet", fx["normals"][t])
         put(eng, "rand_in", R)
         if "cstr_prob" in eng.buf:       # go2_cat: the job-wide "some env moves a joint faster than 4 rad/s" flag (envs/go2_ts.py Go2CaT._any_fast)
-            eng.buf["command_ranges"][abi.CR_ANY_FAST] = float(np.any(np.abs(sim["dof_vel"]) > 4.0))
+            eng.buf["command_ranges"][abi.CR_ANY_FAST + (counter & 1)] = float(np.any(np.abs(sim["dof_vel"]) > 4.0))   # what the SIM phase raises
         eng.step(abi.PHASE_PRE | abi.PHASE_POST | abi.PHASE_RESET, torch.from_numpy(actions).cuda(), counter)
         torch.cuda.synchronize()
         es = get(eng, "episode_sums")
@@ -506,3 +506,33 @@ def test_tron1_pf_env_rollout():
     assert torch.isfinite(obs).all() and torch.isfinite(priv).all() and torch.isfinite(rew).all()
     assert n_reset > 50 and "rew_no_fly" in list(extras["episode"])
     assert float(env.simulator.base_pos[:, 2].max()) < 1.5
+
+
+def test_cat_job_wide_flag_is_raised_by_the_physics_launch():
+    """go2_cat: the SIM launch raises command_ranges[CR_ANY_FAST + (counter & 1)] iff some env moves a joint faster than 4 rad/s
+    (what the reference's (N,) x (N,1) broadcast amounts to, go2_cat.py:179-180); the MDP launch clears the other slot."""
+    import torch
+    from hcr_genesis_lr_cl_amd import abi
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    env, cfg = make_env("go2_cat", 256)
+    env.reset()
+    eng, cr = env._engine, env._engine.buf["command_ranges"]
+    c = env.common_step_counter
+    for scale, want in ((0.0, 0.0), (6.0, 1.0), (0.0, None)):
+        c += 1
+        if scale == 0.0 and want is not None:        # everybody at rest in the air: nothing moves fast
+            s = env.simulator
+            s.dof_vel.zero_(); s._base_lin_vel_w.zero_(); s._base_ang_vel_w.zero_(); s.base_pos[:, 2] += 1.0
+            s.dof_pos.copy_(s.default_dof_pos.expand_as(s.dof_pos))
+        eng.step(abi.PHASE_PRE | abi.PHASE_SIM, torch.randn(256, 12, device="cuda") * scale, c)
+        torch.cuda.synchronize()
+        flag = float(cr[abi.CR_ANY_FAST + (c & 1)])
+        assert flag == float((env.simulator.dof_vel.abs() > 4.0).any())
+        if want is not None:
+            assert flag == want
+        eng.step(abi.PHASE_POST | abi.PHASE_RESET, None, c)
+        torch.cuda.synchronize()
+        assert float(cr[abi.CR_ANY_FAST + ((c + 1) & 1)]) == 0.0
+    env.common_step_counter = c
+    with pytest.raises(RuntimeError):
+        eng.step(abi.PHASE_ALL, torch.zeros(256, 12, device="cuda"), c + 1)      # CaT cannot run as one launch
