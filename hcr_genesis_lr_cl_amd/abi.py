@@ -10,7 +10,7 @@ import os
 
 import numpy as np
 
-JPL = 3
+MAX_JPL = 4
 MAX_LEGS = 4
 MAX_DOF = 12
 MAX_BODIES = 13
@@ -36,6 +36,23 @@ REWARD_NAMES = [
 ]
 R_COUNT = len(REWARD_NAMES)
 REWARD_ID = {n: i for i, n in enumerate(REWARD_NAMES)}
+# terms of the 4-joint sole-foot biped (tron1_sf.py:281-308) share the ids of quadruped-only terms (include/lgsim.h LG_R_FOOT_FLAT ...)
+REWARD_ALIASES_JPL4 = {"hip_pos_zero_command": "hip_pos", "foot_flat": "quad_periodic_gait", "keep_ankle_pitch_zero_in_air": "tracking_foot_clearance"}
+
+
+def reward_id(name, joints_per_leg=3):
+    """enum LgReward value of a reward-scale name for a robot with that many joints per leg."""
+    if joints_per_leg == 4 and name in REWARD_ALIASES_JPL4:
+        return REWARD_ID[REWARD_ALIASES_JPL4[name]]
+    if joints_per_leg == 4 and name in REWARD_ALIASES_JPL4.values():
+        raise KeyError(f"reward term {name} does not exist for four-joint legs")
+    return REWARD_ID[name]
+
+
+def reward_names(joints_per_leg=3):
+    """Names by enum LgReward value as they read for that robot (episode-sum keys)."""
+    inv = {v: k for k, v in REWARD_ALIASES_JPL4.items()} if joints_per_leg == 4 else {}
+    return [inv.get(n, n) for n in REWARD_NAMES]
 OBS_GO2, OBS_GO2_WTW, OBS_GO2_EE, OBS_TRON1_EE, OBS_PROGRAM = 0, 1, 2, 3, 4
 
 f32, i32, u32, i64, u64 = C.c_float, C.c_int32, C.c_uint32, C.c_int64, C.c_uint64
@@ -82,7 +99,8 @@ NUM_CSTR = 9
 CR_ANY_FAST = 17
 CSTR_NAMES = ["torque", "dof_vel", "action_rate", "base_height", "collision", "feet_stumble", "dof_pos", "base_orientation", "stand_still"]
 (SEG_END, SEG_FRAME, SEG_DR, SEG_DR_JOINT, SEG_BASE_LIN_VEL, SEG_CONTACT_STATES, SEG_HEIGHTS, SEG_FEET_REL_HEIGHTS,
- SEG_FEET_HEIGHTS, SEG_FEET_NORMALS, SEG_FOOT_CLEARANCE, SEG_NEXT_STATE, SEG_LAST_ACTIONS, SEG_DR_BASE, SEG_FEET_AIR_TIME) = range(15)
+ SEG_FEET_HEIGHTS, SEG_FEET_NORMALS, SEG_FOOT_CLEARANCE, SEG_NEXT_STATE, SEG_LAST_ACTIONS, SEG_DR_BASE, SEG_FEET_AIR_TIME, SEG_KP,
+ SEG_KD) = range(17)
 
 
 class LgObsProgram(C.Structure):
@@ -102,7 +120,7 @@ class LgTaskCfg(C.Structure):
         ("tracking_sigma", f32), ("base_height_target", f32), ("foot_clearance_target", f32),
         ("foot_height_offset", f32), ("foot_clearance_sigma", f32), ("about_landing_threshold", f32),
         ("feet_air_time_threshold", f32), ("base_height_sigma", f32), ("euler_sigma", f32),
-        ("foot_distance_threshold", f32), ("foot_clearance_ref", i32),
+        ("foot_distance_threshold", f32), ("no_fly_contact_threshold", f32), ("air_time_cmd_dims", i32), ("foot_clearance_ref", i32),
         ("obs_scale_lin_vel", f32), ("obs_scale_ang_vel", f32), ("obs_scale_dof_pos", f32),
         ("obs_scale_dof_vel", f32), ("obs_scale_height", f32),
         ("add_noise", i32), ("noise_vec", f32 * MAX_OBS),

@@ -129,12 +129,12 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
         FW = 9 + 3 * A
         width = {"frame": FW, "dr": 7 + 2 * A, "dr_joint": 3, "base_lin_vel": 3, "contact_states": K, "heights": P,
                  "feet_rel_heights": 9 * F, "feet_heights": 9 * F, "feet_normals": 3 * F, "foot_clearance": F, "next_state": FW,
-                 "last_actions": A, "dr_base": 7, "feet_air_time": F}
+                 "last_actions": A, "dr_base": 7, "feet_air_time": F, "kp": A, "kd": A}
         kind = {"frame": abi.SEG_FRAME, "dr": abi.SEG_DR, "dr_joint": abi.SEG_DR_JOINT, "base_lin_vel": abi.SEG_BASE_LIN_VEL,
                 "contact_states": abi.SEG_CONTACT_STATES, "heights": abi.SEG_HEIGHTS, "feet_rel_heights": abi.SEG_FEET_REL_HEIGHTS,
                 "feet_heights": abi.SEG_FEET_HEIGHTS, "feet_normals": abi.SEG_FEET_NORMALS, "foot_clearance": abi.SEG_FOOT_CLEARANCE,
                 "next_state": abi.SEG_NEXT_STATE, "last_actions": abi.SEG_LAST_ACTIONS, "dr_base": abi.SEG_DR_BASE,
-                "feet_air_time": abi.SEG_FEET_AIR_TIME}
+                "feet_air_time": abi.SEG_FEET_AIR_TIME, "kp": abi.SEG_KP, "kd": abi.SEG_KD}
 
         def fill(prog, blocks, clip):
             assert len(blocks) <= abi.MAX_SEGS
@@ -153,6 +153,12 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
         abi.fill_array(t.noise_vec, go2_noise_vec(cfg, A))         # go2_ts.py:110-131, tron1_pf.py:105-128
         t.slots = go2_slots(A, FW)
         t.heights_offset, t.heights_clip_scale = 0.5, 1             # go2_ts.py:50-52
+        ini = cfg.init_state
+        if getattr(ini, "sit_init_percent", 0.0) > 0.0:            # tron1_sf.py:160-166, 235-254: batch-wide coin, no pitch
+            t.sit_percent = ini.sit_init_percent
+            abi.fill_array(t.sit_pos, ini.sit_pos)
+            abi.fill_array(t.sit_quat, cfg.init_state.rot)
+            abi.fill_array(t.sit_dof_pos, [ini.sit_joint_angles[n] for n in cfg.asset.dof_names])
     elif layout == "tron1_ee":
         e = cfg.env
         t.obs_frame, t.obs_stack, t.num_obs = e.num_single_obs, e.frame_stack, e.num_estimator_features
@@ -194,9 +200,11 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
     abi.fill_array(t.yaw_clip, cfg.commands.ranges.ang_vel_yaw)
     scales = np.zeros(abi.NUM_REWARDS, np.float32)
     for name, s in cfgmod.reward_scales_sorted(cfg).items():
-        if name not in abi.REWARD_ID:
-            raise NotImplementedError(f"reward term {name!r} has no kernel implementation")
-        scales[abi.REWARD_ID[name]] = s * dt                          # legged_robot.py:421 (python float math)
+        try:
+            k = abi.reward_id(name, model.joints_per_leg)
+        except KeyError:
+            raise NotImplementedError(f"reward term {name!r} has no kernel implementation") from None
+        scales[k] = s * dt                                             # legged_robot.py:421 (python float math)
     abi.fill_array(t.reward_scales, scales)
     soft = cfgmod.soft_dof_limits(model, cfg)
     abi.fill_array(t.soft_dof_lo, soft[:, 0])
@@ -211,6 +219,8 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
     t.base_height_sigma = getattr(r, "base_height_tracking_sigma", 0.01)
     t.euler_sigma = getattr(r, "euler_tracking_sigma", 0.1)
     t.foot_distance_threshold = getattr(r, "foot_distance_threshold", 0.0)
+    t.no_fly_contact_threshold = getattr(cfg.reset, "no_fly_contact_threshold", 0.1)     # tron1_pf.py:151-154 | tron1_sf.py:275-278
+    t.air_time_cmd_dims = getattr(cfg.reset, "air_time_cmd_dims", 2)                    # legged_robot.py:553 | tron1_sf.py:264
     t.foot_clearance_ref = {"none": 0, "mean": 1, "max": 2}[getattr(cfg.reset, "foot_clearance_ref", "none")]
     sc = cfg.normalization.obs_scales
     t.obs_scale_lin_vel, t.obs_scale_ang_vel = sc.lin_vel, sc.ang_vel
@@ -222,6 +232,8 @@ def make_task_cfg(model, cfg, seed=None, env_id_offset=0):
         for key, rng in cfg.reset.dof_ranges.items():
             if key in dn:
                 lo[i], span[i] = _span(-rng, rng)
+    for i, rng in enumerate(getattr(cfg.reset, "dof_range_list", [])):   # per-dof half-ranges (tron1_sf.py:213-233)
+        lo[i], span[i] = _span(-rng, rng)
     abi.fill_array(t.reset_dof_lo, lo)
     abi.fill_array(t.reset_dof_span, span)
     t.reset_root_xy_lo, t.reset_root_xy_span = _span(-0.5, 0.5)        # legged_robot.py:288

@@ -332,6 +332,56 @@ class TRON1PFCfg(LeggedRobotCfg):
                     critic_clip=True, aux_program=[], aux_clip=False)
 
 
+# tron1_sf/tron1_sf_config.py:5-163 (TRON1SFCfg) + tron1_sf.py: the 8-DOF sole-foot biped on the plane.  Four joints per leg (abad, hip,
+# knee, ankle); the foot is the ankle body itself (foot_name "ankle", no kept links) with a 0.2 x 0.06 x 0.03 m box sole.
+_SF_JOINTS = [f"{j}_{s}_Joint" for s in ("L", "R") for j in ("abad", "hip", "knee", "ankle")]
+
+
+class TRON1SFCfg(LeggedRobotCfg):
+    env = section(LeggedRobotCfg.env, num_envs=4096, num_single_obs=33, frame_stack=10, c_frame_stack=10, num_observations=33 * 10,
+                  num_single_privileged_obs=33 + 39, num_privileged_obs=(33 + 39) * 10, num_actions=8, env_spacing=2.0)
+    terrain = section(LeggedRobotCfg.terrain, mesh_type="plane")
+    init_state = section(
+        LeggedRobotCfg.init_state, pos=[0.0, 0.0, 0.85], default_joint_angles={n: 0.0 for n in _SF_JOINTS},
+        sit_pos=[0.0, 0.0, 0.6],
+        sit_joint_angles={"abad_L_Joint": 0.0, "hip_L_Joint": 0.58, "knee_L_Joint": 1.35, "ankle_L_Joint": -0.8,
+                          "abad_R_Joint": 0.0, "hip_R_Joint": -0.58, "knee_R_Joint": -1.35, "ankle_R_Joint": -0.8},
+        sit_pitch_angle=0.0, sit_init_percent=0.5)
+    control = section(LeggedRobotCfg.control, stiffness={n: 45.0 for n in _SF_JOINTS},
+                      damping={n: (0.8 if "ankle" in n else 1.5) for n in _SF_JOINTS}, action_scale=0.25, decimation=4)
+    asset = section(
+        LeggedRobotCfg.asset, name="tron1_sf", file="{LEGGED_GYM_ROOT_DIR}/resources/robots/SF_TRON1A/urdf/robot.urdf",
+        foot_name="ankle", penalize_contacts_on=["knee", "hip", "base", "abad"], terminate_after_contacts_on=[],
+        base_link_name="base_Link", dof_names=list(_SF_JOINTS), links_to_keep=[], dof_vel_limits=[])
+    rewards = section(
+        LeggedRobotCfg.rewards, soft_dof_pos_limit=0.9, base_height_target=0.75, foot_clearance_target=0.1, foot_height_offset=0.055,
+        foot_clearance_tracking_sigma=0.01, foot_distance_threshold=0.115, about_landing_threshold=0.05, max_projected_gravity=-0.4,
+        only_positive_rewards=False,
+        scales=section(
+            LeggedRobotCfg.rewards.scales, keep_balance=1.0, dof_pos_limits=-2.0, collision=-1.0, feet_distance=-100.0,
+            tracking_lin_vel=1.0, tracking_ang_vel=1.0, lin_vel_z=-0.5, base_height=-4.0, ang_vel_xy=-0.05, orientation=-5.0,
+            dof_power=-2.0e-4, dof_acc=-2.0e-7, action_rate=-0.01, action_smoothness=-0.01, feet_air_time=1.0, no_fly=0.4,
+            foot_clearance=0.5, foot_landing_vel=-0.15, hip_pos_zero_command=-10.0, foot_flat=0.3))
+    commands = section(
+        LeggedRobotCfg.commands, curriculum=True, max_curriculum=1.0, num_commands=4, resampling_time=10.0, heading_command=True,
+        ranges=section(LeggedRobotCfg.commands.ranges, lin_vel_x=[-0.5, 0.5], lin_vel_y=[-1.0, 1.0], ang_vel_yaw=[-1, 1],
+                       heading=[-3.14, 3.14]))
+    domain_rand = section(
+        LeggedRobotCfg.domain_rand, randomize_friction=True, friction_range=[0.0, 2.0], randomize_base_mass=True,
+        added_mass_range=[-0.5, 1.0], push_robots=True, push_interval_s=10, max_push_vel_xy=1.0, randomize_com_displacement=True,
+        com_pos_x_range=[-0.03, 0.03], com_pos_y_range=[-0.03, 0.03], com_pos_z_range=[-0.03, 0.03], randomize_pd_gain=True,
+        kp_range=[0.8, 1.2], kd_range=[0.8, 1.2], randomize_joint_armature=True, joint_armature_range=[0.11, 0.13],
+        randomize_joint_friction=True, joint_friction_range=[0.00, 0.01], randomize_joint_damping=True, joint_damping_range=[1.4, 1.45])
+    # tron1_sf.py:213-233 writes the reset offsets with the 6-DOF index pairs [0,3] [1,4] [2,5] [3,6] into the 8-DOF vector: dof 3 is
+    # overwritten by the last pair and dof 7 is never set -- reproduced as the per-dof half-ranges below.  Sit pose: one coin per
+    # reset_idx call (:160-166), no pitch.  Air time 0.25 gated by |commands[:, :3]| (:256-267); no_fly counts contacts above 1 N (:275-278)
+    reset = section(dof_ranges={}, dof_range_list=[0.05, 0.2, 0.2, 0.2, 0.2, 0.2, 0.2, 0.0], root_vel_range=0.5, robot="tron1_sf",
+                    obs_layout="program", feet_air_time_threshold=0.25, air_time_cmd_dims=3, no_fly_contact_threshold=1.0,
+                    critic_program=[("base_lin_vel", 1.0), ("frame", 1.0), ("last_actions", 1.0), ("dr_base", 1.0), ("feet_air_time", 1.0),
+                                    ("kp", 1.0), ("kd", 1.0), ("dr_joint", 1.0)],
+                    critic_clip=True, aux_program=[], aux_clip=False)
+
+
 # ---- the other Go2-rough task heads (legged_gym/envs/__init__.py:82-86): same robot, terrain, rewards, resets and domain
 # randomisation as go2_ee (verified by diffing the reference's instantiated config trees); they differ in how the step's
 # outputs are packaged.  Frames are described as observation programs (include/lgsim.h LgObsSeg): (block, extra scale).

@@ -29,7 +29,7 @@
 #include <vector>
 #include <hip/hip_ext.h>
 
-#define LG_ABI_VERSION 2
+#define LG_ABI_VERSION 3
 #define BLOCK 64
 #define MODEL_STG 4   /* uint4 per thread to stage the model table: 4 * 64 * 16 B = 4 KiB >= sizeof(LgModelDesc) */
 static_assert(sizeof(LgModelDesc) <= MODEL_STG * BLOCK * 16, "model table does not fit the staging image");
@@ -114,6 +114,7 @@ struct LgHot {
     float b_swing;
     float gait_period_fixed;
     float sit_percent;
+    int32_t air_time_cmd_dims;
     int32_t task_state_width;
     float yaw_clip[2];
     float base_init_quat[4];
@@ -154,7 +155,7 @@ struct LgHot {
     float o_bound_y[2];
 };
 static void fill_hot(LgHot &H, const LgTaskCfg &t, const LgSimOptions &o, const LgModelDesc &m) {
-    const int n_dof = 3 * m.n_legs;
+    const int n_dof = m.n_bodies - 1;
     memset(&H, 0, sizeof(H));
     H.m_n_links = m.n_links;
     for (int i = 0; i < LG_MAX_LEGS; i++) { H.m_foot_link[i] = m.foot_link[i]; H.m_foot_sphere[i] = m.foot_sphere[i]; }
@@ -175,6 +176,7 @@ static void fill_hot(LgHot &H, const LgTaskCfg &t, const LgSimOptions &o, const 
     H.max_episode_length = t.max_episode_length;
     H.fail_threshold = t.fail_threshold;
     H.max_projected_gravity = t.max_projected_gravity;
+    H.air_time_cmd_dims = t.air_time_cmd_dims;
     H.resample_steps = t.resample_steps;
     H.push_interval = t.push_interval;
     H.max_push_vel_xy = t.max_push_vel_xy;
@@ -396,22 +398,22 @@ struct BodyKin {
 };
 
 // response of the lane's chain + base to forces/torques that only this quad applies:
-//   fspat: spatial force [r x f; f] on the distal body; tl[3]: joint torques.
+//   fspat: spatial force [r x f; f] on the distal body; tl[NJ]: joint torques.
 // Up-sweep to the base contribution dp0 (to be quad-summed by the caller), then after the
 // base solve the down-sweep gives joint accelerations and the distal body's acceleration.
-LG_DEV V6 resp_up(const Joint (&J)[3], const V6 &fspat, const float (&tl)[3], float (&du)[3]) {
+template <int NJ> LG_DEV V6 resp_up(const Joint (&J)[NJ], const V6 &fspat, const float (&tl)[NJ], float (&du)[NJ]) {
     V6 dp = {-fspat.a, -fspat.l};
 #pragma unroll
-    for (int j = 2; j >= 0; j--) {
+    for (int j = NJ - 1; j >= 0; j--) {
         du[j] = tl[j] - dot(J[j].S, dp);
         dp = dp + J[j].U * (du[j] * J[j].dinv);
     }
     return dp;
 }
-LG_DEV V6 resp_down(const Joint (&J)[3], const V6 &a0, const float (&du)[3], float (&dqdd)[3]) {
+template <int NJ> LG_DEV V6 resp_down(const Joint (&J)[NJ], const V6 &a0, const float (&du)[NJ], float (&dqdd)[NJ]) {
     V6 a = a0;
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
+    for (int j = 0; j < NJ; j++) {
         dqdd[j] = (du[j] - dot(J[j].U, a)) * J[j].dinv;
         a = a + J[j].S * dqdd[j];
     }
@@ -441,6 +443,15 @@ struct RandSrc {
         U4 ctr = {e_lo, e_hi, step, 0x40000000u + (unsigned)slot};
         U4 r = philox4x32_10(ctr, k0, k1);
         a = u01(r.x); b = u01(r.y); c = u01(r.z);
+    }
+    LG_DEV void draw4(int slot, float &a, float &b, float &c, float &d) const {   // four-joint legs: the block's fourth output too
+#ifdef LG_DBG_NO_DRAWS
+        a = b = c = d = 0.5f; return;
+#endif
+        if (in) { a = in[slot]; b = in[slot + 1]; c = in[slot + 2]; d = in[slot + 3]; return; }
+        U4 ctr = {e_lo, e_hi, step, 0x40000000u + (unsigned)slot};
+        U4 r = philox4x32_10(ctr, k0, k1);
+        a = u01(r.x); b = u01(r.y); c = u01(r.z); d = u01(r.w);
     }
     // a whole Philox block (4 uniforms) from a counter space disjoint from the slot space; used
     // where a lane needs several draws per step (observation noise)
@@ -489,12 +500,14 @@ enum { XA = 0, XLA = 3, XLLA = 6, XQ = 9, XQD = 12, XLQD = 15, XTQ = 18, XFL = 2
 // and every other task's code drops out of the instantiation (fewer scalar registers, a shorter tail).
 // PROF 2 (host-checked, `wtw_profile`): the go2_wtw task on the plane -- gait clock and 5-frame stacks stay, terrain and the other
 // tasks' packaging drop out.
-template <int LEGS, unsigned PH, bool FUSED, int PROF = 0>
+// JPL: joints per leg of the serial chains (3: go2, TRON1 point foot; 4: TRON1 sole foot, whose last body is the foot itself).
+template <int LEGS, unsigned PH, bool FUSED, int PROF = 0, int JPL = 3>
 LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF, const float *sX, const int vtid, const int vlane) {
     constexpr bool FLAT = PROF == 1, WTWP = PROF == 2, PLANE = FLAT || WTWP, EEP = PROF == 3, PRGP = PROF == 4, ROUGHQ = EEP || PRGP;
     constexpr bool DO_PRE = (PH & LG_PHASE_PRE) != 0, DO_SIM = (PH & LG_PHASE_SIM) != 0;
     constexpr bool DO_POST = (PH & LG_PHASE_POST) != 0, DO_RESET = (PH & LG_PHASE_RESET) != 0;
-    constexpr int A = LEGS * 3;
+    constexpr int A = LEGS * JPL;
+    static_assert(JPL == 3 || (JPL == 4 && !FUSED && LEGS == 2), "four-joint legs: leg-per-lane biped only");
     // model table -> LDS once per workgroup: per-lane (leg-indexed) reads then cost an LDS access
     // instead of an L2 round trip with a single wave per SIMD to hide it
     unsigned long long _stamp0 = 0; (void)_stamp0;
@@ -524,19 +537,19 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     if (!live) e = B.n_envs - 1;  // dead lanes shadow the last env (keeps DPP quads uniform), never store
     const bool lead = live && leg == 0;
     const int L = p.k.m_n_links, F = LEGS;
-    const int b0 = 1 + 3 * leg;            // first body of this lane's chain
-    const int d0 = 3 * leg;                // first dof
+    const int b0 = 1 + JPL * leg;          // first body of this lane's chain
+    const int d0 = JPL * leg;              // first dof
     const int foot_link = leg == 0 ? p.k.m_foot_link[0] : (leg == 1 ? p.k.m_foot_link[1] : (leg == 2 ? p.k.m_foot_link[2] : p.k.m_foot_link[3]));
     int foot_slot = 0;                     // rank of this foot among feet in link order (feet_indices)
 #pragma unroll
     for (int k = 0; k < LEGS; k++) foot_slot += (p.k.m_foot_link[k] < foot_link) ? 1 : 0;
 
     // ---------------- PRE: clip + action history (legged_robot.py:230-239) -----------------
-    float act[3], last_act[3], llast_act[3];
+    float act[JPL], last_act[JPL], llast_act[JPL];
     if (DO_PRE) {
         const float ca = p.k.clip_actions;
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < JPL; j++) {
             float prev = B.actions[e * A + d0 + j], prev2 = B.last_actions[e * A + d0 + j];
             act[j] = clampf(p.actions[e * A + d0 + j], -ca, ca);
             last_act[j] = prev;
@@ -544,13 +557,13 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         }   // the three history stores are issued after every start-of-kernel load (see "prologue stores" below)
     } else if (DO_SIM && !DO_POST) {  // Simulator.step(actions): actions come pre-clipped from the env
 #pragma unroll
-        for (int j = 0; j < 3; j++) { act[j] = p.actions[e * A + d0 + j]; last_act[j] = llast_act[j] = 0.f; }
+        for (int j = 0; j < JPL; j++) { act[j] = p.actions[e * A + d0 + j]; last_act[j] = llast_act[j] = 0.f; }
     } else if (FUSED) {   // handed over by the physics phase of the same launch through LDS
 #pragma unroll
-        for (int j = 0; j < 3; j++) { act[j] = sX[(XA + j) * 16 + vlane]; last_act[j] = sX[(XLA + j) * 16 + vlane]; llast_act[j] = sX[(XLLA + j) * 16 + vlane]; }
+        for (int j = 0; j < JPL; j++) { act[j] = sX[(XA + j) * 16 + vlane]; last_act[j] = sX[(XLA + j) * 16 + vlane]; llast_act[j] = sX[(XLLA + j) * 16 + vlane]; }
     } else {
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < JPL; j++) {
             act[j] = B.actions[e * A + d0 + j];
             last_act[j] = B.last_actions[e * A + d0 + j];
             llast_act[j] = B.llast_actions[e * A + d0 + j];
@@ -559,18 +572,18 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
 
     // ---------------- state ----------------------------------------------------------------
     V3 pos, vw, ww;
-    float qx, qy, qz, qw, q[3], qd[3];
+    float qx, qy, qz, qw, q[JPL], qd[JPL];
     if (FUSED) {
         auto X3 = [&](int k) { return v3(sX[k * 16 + vlane], sX[(k + 1) * 16 + vlane], sX[(k + 2) * 16 + vlane]); };
         pos = X3(XPOS); vw = X3(XVW); ww = X3(XWW);
         qx = sX[XQUAT * 16 + vlane]; qy = sX[(XQUAT + 1) * 16 + vlane]; qz = sX[(XQUAT + 2) * 16 + vlane]; qw = sX[(XQUAT + 3) * 16 + vlane];
 #pragma unroll
-        for (int j = 0; j < 3; j++) { q[j] = sX[(XQ + j) * 16 + vlane]; qd[j] = sX[(XQD + j) * 16 + vlane]; }
+        for (int j = 0; j < JPL; j++) { q[j] = sX[(XQ + j) * 16 + vlane]; qd[j] = sX[(XQD + j) * 16 + vlane]; }
     } else {
         pos = ld3(B.base_pos + 3 * e); vw = ld3(B.base_lin_vel_w + 3 * e); ww = ld3(B.base_ang_vel_w + 3 * e);
         qx = B.base_quat[4 * e]; qy = B.base_quat[4 * e + 1]; qz = B.base_quat[4 * e + 2]; qw = B.base_quat[4 * e + 3];
 #pragma unroll
-        for (int j = 0; j < 3; j++) { q[j] = B.dof_pos[e * A + d0 + j]; qd[j] = B.dof_vel[e * A + d0 + j]; }
+        for (int j = 0; j < JPL; j++) { q[j] = B.dof_pos[e * A + d0 + j]; qd[j] = B.dof_vel[e * A + d0 + j]; }
     }
 
     // ---- MDP working set, fetched NOW so that the round trips overlap the physics below instead of being
@@ -578,10 +591,10 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     constexpr bool DO_MDP = DO_POST || DO_RESET;
     const unsigned rmask0 = (unsigned)p.k.reward_mask, rmask = rmask0;   // scalar for the whole kernel
     const int N = B.n_envs;
-    float q0l[3], soft_lo[3] = {0.f, 0.f, 0.f}, soft_hi[3] = {0.f, 0.f, 0.f}, rdof_lo[3] = {0.f, 0.f, 0.f}, rdof_span[3] = {0.f, 0.f, 0.f};
-    float nv_q[3] = {0.f, 0.f, 0.f}, nv_qd[3] = {0.f, 0.f, 0.f}, nv_act[3] = {0.f, 0.f, 0.f}, nv_clk[2] = {0.f, 0.f};
+    float q0l[JPL], soft_lo[JPL] = {0.f, 0.f, 0.f}, soft_hi[JPL] = {0.f, 0.f, 0.f}, rdof_lo[JPL] = {0.f, 0.f, 0.f}, rdof_span[JPL] = {0.f, 0.f, 0.f};
+    float nv_q[JPL] = {0.f, 0.f, 0.f}, nv_qd[JPL] = {0.f, 0.f, 0.f}, nv_act[JPL] = {0.f, 0.f, 0.f}, nv_clk[2] = {0.f, 0.f};
 #pragma unroll
-    for (int j = 0; j < 3; j++) q0l[j] = O->default_dof_pos[d0 + j];
+    for (int j = 0; j < JPL; j++) q0l[j] = O->default_dof_pos[d0 + j];
     float cmd0 = 0.f, cmd1 = 0.f, cmd2 = 0.f, cmd3 = 0.f, air = 0.f;
     int ep_len = 0, last_contact = 0, dirty_prev = 0;
     long long fail_buf = 0;
@@ -592,7 +605,9 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     V3 origin_pre = v3(0, 0, 0);
     // physics-side start-of-kernel loads: snapshot sources and per-env dynamics parameters
     V3 snap_fv = v3(0, 0, 0), snap_blv = v3(0, 0, 0), snap_bav = v3(0, 0, 0), dr_com = v3(0, 0, 0), dr_joint = v3(0, 0, 0);
-    float dr_mass = 0.f, dr_fric = 1.f, dr_kp[3] = {1.f, 1.f, 1.f}, dr_kd[3] = {1.f, 1.f, 1.f}, gain_p[3] = {0.f, 0.f, 0.f}, gain_d[3] = {0.f, 0.f, 0.f};
+    float dr_mass = 0.f, dr_fric = 1.f, dr_kp[JPL], dr_kd[JPL], gain_p[JPL] = {0.f, 0.f, 0.f}, gain_d[JPL] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int j = 0; j < JPL; j++) dr_kp[j] = dr_kd[j] = 1.f;
     if (DO_SIM) {
         snap_fv = ld3(B.feet_vel + (e * F + foot_slot) * 3);
         snap_blv = ld3(B.base_lin_vel + 3 * e); snap_bav = ld3(B.base_ang_vel + 3 * e);
@@ -600,7 +615,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         if (B.base_com_bias) dr_com = ld3(B.base_com_bias + 3 * e);
         if (B.friction_values) dr_fric = B.friction_values[e];
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < JPL; j++) {
             if (B.kp_scale) dr_kp[j] = B.kp_scale[e * A + d0 + j];
             if (B.kd_scale) dr_kd[j] = B.kd_scale[e * A + d0 + j];
             gain_p[j] = O->kp[d0 + j]; gain_d[j] = O->kd[d0 + j];
@@ -609,7 +624,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     }
     if (DO_MDP && !FUSED) {
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < JPL; j++) {
             soft_lo[j] = T->soft_dof_lo[d0 + j]; soft_hi[j] = T->soft_dof_hi[d0 + j];
             rdof_lo[j] = T->reset_dof_lo[d0 + j]; rdof_span[j] = T->reset_dof_span[d0 + j];
             nv_q[j] = T->noise_vec[9 + d0 + j]; nv_qd[j] = T->noise_vec[9 + A + d0 + j]; nv_act[j] = T->noise_vec[9 + 2 * A + d0 + j];
@@ -631,10 +646,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
 
     // read-back quantities handed from SIM to POST/RESET (registers when fused, HBM otherwise)
     V3 blv, bav, pg, eul;            // body-frame lin/ang vel, projected gravity, euler
-    float last_qd[3], torque[3];
+    float last_qd[JPL], torque[JPL];
     V3 f_link[4];                    // net contact force on this leg's hip, thigh, calf, foot (world)
     V3 f_base = v3(0, 0, 0);         // net contact force on the base (whole env)
     V3 foot_p, foot_v, last_foot_v = v3(0, 0, 0);
+    float foot_zx = 0.f, foot_zy = 0.f;   // x, y of the world z axis seen from the foot body (four-joint legs: _reward_foot_flat)
     // this lane's share of the sampled terrain heights (k = leg + i * LEGS), kept in registers from the moment they are
     // sampled / loaded until the observation is written: one batch of independent loads instead of a dependent
     // load -> store chain per entry in each consumer
@@ -657,7 +673,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     // MDP working set -> LDS for the duration of the physics (it arrived in the same load burst; parking it here keeps
     // ~70 registers per lane free in the sub-step loop).  Layout [value][lane]: conflict-free.
     constexpr bool STASH = DO_MDP && DO_SIM;
-    constexpr int NST = LG_R_COUNT + 36;
+    constexpr int NST = LG_R_COUNT + 7 * JPL + 15;
     __shared__ float sSt[STASH ? NST : 1][BLOCK];
     if (STASH) {
         const int t = threadIdx.x;
@@ -665,7 +681,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         for (int k = 0; k < LG_R_COUNT; k++) sSt[k][t] = es[k];
         int c = LG_R_COUNT;
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < JPL; j++) {
             sSt[c++][t] = soft_lo[j]; sSt[c++][t] = soft_hi[j]; sSt[c++][t] = rdof_lo[j]; sSt[c++][t] = rdof_span[j];
             sSt[c++][t] = nv_q[j]; sSt[c++][t] = nv_qd[j]; sSt[c++][t] = nv_act[j];
         }
@@ -683,7 +699,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     //      round trip of each; issued here the stores drain under the physics instead.
     if (DO_PRE && live) {
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < JPL; j++) {
             B.llast_actions[e * A + d0 + j] = llast_act[j];
             B.last_actions[e * A + d0 + j] = last_act[j];
             B.actions[e * A + d0 + j] = act[j];
@@ -692,11 +708,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     if (DO_SIM) {
         // "last" snapshots (genesis_simulator.py:21-24)
 #pragma unroll
-        for (int j = 0; j < 3; j++) last_qd[j] = qd[j];
+        for (int j = 0; j < JPL; j++) last_qd[j] = qd[j];
         last_foot_v = snap_fv;
         if (live) {
 #pragma unroll
-            for (int j = 0; j < 3; j++) B.last_dof_vel[e * A + d0 + j] = qd[j];
+            for (int j = 0; j < JPL; j++) B.last_dof_vel[e * A + d0 + j] = qd[j];
             st3(B.last_feet_vel + (e * F + foot_slot) * 3, snap_fv);
             if (lead) {
                 st3(B.last_base_lin_vel + 3 * e, snap_blv);
@@ -707,9 +723,9 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         const float mass0 = M->mass[0] + dr_mass;
         V3 com0 = ld3(M->com[0]) + dr_com;
         const float mu = HOT(o_terrain_friction) * dr_fric;
-        float kps[3], kds[3], arm[3], jdamp[3], jfric[3];
+        float kps[JPL], kds[JPL], arm[JPL], jdamp[JPL], jfric[JPL];
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < JPL; j++) {
             kps[j] = dr_kp[j] * gain_p[j];
             kds[j] = dr_kd[j] * gain_d[j];
             arm[j] = B.joint_armature ? dr_joint.x : M->armature[d0 + j];
@@ -727,11 +743,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         // ---- this lane's model constants and collision spheres, read from the LDS table ONCE per launch and kept
         //      in registers across the four sub-steps (a single wave per SIMD cannot hide ~100-cycle LDS round
         //      trips issued from inside the dependency chain: they were 40 % of the wave's cycles)
-        float Lm[3], Lqlo[3], Lqhi[3], Leff[3], Lvlim[3];
-        V3 Lcom[3], Ljpos[3], Lax[3];
-        S3 LIc[3];
+        float Lm[JPL], Lqlo[JPL], Lqhi[JPL], Leff[JPL], Lvlim[JPL];
+        V3 Lcom[JPL], Ljpos[JPL], Lax[JPL];
+        S3 LIc[JPL];
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < JPL; j++) {
             const int b = b0 + j;
             Lm[j] = M->mass[b]; Lcom[j] = ld3(M->com[b]); Ljpos[j] = ld3(M->jpos[b]); Lax[j] = ld3(M->axis[b]);
             const S3 t = {M->inertia[b][0], M->inertia[b][1], M->inertia[b][2], M->inertia[b][3], M->inertia[b][4], M->inertia[b][5]};
@@ -739,20 +755,28 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             Lqlo[j] = M->q_lo[d0 + j]; Lqhi[j] = M->q_hi[d0 + j]; Leff[j] = M->effort[d0 + j];
             Lvlim[j] = HOT(o_joint_vel_clamp) * M->vel_limit[d0 + j];
         }
-        // spheres: up to SPH0/SPH1/SPH2 on the three chain bodies (foot sphere excluded) and SPHB of the base
-        // spheres dealt round-robin to the lanes of the env; counts are validated by lg_create
-        constexpr int SPH0 = 2, SPH1 = 2, SPH2 = 5, SPHB = 4;
+        // spheres: up to SPH0/SPH1/SPH2 on the first, second and LAST chain body (foot sphere excluded), SPHM on the third
+        // of a four-joint chain, and SPHB of the base spheres dealt round-robin to the lanes of the env; counts are
+        // validated by lg_create
+        constexpr int SPH0 = 2, SPH1 = 2, SPH2 = 5, SPHM = JPL == 4 ? 3 : 1, SPHB = 4;
         struct Sph { V3 p; float r, w; };
-        Sph S0[SPH0], S1[SPH1], S2[SPH2], SB[SPHB];
-        int n0 = 0, n1 = 0, n2 = 0, nB = 0;
+        Sph S0[SPH0], S1[SPH1], S2[SPH2], SM[SPHM], SB[SPHB];
+        int n0 = 0, n1 = 0, n2 = 0, nM = 0, nB = 0;
         {
             auto ld = [&](int s) { Sph t = {ld3(M->sph_pos[s]), M->sph_r[s], M->sph_w[s]}; return t; };
-            const int a0 = M->body_sph_start[b0], a1 = M->body_sph_start[b0 + 1], a2 = M->body_sph_start[b0 + 2], a3 = M->body_sph_start[b0 + 3];
-            n0 = a1 - a0; n1 = a2 - a1;
+            const int a0 = M->body_sph_start[b0], a1 = M->body_sph_start[b0 + 1];
+            const int a2 = M->body_sph_start[b0 + JPL - 1], a3 = M->body_sph_start[b0 + JPL];   // last body of the chain
+            const int a1e = M->body_sph_start[b0 + 2];                                           // end of the second body's spheres
+            n0 = a1 - a0; n1 = a1e - a1;
 #pragma unroll
             for (int k = 0; k < SPH0; k++) S0[k] = ld(min(a0 + k, a1 - 1 >= a0 ? a1 - 1 : a0));
 #pragma unroll
-            for (int k = 0; k < SPH1; k++) S1[k] = ld(min(a1 + k, a2 - 1 >= a1 ? a2 - 1 : a1));
+            for (int k = 0; k < SPH1; k++) S1[k] = ld(min(a1 + k, a1e - 1 >= a1 ? a1e - 1 : a1));
+            if (JPL == 4) {
+                nM = a2 - a1e;
+#pragma unroll
+                for (int k = 0; k < SPHM; k++) SM[k] = ld(min(a1e + k, a2 - 1 >= a1e ? a2 - 1 : a1e));
+            }
             int cnt = 0;
 #pragma unroll
             for (int k = 0; k < SPH2 + 1; k++) {       // skip the foot sphere (solved implicitly in stage 2)
@@ -780,10 +804,10 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         for (int sub = 0; sub < HOT(o_decimation); sub++) {
             const M3 Rb = quat_to_mat(qx, qy, qz, qw);
             // ---- forward kinematics + velocities of the chain (root -> leaf) -----------------
-            BodyKin K[3];
-            Joint J[3];
+            BodyKin K[JPL];
+            Joint J[JPL];
 #pragma unroll
-            for (int j = 0; j < 3; j++) f_link[j] = v3(0, 0, 0);
+            for (int j = 0; j < JPL; j++) f_link[j] = v3(0, 0, 0);
             f_link[3] = v3(0, 0, 0);
             V3 fb_acc = v3(0, 0, 0);       // this lane's share of base-sphere forces
             V6 pbase_ext = {v3(0, 0, 0), v3(0, 0, 0)};  // spatial force of that share about O
@@ -792,7 +816,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 V3 Pp = v3(0, 0, 0);
                 V6 Vp = {ww, vw};
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
+                for (int j = 0; j < JPL; j++) {
                     const int b = b0 + j;
                     const V3 jp = Ljpos[j], ax = Lax[j];
                     K[j].P = Pp + mul(Rp, jp);
@@ -816,15 +840,23 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             }
             // ---- body (non-foot) collision spheres: penalty made implicit with the conservative
             //      point inverse mass sph_w; lane handles its chain + every LEGS-th base sphere
-            auto sphere_contact = [&](const Sph &sp, const M3 &R, V3 P, const V6 &V, V3 &fsum, V6 &pacc) {
+            // Sole corners (four-joint legs, the spheres of the foot body besides the foot sphere): they hold the foot flat, the load
+            // itself is carried by the foot sphere at the sole centre (stage 2, exact).  `ank` = the chain's last joint with
+            // dinv = 1 / (S^T I_foot S + armature); a corner's inverse mass is twice the ankle's own compliance at the contact point,
+            // 2 (n . (s x (c - P)))^2 dinv (the two corners of an edge share that rotation), plus the model's sph_w; its penetration and
+            // approach velocity are measured relative to the sole centre's (dref, vref) while that one is in the ground
+            auto sphere_contact = [&](const Sph &sp, const M3 &R, V3 P, const V6 &V, V3 &fsum, V6 &pacc, const Joint *ank = nullptr,
+                                      const float dref = 0.f, const float vref = 0.f) {
                 const V3 r = P + mul(R, sp.p);
                 const float rad = sp.r;
                 float h; V3 n;
                 if (PLANE) { h = 0.f; n = v3(0.f, 0.f, 1.f); } else terrain_at(O, p.hf, pos.x + r.x, pos.y + r.y, h, n);
-                const float depth = rad - (pos.z + r.z - h) * n.z;
+                const float depth = rad - (pos.z + r.z - h) * n.z - dref;
                 if (depth > -margin) {
                     const V3 v = V.l + cross(V.a, r);
-                    const float vn = dot(v, n), wi = sp.w;
+                    float wi = sp.w;
+                    if (JPL == 4 && ank) { const float g = dot(n, ank->S.l + cross(ank->S.a, r - n * rad)); wi += 2.f * g * g * ank->dinv; }
+                    const float vn = dot(v, n) - vref;
                     const float fn = (kc * depth - kappa * vn) * rcp(1.f + kappa * dt * wi);
                     if (fn > 0.f) {
                         const V3 vt = v - n * vn;
@@ -845,9 +877,9 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 if (k < nB) sphere_contact(SB[k], Rb, v3(0, 0, 0), V0, fb_acc, pbase_ext);
 
             // ---- actuation (genesis_simulator.py:630-642): PD, torque reported unclipped ----
-            float tau[3];
+            float tau[JPL];
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
+            for (int j = 0; j < JPL; j++) {
                 const float t = kps[j] * (act[j] * HOT(o_action_scale) + q0l[j] - q[j]) - kds[j] * qd[j];
                 torque[j] = t;
                 const float lim = Leff[j];
@@ -858,7 +890,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             I6 IAacc;
             V6 pacc;
 #pragma unroll
-            for (int j = 2; j >= 0; j--) {
+            for (int j = JPL - 1; j >= 0; j--) {
                 {
                     const float m = Lm[j];
                     const V3 cw = K[j].P + mul(K[j].R, Lcom[j]);
@@ -878,6 +910,23 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     } else if (j == 1) {
 #pragma unroll
                         for (int k = 0; k < SPH1; k++) if (k < n1) sphere_contact(S1[k], K[j].R, K[j].P, K[j].V, f_link[j], ext);
+                    } else if (j < JPL - 1) {
+#pragma unroll
+                        for (int k = 0; k < SPHM; k++) if (k < nM) sphere_contact(SM[k], K[j].R, K[j].P, K[j].V, f_link[j], ext);
+                    } else if (JPL == 4) {   // the foot body: spheres see the ankle's compliance (see sphere_contact)
+                        const I6 Ifoot = {Icw + parallel_axis(m, cw), skew(cw * m), S3{m, m, m, 0.f, 0.f, 0.f}};
+                        Joint ank = J[j];
+                        ank.dinv = rcp(dot(J[j].S, mul(Ifoot, J[j].S)) + arm[j]);
+                        float dref = 0.f, vref = 0.f;
+                        {
+                            const V3 rc = K[j].P + mul(K[j].R, foot_c_loc);
+                            float hc; V3 nc;
+                            if (PLANE) { hc = 0.f; nc = v3(0.f, 0.f, 1.f); } else terrain_at(O, p.hf, pos.x + rc.x, pos.y + rc.y, hc, nc);
+                            const float dc = foot_r - (pos.z + rc.z - hc) * nc.z;
+                            if (dc > 0.f) { dref = dc; vref = dot(K[j].V.l + cross(K[j].V.a, rc), nc); }
+                        }
+#pragma unroll
+                        for (int k = 0; k < SPH2; k++) if (k < n2) sphere_contact(S2[k], K[j].R, K[j].P, K[j].V, f_link[j], ext, &ank, dref, vref);
                     } else {
 #pragma unroll
                         for (int k = 0; k < SPH2; k++) if (k < n2) sphere_contact(S2[k], K[j].R, K[j].P, K[j].V, f_link[j], ext);
@@ -885,7 +934,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     pb = pb - ext;
                     const S3 Ab = Icw + parallel_axis(m, cw);
                     const M3 Bb = skew(cw * m);
-                    if (j == 2) {
+                    if (j == JPL - 1) {
                         IAacc.A = Ab; IAacc.B = Bb;
                         const S3 Cm = {m, m, m, 0.f, 0.f, 0.f};
                         IAacc.C = Cm;
@@ -923,12 +972,12 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             const Chol6 ch = chol6(IA0);
             V6 a0 = chol6_solve(ch, V6{-p0.a, -p0.l});
             // ---- pass 3 down the chain ------------------------------------------------------
-            float qdd[3];
+            float qdd[JPL];
             V6 a_calf;
             {
                 V6 a = a0;
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
+                for (int j = 0; j < JPL; j++) {
                     a = a + J[j].c;
                     qdd[j] = (J[j].u - dot(J[j].U, a)) * J[j].dinv;
                     a = a + J[j].S * qdd[j];
@@ -942,24 +991,24 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             float depth = -1.f;
             bool fact = false;
             {
-                const V3 r = K[2].P + mul(K[2].R, foot_c_loc);
+                const V3 r = K[JPL - 1].P + mul(K[JPL - 1].R, foot_c_loc);
                 float h;
                 if (PLANE) { h = 0.f; cn = v3(0.f, 0.f, 1.f); } else terrain_at(O, p.hf, pos.x + r.x, pos.y + r.y, h, cn);
                 depth = foot_r - (pos.z + r.z - h) * cn.z;
                 fact = depth > -margin;
                 cp = r - cn * foot_r;
             }
-            float lim_e[3], lim_s[3], lim_T[3] = {0.f, 0.f, 0.f};
+            float lim_e[JPL], lim_s[JPL], lim_T[JPL] = {0.f, 0.f, 0.f};
             bool lact = false;
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
+            for (int j = 0; j < JPL; j++) {
                 const float lo = Lqlo[j], hi = Lqhi[j];
                 lim_s[j] = 0.f; lim_e[j] = 0.f;
                 if (q[j] < lo + HOT(o_limit_margin)) { lim_s[j] = 1.f; lim_e[j] = lo - q[j]; lact = true; }
                 else if (q[j] > hi - HOT(o_limit_margin)) { lim_s[j] = -1.f; lim_e[j] = q[j] - hi; lact = true; }
             }
             const int any = quad_or<LEGS>((fact || lact) ? 1 : 0);
-            float dqdd[3] = {0.f, 0.f, 0.f};
+            float dqdd[JPL] = {0.f, 0.f, 0.f};
             V6 da0 = {v3(0, 0, 0), v3(0, 0, 0)};
             if (any) {  // uniform across the quad: DPP inside is safe
                 // W columns: response of the contact point to unit forces (this lane's chain + base)
@@ -972,10 +1021,10 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     }
                     const V3 axs[3] = {cn, ct1, ct2};
                     V3 col[3];
-                    const float zero3[3] = {0.f, 0.f, 0.f};
+                    const float zero3[JPL] = {0.f, 0.f, 0.f};
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
-                        float du[3], dq[3];
+                        float du[JPL], dq[JPL];
                         const V6 fsp = {cross(cp, axs[k]), axs[k]};
                         const V6 dp = resp_up(J, fsp, zero3, du);
                         const V6 ab = chol6_solve(ch, V6{-dp.a, -dp.l});
@@ -986,8 +1035,8 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     Ac.xx = dt * col[0].x; Ac.xy = dt * col[1].x; Ac.xz = dt * col[2].x;
                     Ac.yx = dt * col[0].y; Ac.yy = dt * col[1].y; Ac.yz = dt * col[2].y;
                     Ac.zx = dt * col[0].z; Ac.zy = dt * col[1].z; Ac.zz = dt * col[2].z;
-                    const V3 vpt = K[2].V.l + cross(K[2].V.a, cp);
-                    const V3 apt = a_calf.l + cross(a_calf.a, cp) + cross(K[2].V.a, vpt);
+                    const V3 vpt = K[JPL - 1].V.l + cross(K[JPL - 1].V.a, cp);
+                    const V3 apt = a_calf.l + cross(a_calf.a, cp) + cross(K[JPL - 1].V.a, vpt);
                     const V3 vf = vpt + apt * dt;
                     vfree = v3(dot(cn, vf), dot(ct1, vf), dot(ct2, vf));
                 }
@@ -1014,9 +1063,9 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                         }
                     }
                     fc = fnew;
-                    float tl[3];
+                    float tl[JPL];
 #pragma unroll
-                    for (int j = 0; j < 3; j++) {
+                    for (int j = 0; j < JPL; j++) {
                         tl[j] = 0.f;
                         if (lim_s[j] != 0.f) {
                             // compliance: 1/d on the first sweep, then the response measured in the previous one
@@ -1031,14 +1080,15 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     // exact response of the whole robot to the current force set
                     const V3 fw = cn * fc.x + ct1 * fc.y + ct2 * fc.z;
                     const V6 fsp = {cross(cp, fw), fw};
-                    float du[3];
+                    float du[JPL];
                     const V6 dp = quad_sum<LEGS>(resp_up(J, fsp, tl, du));
                     da0 = chol6_solve(ch, V6{-dp.a, -dp.l});
                     const V6 ac = resp_down(J, da0, du, dqdd);
                     const V3 ra = ac.l + cross(ac.a, cp);
                     resp_c = v3(dot(cn, ra), dot(ct1, ra), dot(ct2, ra));
                 }
-                f_link[3] = cn * fc.x + ct1 * fc.y + ct2 * fc.z;
+                if (JPL == 4) f_link[3] += cn * fc.x + ct1 * fc.y + ct2 * fc.z;   // the foot is the last body's own link: add to its other spheres
+                else f_link[3] = cn * fc.x + ct1 * fc.y + ct2 * fc.z;
             }
             // ---- semi-implicit Euler ------------------------------------------------------------
             {
@@ -1048,7 +1098,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 vw = v3(clampf(vw.x + dt * alin.x, -mv, mv), clampf(vw.y + dt * alin.y, -mv, mv), clampf(vw.z + dt * alin.z, -mv, mv));
                 ww = v3(clampf(ww.x + dt * alpha.x, -mw, mw), clampf(ww.y + dt * alpha.y, -mw, mw), clampf(ww.z + dt * alpha.z, -mw, mw));
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
+                for (int j = 0; j < JPL; j++) {
                     const float vl = Lvlim[j];
                     qd[j] = clampf(qd[j] + dt * (qdd[j] + dqdd[j]), -vl, vl);
                     q[j] += dt * qd[j];
@@ -1071,14 +1121,17 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
 
         STAMP(4);
         if (!PLANE && p.k.cat_enable) {   // go2_cat's job-wide "some joint faster than 4 rad/s" flag (LG_CR_ANY_FAST): every wave that sees one raises it
-            const bool fast = live && (fabsf(qd[0]) > 4.0f || fabsf(qd[1]) > 4.0f || fabsf(qd[2]) > 4.0f);
+            bool fast = false;
+#pragma unroll
+            for (int j = 0; j < JPL; j++) fast = fast || fabsf(qd[j]) > 4.0f;
+            fast = fast && live;
             if (__builtin_amdgcn_ballot_w64(fast) != 0ull && threadIdx.x == 0) B.command_ranges[LG_CR_ANY_FAST + (int)(p.counter & 1)] = 1.0f;
         }
         // ---- read-back (genesis_simulator.py:35-60) ----------------------------------------------
         {   // non-finite guard: re-seat the robot (see oracle for the rationale)
             float chk = pos.x + pos.y + pos.z + qx + qy + qz + qw + vw.x + vw.y + vw.z + ww.x + ww.y + ww.z;
 #pragma unroll
-            for (int j = 0; j < 3; j++) chk += q[j] + qd[j];
+            for (int j = 0; j < JPL; j++) chk += q[j] + qd[j];
             const int bad = quad_or<LEGS>(isfinite(chk) ? 0 : 1);
             if (bad) {
                 pos = v3(HOT(o_base_init_pos[0]), HOT(o_base_init_pos[1]), HOT(o_base_init_pos[2]));
@@ -1086,7 +1139,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 vw = ww = v3(0, 0, 0);
                 qx = qy = qz = 0.f; qw = 1.f;
 #pragma unroll
-                for (int j = 0; j < 3; j++) { q[j] = q0l[j]; qd[j] = 0.f; torque[j] = 0.f; f_link[j] = v3(0, 0, 0); }
+                for (int j = 0; j < JPL; j++) { q[j] = q0l[j]; qd[j] = 0.f; torque[j] = 0.f; f_link[j] = v3(0, 0, 0); }
                 f_link[3] = v3(0, 0, 0); f_base = v3(0, 0, 0);
             }
         }
@@ -1108,7 +1161,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             const M3 Rb = quat_to_mat(qx, qy, qz, qw);
             M3 Rp = Rb; V3 Pp = v3(0, 0, 0); V6 Vp = {ww, vw};
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
+            for (int j = 0; j < JPL; j++) {
                 const int b = b0 + j;
                 const V3 jp = ld3(M->jpos[b]), ax = ld3(M->axis[b]);
                 const M3 jr = {M->jrot[b][0], M->jrot[b][1], M->jrot[b][2], M->jrot[b][3], M->jrot[b][4],
@@ -1124,10 +1177,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             const V3 r = Pp + mul(Rp, ld3(M->link_pos[foot_link]));
             foot_p = pos + r;
             foot_v = Vp.l + cross(Vp.a, r);
+            foot_zx = Rp.zx; foot_zy = Rp.zy;
         }
         if (live) {
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
+            for (int j = 0; j < JPL; j++) {
                 B.dof_pos[e * A + d0 + j] = q[j];
                 B.dof_vel[e * A + d0 + j] = qd[j];
                 B.torques[e * A + d0 + j] = torque[j];
@@ -1228,7 +1282,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             for (int k = 0; k < 4; k++) f_link[k] = X3(XFL + 3 * k);
             f_base = X3(XFB); foot_p = X3(XFP); foot_v = X3(XFV); last_foot_v = X3(XLFV);
 #pragma unroll
-            for (int j = 0; j < 3; j++) { last_qd[j] = sX[(XLQD + j) * 16 + vlane]; torque[j] = sX[(XTQ + j) * 16 + vlane]; }
+            for (int j = 0; j < JPL; j++) { last_qd[j] = sX[(XLQD + j) * 16 + vlane]; torque[j] = sX[(XTQ + j) * 16 + vlane]; }
         } else {
             blv = ld3(B.base_lin_vel + 3 * e); bav = ld3(B.base_ang_vel + 3 * e);
             pg = ld3(B.projected_gravity + 3 * e); eul = ld3(B.base_euler + 3 * e);
@@ -1239,7 +1293,18 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             foot_v = ld3(B.feet_vel + (e * F + foot_slot) * 3);
             last_foot_v = ld3(B.last_feet_vel + (e * F + foot_slot) * 3);
 #pragma unroll
-            for (int j = 0; j < 3; j++) { last_qd[j] = B.last_dof_vel[e * A + d0 + j]; torque[j] = B.torques[e * A + d0 + j]; }
+            for (int j = 0; j < JPL; j++) { last_qd[j] = B.last_dof_vel[e * A + d0 + j]; torque[j] = B.torques[e * A + d0 + j]; }
+        }
+        if (JPL == 4 && DO_POST) {   // orientation of the foot body (rigid_body_states[:, feet, 3:7] of tron1_sf.py:300) from the joint angles
+            M3 Rp = quat_to_mat(qx, qy, qz, qw);
+#pragma unroll
+            for (int j = 0; j < JPL; j++) {
+                const int b = b0 + j;
+                const M3 jr = {M->jrot[b][0], M->jrot[b][1], M->jrot[b][2], M->jrot[b][3], M->jrot[b][4],
+                               M->jrot[b][5], M->jrot[b][6], M->jrot[b][7], M->jrot[b][8]};
+                Rp = mul(mul(Rp, jr), axis_angle(ld3(M->axis[b]), q[j]));
+            }
+            foot_zx = Rp.zx; foot_zy = Rp.zy;
         }
         if (P > 0) {
             float acc = 0.f;
@@ -1319,7 +1384,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         for (int k = 0; k < LG_R_COUNT; k++) es[k] = SS(k);
         int c = LG_R_COUNT;
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < JPL; j++) {
             soft_lo[j] = SS(c++); soft_hi[j] = SS(c++); rdof_lo[j] = SS(c++); rdof_span[j] = SS(c++);
             nv_q[j] = SS(c++); nv_qd[j] = SS(c++); nv_act[j] = SS(c++);
         }
@@ -1437,7 +1502,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         if (!PLANE && !EEP && p.k.cat_enable) {
             int c_tq = 0, c_qd = 0, c_ar = 0, lo_any = 0, hi_any = 0, c_fast = 0;
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
+            for (int j = 0; j < JPL; j++) {
                 c_tq |= fabsf(torque[j]) > M->effort[d0 + j] ? 1 : 0;
                 c_qd |= fabsf(qd[j]) > T->dof_vel_limits[d0 + j] ? 1 : 0;
                 c_ar |= fabsf(act[j] - last_act[j]) / cdt > T->cat_action_rate ? 1 : 0;
@@ -1480,9 +1545,9 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         };
         const float cmd_xy = sqrtf(cmd0 * cmd0 + cmd1 * cmd1);
         const float cmd_xyz = sqrtf(cmd0 * cmd0 + cmd1 * cmd1 + cmd2 * cmd2);
-        float dq0[3];
+        float dq0[JPL];
 #pragma unroll
-        for (int j = 0; j < 3; j++) dq0[j] = q[j] - q0l[j];
+        for (int j = 0; j < JPL; j++) dq0[j] = q[j] - q0l[j];
         auto gait_reward = [&]() {   // "step" indicator of go2_wtw.py:377-470 / tron1_pf_ee.py:347-424
             const float two_pi = 6.283185307179586f;
             float ph = phi + theta;
@@ -1496,13 +1561,13 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         if (RON(LG_R_ACTION_RATE)) {                              // :495-497
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; j++) { const float d = last_act[j] - act[j]; s += d * d; }
+            for (int j = 0; j < JPL; j++) { const float d = last_act[j] - act[j]; s += d * d; }
             add(LG_R_ACTION_RATE, quad_sum<LEGS>(s));
         }
         if (RON(LG_R_ACTION_SMOOTHNESS)) {                        // :499-503
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; j++) { const float d = act[j] - 2.f * last_act[j] + llast_act[j]; s += d * d; }
+            for (int j = 0; j < JPL; j++) { const float d = act[j] - 2.f * last_act[j] + llast_act[j]; s += d * d; }
             add(LG_R_ACTION_SMOOTHNESS, quad_sum<LEGS>(s));
         }
         if (RON(LG_R_ANG_VEL_XY)) add(LG_R_ANG_VEL_XY, bav.x * bav.x + bav.y * bav.y);   // :462-464
@@ -1524,19 +1589,19 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         if (RON(LG_R_DOF_ACC)) {                                  // :490-493
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; j++) { const float d = (last_qd[j] - qd[j]) / cdt; s += d * d; }
+            for (int j = 0; j < JPL; j++) { const float d = (last_qd[j] - qd[j]) / cdt; s += d * d; }
             add(LG_R_DOF_ACC, quad_sum<LEGS>(s));
         }
         if (RON(LG_R_DOF_CLOSE_TO_DEFAULT)) {                     // :571-573
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; j++) s += dq0[j] * dq0[j];
+            for (int j = 0; j < JPL; j++) s += dq0[j] * dq0[j];
             add(LG_R_DOF_CLOSE_TO_DEFAULT, quad_sum<LEGS>(s));
         }
         if (RON(LG_R_DOF_POS_LIMITS)) {                           // :518-522
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
+            for (int j = 0; j < JPL; j++) {
                 s += -fminf(q[j] - soft_lo[j], 0.f);
                 s += fmaxf(q[j] - soft_hi[j], 0.f);
             }
@@ -1545,25 +1610,25 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         if (RON(LG_R_DOF_POS_STAND_STILL)) {                      // :561-563
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; j++) s += dq0[j] * dq0[j];
+            for (int j = 0; j < JPL; j++) s += dq0[j] * dq0[j];
             add(LG_R_DOF_POS_STAND_STILL, quad_sum<LEGS>(s) * (cmd_xyz < 0.1f ? 1.f : 0.f));
         }
         if (RON(LG_R_DOF_POWER)) {                                // :486-488
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; j++) s += fabsf(torque[j] * qd[j]);
+            for (int j = 0; j < JPL; j++) s += fabsf(torque[j] * qd[j]);
             add(LG_R_DOF_POWER, quad_sum<LEGS>(s));
         }
         if (RON(LG_R_DOF_VEL)) {                                  // :482-484
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; j++) s += qd[j] * qd[j];
+            for (int j = 0; j < JPL; j++) s += qd[j] * qd[j];
             add(LG_R_DOF_VEL, quad_sum<LEGS>(s));
         }
         if (RON(LG_R_DOF_VEL_STAND_STILL)) {                      // :557-559
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; j++) s += fabsf(qd[j]);
+            for (int j = 0; j < JPL; j++) s += fabsf(qd[j]);
             add(LG_R_DOF_VEL_STAND_STILL, quad_sum<LEGS>(s) * (cmd_xyz < 0.1f ? 1.f : 0.f));
         }
         if (RON(LG_R_FEET_AIR_TIME)) {                            // :545-555 (stateful)
@@ -1573,7 +1638,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             const float first = (air > 0.f ? 1.f : 0.f) * (float)filt;
             air += cdt;
             float r = quad_sum<LEGS>((air - hc_feet_air_time_threshold) * first);
-            r *= cmd_xy > 0.1f ? 1.f : 0.f;
+            r *= ((!FLAT && HOT(air_time_cmd_dims) == 3) ? cmd_xyz : cmd_xy) > 0.1f ? 1.f : 0.f;
             air *= filt ? 0.f : 1.f;
             add(LG_R_FEET_AIR_TIME, r);
         }
@@ -1606,19 +1671,28 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             const float vz = land ? foot_v.z : 0.f;
             add(LG_R_FOOT_LANDING_VEL, quad_sum<LEGS>(vz * vz));
         }
-        if (RON(LG_R_HIP_POS)) add(LG_R_HIP_POS, quad_sum<LEGS>(dq0[0] * dq0[0]));   // go2_ee.py:152-159
+        if (RON(LG_R_HIP_POS)) {
+            if constexpr (JPL == 4)   // tron1_sf.py:281-285 (LG_R_HIP_POS_ZERO_COMMAND): dofs [1, 5] = the second joint of each leg, at ~zero command
+                add(LG_R_HIP_POS_ZERO_COMMAND, quad_sum<LEGS>(dq0[1] * dq0[1]) * (cmd_xyz < 0.1f ? 1.f : 0.f));
+            else add(LG_R_HIP_POS, quad_sum<LEGS>(dq0[0] * dq0[0]));   // go2_ee.py:152-159
+        }
         if (RON(LG_R_KEEP_BALANCE)) add(LG_R_KEEP_BALANCE, 1.f);                      // :601-603
         if (RON(LG_R_LIN_VEL_Z)) add(LG_R_LIN_VEL_Z, blv.z * blv.z);                  // :458-460
         if (RON(LG_R_NO_FLY)) {                                   // tron1_pf.py:151-154: exactly one foot on the ground
-            const float cnt = quad_sum<LEGS>(f_link[3].z > 0.1f ? 1.f : 0.f);
+            const float cnt = quad_sum<LEGS>(f_link[3].z > T->no_fly_contact_threshold ? 1.f : 0.f);
             add(LG_R_NO_FLY, cnt == 1.f ? 1.f : 0.f);
         }
         if (RON(LG_R_ORIENTATION)) add(LG_R_ORIENTATION, pg.x * pg.x + pg.y * pg.y);  // :466-468
-        if (RON(LG_R_QUAD_PERIODIC_GAIT)) add(LG_R_QUAD_PERIODIC_GAIT, gait_reward());   // go2_wtw.py:472-484
+        if (RON(LG_R_QUAD_PERIODIC_GAIT)) {
+            if constexpr (JPL == 4) {   // tron1_sf.py:297-308 (LG_R_FOOT_FLAT): world z in the foot frame = third row of the foot's rotation
+                const float tilt = fabsf(foot_zx) + fabsf(foot_zy);
+                add(LG_R_FOOT_FLAT, quad_sum<LEGS>(__expf(-tilt / 0.1f)));
+            } else add(LG_R_QUAD_PERIODIC_GAIT, gait_reward());   // go2_wtw.py:472-484
+        }
         if (RON(LG_R_TORQUES)) {                                  // :478-480
             float s = 0.f;
 #pragma unroll
-            for (int j = 0; j < 3; j++) s += torque[j] * torque[j];
+            for (int j = 0; j < JPL; j++) s += torque[j] * torque[j];
             add(LG_R_TORQUES, quad_sum<LEGS>(s));
         }
         if (RON(LG_R_TRACKING_ANG_VEL)) {                         // :539-543
@@ -1630,7 +1704,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             const float d = WTW ? pos.z - bh_tgt : (P > 0 ? mean_height : pos.z) - hc_base_height_target;
             add(LG_R_TRACKING_BASE_HEIGHT, __expf(-(d * d) / HOT(base_height_sigma)));
         }
-        if (RON(LG_R_TRACKING_FOOT_CLEARANCE)) {                  // go2_wtw.py:507-519
+        if (JPL == 4 && RON(LG_R_TRACKING_FOOT_CLEARANCE)) {      // tron1_sf.py:287-295 (LG_R_KEEP_ANKLE_PITCH_ZERO_IN_AIR): |ankle angle| of the feet in the air
+            const float s = quad_sum<LEGS>(f_link[3].z > 1.0f ? 0.f : fabsf(q[JPL - 1]));
+            add(LG_R_KEEP_ANKLE_PITCH_ZERO_IN_AIR, __expf(-fabsf(s) / 0.2f));
+        }
+        if (JPL != 4 && RON(LG_R_TRACKING_FOOT_CLEARANCE)) {      // go2_wtw.py:507-519
             const float vxy = sqrtf(foot_v.x * foot_v.x + foot_v.y * foot_v.y);
             const float d = foot_p.z - fc_tgt - hc_foot_height_offset;
             add(LG_R_TRACKING_FOOT_CLEARANCE, __expf(-quad_sum<LEGS>(vxy * (d * d)) / hc_foot_clearance_sigma));
@@ -1667,13 +1745,15 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     // reset updates these copies when it redraws the parameters.  vmcnt retires loads and stores in order: a load issued
     // after a run of stores is only usable once those stores have drained, so a load next to each `putp` cost a store
     // round trip apiece (tron1: 25 of them, 17 k of the observation section's 24 k cycles).
-    float ld_kp[3] = {1.f, 1.f, 1.f}, ld_kd[3] = {1.f, 1.f, 1.f}, ld_nv3[3] = {0.f, 0.f, 0.f}, ld_haf[9];
+    float ld_kp[JPL], ld_kd[JPL], ld_nv3[3] = {0.f, 0.f, 0.f}, ld_haf[9];
+#pragma unroll
+    for (int j = 0; j < JPL; j++) ld_kp[j] = ld_kd[j] = 1.f;
     float ld_fric = 1.f, ld_mass = 0.f, ld_com[3] = {0.f, 0.f, 0.f}, ld_push[2] = {0.f, 0.f}, ld_jnt[3] = {0.f, 0.f, 0.f};
 #pragma unroll
     for (int k = 0; k < 9; k++) ld_haf[k] = 0.f;
     if (DO_RESET && hc_obs_layout != LG_OBS_GO2) {   // ahead of the reset block's stores too; a reset updates these copies
 #pragma unroll
-        for (int j = 0; j < 3; j++) { ld_kp[j] = B.kp_scale[e * A + d0 + j]; ld_kd[j] = B.kd_scale[e * A + d0 + j]; }
+        for (int j = 0; j < JPL; j++) { ld_kp[j] = B.kp_scale[e * A + d0 + j]; ld_kd[j] = B.kd_scale[e * A + d0 + j]; }
         if (P > 0 && HOT(o_feet_terrain_info)) {
 #pragma unroll
             for (int k = 0; k < 3; k++) ld_nv3[k] = B.normal_vector_around_feet[((size_t)e * F + foot_slot) * 3 + k];
@@ -1747,10 +1827,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 sit = us < hc_sit_percent;
             }
             // _reset_dofs (go2.py:17-37): default + U(range) per joint, zero velocity
-            float ud[3];
-            rs.draw3(HOT(slots.reset_dof) + d0, ud[0], ud[1], ud[2]);
+            float ud[JPL];
+            if constexpr (JPL == 4) rs.draw4(HOT(slots.reset_dof) + d0, ud[0], ud[1], ud[2], ud[3]);
+            else rs.draw3(HOT(slots.reset_dof) + d0, ud[0], ud[1], ud[2]);
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
+            for (int j = 0; j < JPL; j++) {
                 q[j] = sit ? T->sit_dof_pos[d0 + j]
                            : q0l[j] + (rdof_span[j] * ud[j] + rdof_lo[j]);
                 qd[j] = 0.f;
@@ -1791,7 +1872,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             air = 0.f; ep_len = 0; fail_buf = 0; last_foot_v = v3(0, 0, 0);
             if (live) {
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
+                for (int j = 0; j < JPL; j++) {
                     B.dof_pos[e * A + d0 + j] = q[j];
                     B.dof_vel[e * A + d0 + j] = 0.f;
                     B.last_dof_vel[e * A + d0 + j] = 0.f;
@@ -1799,11 +1880,16 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 }
                 st3(B.last_feet_vel + (e * F + foot_slot) * 3, v3(0, 0, 0));
                 if (HOT(dr_pd_on)) {   // genesis_simulator.py:735-739
-                    float up[3], ud2[3];
-                    rs.draw3(HOT(slots.dr_kp) + d0, up[0], up[1], up[2]);
-                    rs.draw3(HOT(slots.dr_kd) + d0, ud2[0], ud2[1], ud2[2]);
+                    float up[JPL], ud2[JPL];
+                    if constexpr (JPL == 4) {
+                        rs.draw4(HOT(slots.dr_kp) + d0, up[0], up[1], up[2], up[3]);
+                        rs.draw4(HOT(slots.dr_kd) + d0, ud2[0], ud2[1], ud2[2], ud2[3]);
+                    } else {
+                        rs.draw3(HOT(slots.dr_kp) + d0, up[0], up[1], up[2]);
+                        rs.draw3(HOT(slots.dr_kd) + d0, ud2[0], ud2[1], ud2[2]);
+                    }
 #pragma unroll
-                    for (int j = 0; j < 3; j++) {
+                    for (int j = 0; j < JPL; j++) {
                         ld_kp[j] = HOT(dr_kp_span) * up[j] + HOT(dr_kp_lo); B.kp_scale[e * A + d0 + j] = ld_kp[j];
                         ld_kd[j] = HOT(dr_kd_span) * ud2[j] + HOT(dr_kd_lo); B.kd_scale[e * A + d0 + j] = ld_kd[j];
                     }
@@ -1913,11 +1999,13 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         const int ns = HOT(slots.noise);
         // uniforms for the noisy entries only (commands and actions carry zero noise scale): q, qd per lane,
         // gravity + ang vel on the lead lane
-        float uq[3] = {0.5f, 0.5f, 0.5f}, uqd[3] = {0.5f, 0.5f, 0.5f}, ub[6] = {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f};
+        float uq[JPL], uqd[JPL], uact[JPL], ub[6] = {0.5f, 0.5f, 0.5f, 0.5f, 0.5f, 0.5f};
+#pragma unroll
+        for (int j = 0; j < JPL; j++) uq[j] = uqd[j] = uact[j] = 0.5f;
         if (nz) {
             if (rs.in) {
 #pragma unroll
-                for (int j = 0; j < 3; j++) { uq[j] = rs.in[ns + 9 + d0 + j]; uqd[j] = rs.in[ns + 9 + A + d0 + j]; }
+                for (int j = 0; j < JPL; j++) { uq[j] = rs.in[ns + 9 + d0 + j]; uqd[j] = rs.in[ns + 9 + A + d0 + j]; }
                 if (lead) {
 #pragma unroll
                     for (int k = 0; k < 6; k++) ub[k] = rs.in[ns + 3 + k];
@@ -1925,9 +2013,14 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             } else {
                 // two Philox blocks per lane, all four outputs used: the fourth ones of the env's lanes are the base's
                 // six uniforms (a call is ~800 cycles and a lead-only call stalls the whole wave)
-                float sp0, sp1;
-                rs.block4(2 * leg, uq[0], uq[1], uq[2], sp0);
-                rs.block4(2 * leg + 1, uqd[0], uqd[1], uqd[2], sp1);
+                float sp0 = 0.5f, sp1 = 0.5f;
+                if constexpr (JPL == 4) {   // all four outputs go to the joints; the base's six uniforms come from two more blocks
+                    rs.block4(2 * leg, uq[0], uq[1], uq[2], uq[3]);
+                    rs.block4(2 * leg + 1, uqd[0], uqd[1], uqd[2], uqd[3]);
+                } else {
+                    rs.block4(2 * leg, uq[0], uq[1], uq[2], sp0);
+                    rs.block4(2 * leg + 1, uqd[0], uqd[1], uqd[2], sp1);
+                }
                 auto bcq = [](float v, int k) {   // lane k of the quad (the env's lanes), k compile-time after unrolling
                     const int x = __float_as_int(v);
                     return __int_as_float(k == 0 ? __builtin_amdgcn_update_dpp(0, x, 0x00, 0xF, 0xF, false)
@@ -1937,20 +2030,22 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 if (LEGS == 4) {
                     ub[0] = bcq(sp0, 0); ub[1] = bcq(sp1, 0); ub[2] = bcq(sp0, 1); ub[3] = bcq(sp1, 1); ub[4] = bcq(sp0, 2); ub[5] = bcq(sp1, 2);
                 } else {   // two lanes per env: one more block, same id on both lanes of the pair (only the lead's copy is used)
+                    if constexpr (JPL == 4) { float d0_, d1_; rs.block4(2 * LEGS + 1, sp0, sp1, d0_, d1_); }
                     ub[0] = sp0; ub[1] = sp1;
                     rs.block4(2 * LEGS, ub[2], ub[3], ub[4], ub[5]);
                 }
             }
         }
-        float uact[3] = {0.5f, 0.5f, 0.5f}, uclk[2] = {0.5f, 0.5f};
+        float uclk[2] = {0.5f, 0.5f};
         if (nz && hc_noise_act0 != 0.f) {  // uniform index: scalar load   // tron1_pf_ee.py:338-342 (quirk 4): actions and clock are noisy too
             if (rs.in) {
 #pragma unroll
-                for (int j = 0; j < 3; j++) uact[j] = rs.in[ns + 9 + 2 * A + d0 + j];
+                for (int j = 0; j < JPL; j++) uact[j] = rs.in[ns + 9 + 2 * A + d0 + j];
                 uclk[0] = rs.in[ns + 9 + 3 * A + foot_slot]; uclk[1] = rs.in[ns + 9 + 3 * A + LEGS + foot_slot];
             } else {
                 float dummy;
-                rs.block3(2 * LEGS + 2 + leg, uact[0], uact[1], uact[2]);
+                if constexpr (JPL == 4) rs.block4(2 * LEGS + 2 + leg, uact[0], uact[1], uact[2], uact[3]);
+                else rs.block3(2 * LEGS + 2 + leg, uact[0], uact[1], uact[2]);
                 rs.block3(3 * LEGS + 2 + leg, uclk[0], uclk[1], dummy);
             }
         }
@@ -1976,7 +2071,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         auto putp = [&](int idx, float v) { const float c = clampf(v, -co, co); pn[idx] = c; if (has_pn2) pn2[idx] = c; };
         if (live) {
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
+            for (int j = 0; j < JPL; j++) {
                 put(9 + d0 + j, (q[j] - q0l[j]) * hc_obs_scale_dof_pos, uq[j], nv_q[j]);
                 put(9 + A + d0 + j, qd[j] * hc_obs_scale_dof_vel, uqd[j], nv_qd[j]);
                 put(9 + 2 * A + d0 + j, act[j], uact[j], nv_act[j]);
@@ -1995,7 +2090,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 put(49 + foot_slot, cs, 0.5f, 0.f);
                 put(57 + foot_slot, theta, 0.5f, 0.f);
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
+                for (int j = 0; j < JPL; j++) {
                     putp(FR + 10 + d0 + j, ld_kp[j]);
                     putp(FR + 10 + A + d0 + j, ld_kd[j]);
                 }
@@ -2016,7 +2111,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             float *lab = B.labels_buf + ((size_t)cs * N + e) * hc_num_labels;
             if (live) {
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
+                for (int j = 0; j < JPL; j++) {
                     putp(FR + 7 + d0 + j, ld_kp[j] - HOT(kp_offset));
                     putp(FR + 7 + A + d0 + j, ld_kd[j] - HOT(kd_offset));
                 }
@@ -2070,7 +2165,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 put(9 + 3 * A + F + foot_slot, cs, uclk[1], nv_clk[1]);
                 ts[4 + foot_slot] = theta; ts[6 + foot_slot] = sn; ts[6 + F + foot_slot] = cs; ts[10 + foot_slot] = expC;
 #pragma unroll
-                for (int j = 0; j < 3; j++) {
+                for (int j = 0; j < JPL; j++) {
                     putp(oDR + 7 + d0 + j, ld_kp[j] - HOT(kp_offset));
                     putp(oDR + 7 + A + d0 + j, ld_kd[j] - HOT(kd_offset));
                 }
@@ -2136,7 +2231,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     if (kind == LG_SEG_DR) {
                         if (live) {
 #pragma unroll
-                            for (int j = 0; j < 3; j++) { Wr(off + 7 + d0 + j, ld_kp[j] - HOT(kp_offset)); Wr(off + 7 + A + d0 + j, ld_kd[j] - HOT(kd_offset)); }
+                            for (int j = 0; j < JPL; j++) { Wr(off + 7 + d0 + j, ld_kp[j] - HOT(kp_offset)); Wr(off + 7 + A + d0 + j, ld_kd[j] - HOT(kd_offset)); }
                         }
                         if (lead) {
                             Wr(off + 0, ld_fric - HOT(friction_offset)); Wr(off + 1, ld_mass);
@@ -2193,7 +2288,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     } else if (kind == LG_SEG_LAST_ACTIONS) {     // a_{t-1}: zero for an env that was just reset
                         if (live) {
 #pragma unroll
-                            for (int j = 0; j < 3; j++) Wr(off + d0 + j, last_act[j]);
+                            for (int j = 0; j < JPL; j++) Wr(off + d0 + j, last_act[j]);
                         }
                     } else if (kind == LG_SEG_DR_BASE) {
                         if (lead) {
@@ -2203,6 +2298,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                         }
                     } else if (kind == LG_SEG_FEET_AIR_TIME) {
                         if (live) Wr(off + foot_slot, air);
+                    } else if (kind == LG_SEG_KP || kind == LG_SEG_KD) {
+                        if (live) {
+#pragma unroll
+                            for (int j = 0; j < JPL; j++) Wr(off + d0 + j, kind == LG_SEG_KP ? ld_kp[j] - HOT(kp_offset) : ld_kd[j] - HOT(kd_offset));
+                        }
                     } else if (kind == LG_SEG_FOOT_CLEARANCE) {
                         if (live) Wr(off + foot_slot, clampf(foot_p.z - foot_hmean - hc_foot_height_offset, -1.f, 1.f));
                     }   // LG_SEG_FRAME / LG_SEG_NEXT_STATE: written entry by entry in put()
@@ -2222,7 +2322,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     // last == llast == a_t, which makes action_smoothness == action_rate
     if (DO_RESET && hc_double_shift && live) {
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < JPL; j++) {
             B.llast_actions[e * A + d0 + j] = reset ? 0.f : last_act[j];
             B.last_actions[e * A + d0 + j] = act[j];
         }
@@ -2250,11 +2350,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     STAMP(11);
 }
 
-template <int LEGS, unsigned PH, int PROF = 0>
+template <int LEGS, unsigned PH, int PROF = 0, int JPL = 3>
 __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_STG * BLOCK];
     __shared__ int sHot[256 + BLOCK];
-    env_step_body<LEGS, PH, false, PROF>(p, sMraw, sHot, nullptr, nullptr, blockIdx.x * BLOCK + threadIdx.x, threadIdx.x & 63);
+    env_step_body<LEGS, PH, false, PROF, JPL>(p, sMraw, sHot, nullptr, nullptr, blockIdx.x * BLOCK + threadIdx.x, threadIdx.x & 63);
 }
 
 #include "lg_quad.h"
@@ -2295,23 +2395,27 @@ static int upload_hot(LgEngine *h) {
 }
 
 static int validate_model(const LgModelDesc *m) {
-    if (m->n_legs != 2 && m->n_legs != 4) return fail("lg_create: engine supports 2 or 4 legs of 3 revolute joints");
-    if (m->n_bodies != 1 + 3 * m->n_legs) return fail("lg_create: n_bodies must be 1 + 3*n_legs");
+    if (m->n_legs != 2 && m->n_legs != 4) return fail("lg_create: engine supports 2 or 4 legs");
+    const int J = m->n_bodies == 1 + 3 * m->n_legs ? 3 : 4;     // joints per leg
+    if (m->n_bodies != 1 + J * m->n_legs || (J == 4 && m->n_legs != 2))
+        return fail("lg_create: n_bodies must be 1 + 3*n_legs (2 or 4 legs of 3 revolute joints) or 1 + 4*2 (two legs of 4)");
     if (m->n_links < m->n_bodies || m->n_links > LG_MAX_LINKS) return fail("lg_create: bad n_links");
     if (m->n_spheres < m->n_legs || m->n_spheres > LG_MAX_SPHERES) return fail("lg_create: bad n_spheres");
     for (int l = 0; l < m->n_legs; l++) {
         int fl = m->foot_link[l], fsph = m->foot_sphere[l];
         if (fl < 4 || fl >= m->n_links) return fail("lg_create: foot link index out of range");
-        if (fsph < 0 || fsph >= m->n_spheres || m->sph_body[fsph] != 3 + 3 * l) return fail("lg_create: foot sphere must sit on the last body of its leg");
-        // kernel assumes link rows [hip, thigh, calf, foot] of a leg are contiguous
+        if (fsph < 0 || fsph >= m->n_spheres || m->sph_body[fsph] != J + J * l) return fail("lg_create: foot sphere must sit on the last body of its leg");
+        // kernel assumes the four link rows of a leg are contiguous: [hip, thigh, calf, foot] (the foot a kept link of the calf body) or,
+        // with four joints, the four bodies themselves (the foot is the last one)
         for (int k = 0; k < 3; k++)
-            if (m->link_body[fl - 3 + k] != 1 + 3 * l + k) return fail("lg_create: leg links must be contiguous and end with the foot");
-        if (m->link_body[fl] != 3 + 3 * l) return fail("lg_create: foot link must move with the last body of its leg");
+            if (m->link_body[fl - 3 + k] != 1 + J * l + k) return fail("lg_create: leg links must be contiguous and end with the foot");
+        if (m->link_body[fl] != J + J * l) return fail("lg_create: foot link must move with the last body of its leg");
     }
     if (m->link_body[0] != 0) return fail("lg_create: link 0 must be the base");
-    for (int l = 0; l < m->n_legs; l++) {   // register-resident sphere tables of the kernel: 2 / 2 / 5 (+foot) per chain body
-        const int *st = m->body_sph_start + 1 + 3 * l;
-        if (st[1] - st[0] > 2 || st[2] - st[1] > 2 || st[3] - st[2] > 6) return fail("lg_create: too many collision spheres on a leg body (max 2/2/5+foot)");
+    for (int l = 0; l < m->n_legs; l++) {   // register-resident sphere tables of the kernel: 2 / 2 / [3 /] 5 (+foot) per chain body
+        const int *st = m->body_sph_start + 1 + J * l;
+        if (st[1] - st[0] > 2 || st[2] - st[1] > 2 || (J == 4 && st[3] - st[2] > 3) || st[J] - st[J - 1] > 6)
+            return fail("lg_create: too many collision spheres on a leg body (max 2/2/5+foot, or 2/2/3/5+foot with four joints)");
     }
     if ((m->body_sph_start[1] - m->body_sph_start[0] + m->n_legs - 1) / m->n_legs > 4) return fail("lg_create: too many base collision spheres (max 4 per leg lane)");
     for (int b = 0; b <= m->n_bodies; b++)
@@ -2418,7 +2522,7 @@ static int prof_begin(LgEngine *h, hipStream_t st) {
         else hipLaunchKernelGGL(kern, grid_, block, 0, st, p); } while (0)
 
 static bool flat_noise_ok(const LgEngine *h) {   // commands and actions carry no observation noise (go2.py:92-117)
-    const int A = 3 * h->model.n_legs;
+    const int A = h->model.n_bodies - 1;
     for (int i = 0; i < 3; i++) if (h->task.noise_vec[i] != 0.f) return false;
     for (int i = 0; i < A; i++) if (h->task.noise_vec[9 + 2 * A + i] != 0.f) return false;
     return true;
@@ -2430,7 +2534,8 @@ static bool flat_profile(const LgEngine *h) {
     const LgBuffers &b = h->bufs;
     return t.obs_layout == LG_OBS_GO2 && t.gait_mode == 0 && t.double_shift == 0 && t.obs_stack == 1 && t.obs_slack == 0 && t.priv_frame == 0 &&
            t.priv_stack <= 1 && t.num_priv_obs == 0 && t.terrain_curriculum == 0 && t.custom_origins == 0 && t.sit_percent == 0.f &&
-           t.behavior_resample_steps == 0 && t.num_labels == 0 && t.cat_enable == 0 && t.noise_vec[9 + 6 * h->model.n_legs] == 0.f &&
+           t.behavior_resample_steps == 0 && t.num_labels == 0 && t.cat_enable == 0 && t.noise_vec[9 + 6 * h->model.n_legs] == 0.f && t.air_time_cmd_dims != 3 &&
+           h->model.n_bodies == 1 + 3 * h->model.n_legs &&
            o.n_height_points == 0 && o.terrain_rows == 0 && o.feet_terrain_info == 0 && !b.link_contact_states && !b.task_state && !h->hf &&
            !b.rand_in && !b.joint_armature && !t.dr_joint_on && !t.dr_pd_on && t.reset_lin_vel_span == 0.f && t.reset_ang_vel_span == 0.f && flat_noise_ok(h) &&
            // reward terms the component-layout tail (lg_quad.h) does not carry: gait clocks, biped and wtw-only terms
@@ -2460,7 +2565,7 @@ static int rough_profile(const LgEngine *h) {
     return 0;
 }
 
-template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *actions, int64_t counter, hipStream_t st) {
+template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, const float *actions, int64_t counter, hipStream_t st) {
     KParams p;
     p.M = h->d_model; p.O = h->d_opts; p.T = h->d_task; p.H = h->d_hot; p.hf = h->hf; p.B = h->bufs; p.actions = actions; p.counter = counter;
     p.jrot_identity = 1;
@@ -2474,7 +2579,7 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
         for (int j = 0; j < 3; j++) {
             int code = -2;
             for (int l = 0; l < LEGS; l++) {
-                const float *ax = h->model.axis[1 + 3 * l + j];
+                const float *ax = h->model.axis[1 + JPL * l + j];
                 int c = -1;
                 for (int k = 0; k < 3; k++)
                     if (fabsf(fabsf(ax[k]) - 1.f) < 1e-6f && fabsf(ax[(k + 1) % 3]) < 1e-6f && fabsf(ax[(k + 2) % 3]) < 1e-6f) c = k;
@@ -2515,10 +2620,10 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
     // auto: component-per-lane while that needs at most two waves per SIMD (1024 SIMDs).  Measured go2, us per step,
     // component vs leg layout: 4096 envs 34.7 / 56.6, 8192: 50.9 / 55.2, 12288: 69.2 / 55.5, 16384: 92 / 60
     // the component-per-lane kernel is specialised for identity joint frames and hip-x / thigh-y / knee-y axes (lg_quad.h)
-    const bool quad_ok = p.jrot_identity && p.k.joint_axis[0] == 0 && p.k.joint_axis[1] == 1 && p.k.joint_axis[2] == 1;
+    const bool quad_ok = JPL == 3 && p.jrot_identity && p.k.joint_axis[0] == 0 && p.k.joint_axis[1] == 1 && p.k.joint_axis[2] == 1;
     if (h->opts.sim_layout == 2 && !quad_ok) return fail("lg_step: sim_layout 2 needs identity joint frames and x / y / y joint axes");
     const int layout = h->opts.sim_layout ? h->opts.sim_layout : ((quad_ok && (long long)threads * 4 <= 2048LL * BLOCK) ? 2 : 1);
-    if (layout == 2 && (ph & LG_PHASE_SIM)) {
+    if constexpr (JPL == 3) if (layout == 2 && (ph & LG_PHASE_SIM)) {
         dim3 qgrid((threads * 4 + BLOCK - 1) / BLOCK);
         const bool pre = (ph & LG_PHASE_PRE) != 0;
         if (!pre && !actions) p.actions = nullptr;
@@ -2539,8 +2644,8 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
         else LG_LAUNCH(pi, (quad_sim_kernel<LEGS, false, 0u>), qgrid);
         HIPCHK(hipGetLastError());
         if (!fuse && rest) {
-            if (rest == (LG_PHASE_POST | LG_PHASE_RESET)) LG_LAUNCH_LAST(pi, (env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET>), grid);
-            else if (rest == LG_PHASE_POST) LG_LAUNCH_LAST(pi, (env_step_kernel<LEGS, LG_PHASE_POST>), grid);
+            if (rest == (LG_PHASE_POST | LG_PHASE_RESET)) LG_LAUNCH_LAST(pi, (env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET, 0, JPL>), grid);
+            else if (rest == LG_PHASE_POST) LG_LAUNCH_LAST(pi, (env_step_kernel<LEGS, LG_PHASE_POST, 0, JPL>), grid);
             else return fail("lg_step: unsupported phase combination");
         }
         HIPCHK(hipGetLastError());
@@ -2549,21 +2654,21 @@ template <int LEGS> static int launch(LgEngine *h, uint32_t ph, const float *act
     const int pi = (ph & LG_PHASE_SIM) ? prof_begin(h, st) : -1;
     switch (ph) {
     case LG_PHASE_ALL:
-        if (flat_profile(h)) LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_ALL, 1>), grid);     // large go2 batches: same FLAT constants
-        else LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_ALL>), grid);
+        if constexpr (JPL == 3) { if (flat_profile(h)) { LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_ALL, 1>), grid); break; } }   // large go2 batches: same FLAT constants
+        LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_ALL, 0, JPL>), grid);
         break;
-    case LG_PHASE_SIM: LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_SIM>), grid); break;
+    case LG_PHASE_SIM: LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_SIM, 0, JPL>), grid); break;
     case LG_PHASE_PRE | LG_PHASE_POST | LG_PHASE_RESET:
-        hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_PRE | LG_PHASE_POST | LG_PHASE_RESET>), grid, block, 0, st, p); break;
+        hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_PRE | LG_PHASE_POST | LG_PHASE_RESET, 0, JPL>), grid, block, 0, st, p); break;
     case LG_PHASE_PRE | LG_PHASE_SIM | LG_PHASE_POST:
-        LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_PRE | LG_PHASE_SIM | LG_PHASE_POST>), grid); break;
-    case LG_PHASE_PRE | LG_PHASE_SIM: LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_PRE | LG_PHASE_SIM>), grid); break;
-    case LG_PHASE_RESET: hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_RESET>), grid, block, 0, st, p); break;
+        LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_PRE | LG_PHASE_SIM | LG_PHASE_POST, 0, JPL>), grid); break;
+    case LG_PHASE_PRE | LG_PHASE_SIM: LG_LAUNCH(pi, (env_step_kernel<LEGS, LG_PHASE_PRE | LG_PHASE_SIM, 0, JPL>), grid); break;
+    case LG_PHASE_RESET: hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_RESET, 0, JPL>), grid, block, 0, st, p); break;
     case LG_PHASE_PRE | LG_PHASE_POST:
-        hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_PRE | LG_PHASE_POST>), grid, block, 0, st, p); break;
+        hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_PRE | LG_PHASE_POST, 0, JPL>), grid, block, 0, st, p); break;
     case LG_PHASE_POST | LG_PHASE_RESET:
-        hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET>), grid, block, 0, st, p); break;
-    case LG_PHASE_POST: hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST>), grid, block, 0, st, p); break;
+        hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET, 0, JPL>), grid, block, 0, st, p); break;
+    case LG_PHASE_POST: hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST, 0, JPL>), grid, block, 0, st, p); break;
     default: return fail("lg_step: unsupported phase combination (ALL, SIM, PRE|SIM, PRE|POST|RESET, PRE|SIM|POST, PRE|POST, POST|RESET, POST, RESET)");
     }
     HIPCHK(hipGetLastError());
@@ -2605,6 +2710,7 @@ extern "C" int lg_step(LgHandle h, uint32_t phases, const float *actions, int64_
         else HIPCHK(hipEventCreateWithFlags(&h->ra_ev[slot], hipEventDisableTiming));
         HIPCHK(hipEventRecord(h->ra_ev[slot], st));
     }
+    if (h->model.n_bodies == 1 + 4 * h->model.n_legs) return launch<2, 4>(h, phases, actions, counter, st);   // validate_model: two legs
     return h->model.n_legs == 4 ? launch<4>(h, phases, actions, counter, st) : launch<2>(h, phases, actions, counter, st);
 }
 

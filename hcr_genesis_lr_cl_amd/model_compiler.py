@@ -27,7 +27,7 @@ from dataclasses import dataclass, field
 
 import numpy as np
 
-JOINTS_PER_LEG = 3
+JOINTS_PER_LEG = 3          # go2, TRON1 point foot; the TRON1 sole-foot biped has 4 (two legs)
 MAX_LEGS = 4
 MAX_BODIES = 1 + MAX_LEGS * JOINTS_PER_LEG
 MAX_LINKS = 24
@@ -183,6 +183,24 @@ def _spheres_for(kind, params, xyz, R):
     return out
 
 
+def _sole_spheres(size, xyz, R):
+    """A box that IS a foot body (TRON1 sole foot, SF_TRON1A/urdf/robot.urdf ankle_*_Link: 0.2 x 0.06 x 0.03): the inscribed sphere
+    at the box centre -- the leg's foot sphere, solved against the exact operational-space inertia like a point foot -- followed by
+    the four corners of the face turned away from the joint (the sole) as zero-radius points, which hold the foot flat."""
+    s = np.array(size, dtype=float)
+    k = int(np.argmin(s))                       # thickness axis
+    c_joint = R.T @ (-xyz)                      # joint origin seen from the box centre, box axes
+    sgn = -1.0 if c_joint[k] > 0 else 1.0       # the sole is the face on the far side of the joint
+    out = [(xyz.copy(), 0.5 * s[k])]
+    a, b = [i for i in range(3) if i != k]
+    for sa in (-0.5, 0.5):
+        for sb in (-0.5, 0.5):
+            v = np.zeros(3)
+            v[a], v[b], v[k] = sa * s[a], sb * s[b], sgn * 0.5 * s[k]
+            out.append((xyz + R @ v, 0.0))
+    return out
+
+
 class RobotModel:
     """Flat model; see module docstring.  ``arrays`` holds everything numeric."""
 
@@ -200,7 +218,11 @@ class RobotModel:
 
     @property
     def n_dof(self):
-        return self.n_legs * JOINTS_PER_LEG
+        return int(self.arrays["n_bodies"]) - 1
+
+    @property
+    def joints_per_leg(self):
+        return self.n_dof // self.n_legs
 
     @property
     def n_links(self):
@@ -265,12 +287,18 @@ def compile_urdf(path, dof_names, links_to_keep, foot_name, base_link_name=None,
         by_parent.setdefault(j.parent, []).append(j)
 
     n_dof = len(dof_names)
-    if n_dof % JOINTS_PER_LEG:
-        raise ValueError("dof_names must list 3 joints per leg")
-    n_legs = n_dof // JOINTS_PER_LEG
-    if n_legs > MAX_LEGS:
-        raise ValueError("too many legs")
     jbyname = {j.name: j for j in joints}
+    # legs = actuated joints hanging (through fixed joints) off the base; every leg is a serial chain of jpl joints
+    def _body_above(link):
+        while link != base and jmap_child[link].jtype == "fixed":
+            link = jmap_child[link].parent
+        return link
+    n_legs = sum(1 for dn in dof_names if dn in jbyname and _body_above(jbyname[dn].parent) == base)
+    if n_legs == 0 or n_dof % n_legs:
+        raise ValueError("dof_names must list the same number of joints for every leg")
+    jpl = n_dof // n_legs
+    if n_legs > MAX_LEGS or (jpl, n_legs) not in ((3, 2), (3, 4), (4, 2)):
+        raise ValueError(f"unsupported topology: {n_legs} legs of {jpl} joints (supported: 2 or 4 legs of 3, 2 legs of 4)")
     for dn in dof_names:
         if dn not in jbyname or jbyname[dn].jtype not in ("revolute", "continuous"):
             raise ValueError(f"dof {dn} is not a revolute joint of {path}")
@@ -301,10 +329,10 @@ def compile_urdf(path, dof_names, links_to_keep, foot_name, base_link_name=None,
         jrot[1 + d] = R.reshape(-1)
         a = j.axis / np.linalg.norm(j.axis)
         axis[1 + d] = a
-        leg, k = divmod(d, JOINTS_PER_LEG)
+        leg, k = divmod(d, jpl)
         expect = 0 if k == 0 else d  # body index of expected parent
         if parent[1 + d] != expect:
-            raise ValueError(f"{dn}: tree is not base + {n_legs} serial 3-joint legs in dof order")
+            raise ValueError(f"{dn}: tree is not base + {n_legs} serial {jpl}-joint legs in dof order")
 
     # fold every remaining link (fixed children) into its body
     mass = np.zeros(nb)
@@ -318,7 +346,8 @@ def compile_urdf(path, dof_names, links_to_keep, foot_name, base_link_name=None,
         if lk.mass > 0.0:
             parts[body].append((lk.mass, xyz + R @ lk.com, R @ lk.inertia @ R.T))
         for kind, params, cxyz, cR in lk.collisions:
-            for (p, r) in _spheres_for(kind, params, cxyz, cR):
+            sole = kind == "box" and lname in body_of_link and foot_name in lname
+            for (p, r) in (_sole_spheres(params, cxyz, cR) if sole else _spheres_for(kind, params, cxyz, cR)):
                 spheres.append((body, rep_link, xyz + R @ p, r))
         for j in by_parent.get(lname, []):
             if j.child in body_of_link:
@@ -382,11 +411,20 @@ def compile_urdf(path, dof_names, links_to_keep, foot_name, base_link_name=None,
     foot_sphere = np.full(MAX_LEGS, -1, np.int32)
     for li in foot_links:
         b = link_body[li]
-        leg = (b - 1) // JOINTS_PER_LEG
-        if b == 0 or (b - 1) % JOINTS_PER_LEG != JOINTS_PER_LEG - 1:
+        leg = (b - 1) // jpl
+        if b == 0 or (b - 1) % jpl != jpl - 1:
             raise ValueError(f"foot {link_names[li]} is not on the last body of a leg")
         cand = [i for i in range(ns) if sph_link[i] == li]
-        if len(cand) != 1:
+        if link_names[li] in body_of_link:
+            # the foot is the chain's last body itself (sole foot): its first sphere is the sole centre (_sole_spheres)
+            if not cand:
+                raise ValueError(f"foot body {link_names[li]} has no collision geometry")
+            # sole corners: the kernel adds the ankle joint's own compliance at the contact point (lg_kernel.hip sphere_contact);
+            # what is stored here covers every other way the corner can give: shank + foot as a point mass
+            for i in cand[1:]:
+                sph_w[i] = 1.0 / (mass[b] + mass[b - 1])
+            cand = cand[:1]
+        elif len(cand) != 1:
             raise ValueError(f"foot {link_names[li]} must carry exactly one collision sphere")
         foot_link[leg] = li
         foot_sphere[leg] = cand[0]

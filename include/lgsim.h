@@ -27,7 +27,7 @@
 extern "C" {
 #endif
 
-#define LG_JPL 3          /* joints per leg (serial chain) */
+#define LG_MAX_JPL 4      /* joints per leg (serial chain): (n_bodies - 1) / n_legs = 3 (go2, TRON1 point foot) or 4 (TRON1 sole foot) */
 #define LG_MAX_LEGS 4
 #define LG_MAX_DOF 12
 #define LG_MAX_BODIES 13  /* floating base + one body per dof */
@@ -47,7 +47,9 @@ extern "C" {
 /* ---- robot model (output of hcr_genesis_lr_cl_amd/model_compiler.py) -------------------
  * Stands in for gs.morphs.URDF(merge_fixed_links=True, links_to_keep=feet)
  * (genesis_simulator.py:303-313).  Body 0 is the floating base, body 1+d carries dof d
- * (policy order, cfg.asset.dof_names); leg l owns dofs 3l..3l+2. */
+ * (policy order, cfg.asset.dof_names); with J = (n_bodies - 1) / n_legs joints per leg, leg l owns dofs J l .. J l + J - 1.
+ * The foot of a leg is a reported link on the chain's last body: a kept fixed link carrying one sphere (go2, TRON1 point foot)
+ * or, for 4-joint legs, the last body itself (TRON1 sole foot, tron1_sf_config.py:82-84) whose foot_sphere is the sole centre. */
 typedef struct LgModelDesc {
     int32_t n_legs, n_bodies, n_links, n_spheres;
     float mass[LG_MAX_BODIES];
@@ -118,6 +120,11 @@ enum LgReward {
     LG_R_TERMINATION, /* added after the positive clip (legged_robot.py:163-168) */
     LG_R_COUNT
 };
+/* Terms that only exist for the 4-joint sole-foot biped (tron1_sf.py:281-308) share the ids of terms that only exist for
+ * quadrupeds; which meaning an id has follows from the model (joints per leg), the episode-sum / scale arrays are unchanged. */
+#define LG_R_HIP_POS_ZERO_COMMAND LG_R_HIP_POS                          /* tron1_sf.py:281-285 */
+#define LG_R_FOOT_FLAT LG_R_QUAD_PERIODIC_GAIT                          /* tron1_sf.py:297-308 */
+#define LG_R_KEEP_ANKLE_PITCH_ZERO_IN_AIR LG_R_TRACKING_FOOT_CLEARANCE  /* tron1_sf.py:287-295 */
 
 /* observation layouts (reference compute_observations overrides) */
 enum LgObsLayout {
@@ -146,7 +153,9 @@ enum LgObsSeg {
     LG_SEG_NEXT_STATE,    /* the actor frame without noise, actions * action_scale (go2_dreamwaq.py:66-74) */
     LG_SEG_LAST_ACTIONS,  /* last_actions, A (tron1_pf.py:36) */
     LG_SEG_DR_BASE,       /* friction - offset, added mass, CoM 3, push xy 2 (tron1_pf.py:37-41) */
-    LG_SEG_FEET_AIR_TIME  /* feet_air_time, F (tron1_pf.py:42) */
+    LG_SEG_FEET_AIR_TIME, /* feet_air_time, F (tron1_pf.py:42) */
+    LG_SEG_KP,            /* kp_scale - kp_offset, A (tron1_sf.py:40-41) */
+    LG_SEG_KD             /* kd_scale - kd_offset, A (tron1_sf.py:42-43) */
 };
 #define LG_MAX_SEGS 8
 typedef struct LgObsProgram {
@@ -213,6 +222,8 @@ typedef struct LgTaskCfg {
     float tracking_sigma, base_height_target, foot_clearance_target, foot_height_offset;
     float foot_clearance_sigma, about_landing_threshold, feet_air_time_threshold;
     float base_height_sigma, euler_sigma, foot_distance_threshold;
+    float no_fly_contact_threshold;  /* foot force z above which _reward_no_fly counts a contact: 0.1 (tron1_pf.py:151-154), 1.0 (tron1_sf.py:275-278) */
+    int32_t air_time_cmd_dims;       /* _reward_feet_air_time is gated by |commands[:, :dims]| > 0.1: 2 (legged_robot.py:553), 3 (tron1_sf.py:264) */
     int32_t foot_clearance_ref;      /* terrain height _reward_foot_clearance measures from: 0 none (legged_robot.py:575-588), 1 mean of the
                                       * 9 heights around the foot (go2_ee.py:136-150, go2_ts.py:146-160), 2 their max (tron1_pf_ee.py:442-456,
                                       * go2_cts.py:156-170) */

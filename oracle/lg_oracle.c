@@ -162,7 +162,7 @@ static int solve_dense(real *A, real *b, int n) {
 
 /* ---------- per-env working set -------------------------------------------------------- */
 typedef struct {
-    int nb, nd;
+    int nb, nd, jpl;             /* jpl: joints per leg = (n_bodies - 1) / n_legs */
     const LgModelDesc *m;
     real mass0, com0[3];         /* base with domain-randomised mass / com shift */
     real arm[ND], jdamp[ND], jfric[ND];
@@ -188,7 +188,7 @@ static void kinematics(Work *w, const real *pos, const real *quat, const real *v
         rigid_inertia6(w->mass0, w->com0, i6, w->I[0]);
     }
     for (int i = 1; i < w->nb; i++) {
-        int p = (i - 1) % LG_JPL == 0 ? 0 : i - 1;
+        int p = (i - 1) % w->jpl == 0 ? 0 : i - 1;
         real ax[3] = {m->axis[i][0], m->axis[i][1], m->axis[i][2]};
         real jr[9], Rj[9], Rpc[9], jp[3] = {m->jpos[i][0], m->jpos[i][1], m->jpos[i][2]};
         for (int k = 0; k < 9; k++) jr[k] = m->jrot[i][k];
@@ -212,7 +212,7 @@ static void kinematics(Work *w, const real *pos, const real *quat, const real *v
     }
 }
 static real clampr(real x, real lim) { return x > lim ? lim : (x < -lim ? -lim : x); }
-static int parent_of(int i) { return (i - 1) % LG_JPL == 0 ? 0 : i - 1; }
+static int parent_of(const Work *w, int i) { return (i - 1) % w->jpl == 0 ? 0 : i - 1; }
 
 /* articulated inertias; independent of forces */
 static void aba_factor(Work *w) {
@@ -233,7 +233,7 @@ static void aba_factor(Work *w) {
                 for (int k = 0; k < 6; k++) s += Ia[6 * a + k] * w->X[i][6 * k + b];
                 T[6 * a + b] = s;
             }
-        int p = parent_of(i);
+        int p = parent_of(w, i);
         for (int a = 0; a < 6; a++)
             for (int b = 0; b < 6; b++) {
                 real s = 0;
@@ -273,7 +273,7 @@ static void aba_solve(const Work *w, int with_vel, const real *tau, real (*fext)
             for (int k = 0; k < 6; k++) Iac[k] -= w->U[i][k] * uc / w->d[i];
         }
         for (int k = 0; k < 6; k++) pa[k] = pA[i][k] + Iac[k] + w->U[i][k] * u[i] / w->d[i];
-        int p = parent_of(i);
+        int p = parent_of(w, i);
         for (int k = 0; k < 6; k++) {
             real s = 0;
             for (int j = 0; j < 6; j++) s += w->X[i][6 * j + k] * pa[j];
@@ -286,7 +286,7 @@ static void aba_solve(const Work *w, int with_vel, const real *tau, real (*fext)
     solve_dense(A, b, 6);
     memcpy(a[0], b, sizeof(b));
     for (int i = 1; i < w->nb; i++) {
-        int p = parent_of(i);
+        int p = parent_of(w, i);
         real ap[6];
         mv6(w->X[i], a[p], ap);
         if (with_vel)
@@ -385,8 +385,8 @@ static void env_step(const LgModelDesc *m, const LgSimOptions *o, const int16_t 
                      const float *actions, int e) {
     Work w;
     memset(&w, 0, sizeof(w));
-    const int nd = m->n_legs * LG_JPL, nb = 1 + nd, L = m->n_links, F = m->n_legs;
-    w.m = m; w.nb = nb; w.nd = nd;
+    const int nb = m->n_bodies, nd = nb - 1, L = m->n_links, F = m->n_legs;
+    w.m = m; w.nb = nb; w.nd = nd; w.jpl = nd / F;
     real pos[3], quat[4], vw[3], ww[3], q[ND], qd[ND];
     for (int k = 0; k < 3; k++) { pos[k] = B->base_pos[3 * e + k]; vw[k] = B->base_lin_vel_w[3 * e + k]; ww[k] = B->base_ang_vel_w[3 * e + k]; }
     for (int k = 0; k < 4; k++) quat[k] = B->base_quat[4 * e + k];
@@ -441,10 +441,37 @@ static void env_step(const LgModelDesc *m, const LgSimOptions *o, const int16_t 
             for (int k = 0; k < 3; k++) c[k] = w.Pw[i][k] + rw[k];
             terrain_at(o, hf, c[0], c[1], &h, n);
             real depth = m->sph_r[s] - (c[2] - h) * n[2];
+            const int sole = w.jpl == 4 && i % w.jpl == 0;
+            real vref = 0;
+            if (sole) {
+                /* spheres of a four-joint leg's foot body besides the foot sphere (the sole corners): they hold the foot flat while the
+                 * sole centre (foot sphere, solved exactly below) carries the load -- penetration and approach velocity are measured
+                 * relative to the centre's while that one is in the ground */
+                int sc = m->foot_sphere[(i - 1) / w.jpl];
+                real cl[3] = {m->sph_pos[sc][0], m->sph_pos[sc][1], m->sph_pos[sc][2]}, cw[3], cc[3], hc, nc[3], vc[3];
+                matvec3(w.Rw[i], cl, cw);
+                for (int k = 0; k < 3; k++) cc[k] = w.Pw[i][k] + cw[k];
+                terrain_at(o, hf, cc[0], cc[1], &hc, nc);
+                real dc = m->sph_r[sc] - (cc[2] - hc) * nc[2];
+                if (dc > 0) { point_velocity(&w, i, cl, vc); depth -= dc; vref = dot3(vc, nc); }
+            }
             if (depth <= -o->contact_margin) continue;
             real v[3];
             point_velocity(&w, i, rl, v);
-            real vn = dot3(v, n), wi = m->sph_w[s];
+            real vn = dot3(v, n) - vref, wi = m->sph_w[s];
+            if (sole) {
+                /* inverse mass: twice the ankle joint's own compliance at the contact point (the two corners of an edge share that
+                 * rotation), 2 (n . (s x (c - P)))^2 / (S^T I_foot S + armature), plus the model's sph_w */
+                real Is[6], dd = 0, sw[3], rc[3], sxr[3];
+                mv6(w.I[i], w.S[i], Is);
+                for (int k = 0; k < 6; k++) dd += w.S[i][k] * Is[k];
+                dd += w.arm[i - 1];
+                matvec3(w.Rw[i], w.S[i], sw);
+                for (int k = 0; k < 3; k++) rc[k] = c[k] - m->sph_r[s] * n[k] - w.Pw[i][k];
+                cross3(sw, rc, sxr);
+                real g = dot3(n, sxr);
+                wi += 2 * g * g / dd;
+            }
             real fn = (kc * depth - kappa * vn) / (1 + kappa * dt * wi);
             if (fn <= 0) continue;
             real vt[3];
@@ -711,7 +738,7 @@ static void rnea(const Work *w, const real *a0, const real *qdd, int with_vel, r
     memcpy(a[0], a0, sizeof(a[0]));
     for (int i = 0; i < w->nb; i++) {
         if (i > 0) {
-            int p = parent_of(i);
+            int p = parent_of(w, i);
             mv6(w->X[i], a[p], a[i]);
             for (int k = 0; k < 6; k++) a[i][k] += w->S[i][k] * qdd[i - 1] + (with_vel ? w->c[i][k] : 0);
         }
@@ -734,7 +761,7 @@ static void rnea(const Work *w, const real *a0, const real *qdd, int with_vel, r
         real s = 0;
         for (int k = 0; k < 6; k++) s += w->S[i][k] * f[i][k];
         tau[i - 1] = s + w->arm[i - 1] * qdd[i - 1];
-        int p = parent_of(i);
+        int p = parent_of(w, i);
         for (int k = 0; k < 6; k++) {
             real t = 0;
             for (int j = 0; j < 6; j++) t += w->X[i][6 * j + k] * f[i][j];
@@ -749,8 +776,8 @@ int lgo_forward_dynamics(const LgModelDesc *m, const LgSimOptions *o, const floa
                          int method, double *qdd_out, double *base_acc_out /* [ang_w(3), lin_w(3)] */) {
     Work w;
     memset(&w, 0, sizeof(w));
-    const int nd = m->n_legs * LG_JPL, nb = 1 + nd;
-    w.m = m; w.nb = nb; w.nd = nd; w.mass0 = m->mass[0];
+    const int nb = m->n_bodies, nd = nb - 1;
+    w.m = m; w.nb = nb; w.nd = nd; w.jpl = nd / m->n_legs; w.mass0 = m->mass[0];
     for (int k = 0; k < 3; k++) w.com0[k] = m->com[0][k];
     for (int k = 0; k < nd; k++) w.arm[k] = m->armature[k];
     real p_[3], q_[4], v_[3], w_[3], qq[ND], qqd[ND], tau[ND];

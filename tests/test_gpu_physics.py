@@ -112,11 +112,11 @@ def test_extreme_actions_stay_finite(go2, engine):
 def _setup(robot, rough, layout):
     import torch
     from hcr_genesis_lr_cl_amd import builders
-    from hcr_genesis_lr_cl_amd.config import GO2EECfg, TRON1PFEECfg, GO2Cfg
+    from hcr_genesis_lr_cl_amd.config import GO2EECfg, TRON1PFEECfg, GO2Cfg, TRON1SFCfg
     from hcr_genesis_lr_cl_amd.engine import Engine
     from hcr_genesis_lr_cl_amd.model_compiler import load_model
     from hcr_genesis_lr_cl_amd.terrain import Terrain
-    cfg = {"go2": GO2EECfg if rough else GO2Cfg, "tron1_pf": TRON1PFEECfg}[robot]()
+    cfg = {"go2": GO2EECfg if rough else GO2Cfg, "tron1_pf": TRON1PFEECfg, "tron1_sf": TRON1SFCfg}[robot]()
     cfg.hip.sim_layout = layout
     if not rough:
         cfg.terrain.mesh_type, cfg.terrain.measure_heights, cfg.terrain.curriculum = "plane", False, False
@@ -135,11 +135,12 @@ def _setup(robot, rough, layout):
     return model, cfg, desc, opts, eng, terrain
 
 
-@pytest.mark.parametrize("layout", LAYOUTS)
-@pytest.mark.parametrize("robot,rough", [("tron1_pf", False), ("go2", True), ("tron1_pf", True)])
+@pytest.mark.parametrize("robot,rough,layout", [("tron1_pf", False, 1), ("tron1_pf", False, 2), ("go2", True, 1), ("go2", True, 2),
+                                                ("tron1_pf", True, 1), ("tron1_pf", True, 2), ("tron1_sf", False, 1)])
 def test_one_control_step_matches_oracle_other_configs(robot, rough, layout):
     """TRON1 exercises the 2-lanes-per-env instantiation, joint_rot/armature/damping tables; `rough` the
-    heightfield contact (bilinear height + gradient normal) on stairs / slopes / obstacles."""
+    heightfield contact (bilinear height + gradient normal) on stairs / slopes / obstacles; tron1_sf the four-joint chains and
+    the sole contact (leg-per-lane layout only)."""
     import torch
     from hcr_genesis_lr_cl_amd import abi
     from oracle import oracle as orc
@@ -156,7 +157,7 @@ def test_one_control_step_matches_oracle_other_configs(robot, rough, layout):
         h = mo.sample_heights(st.arr["base_pos"], np.tile([0, 0, 0, 1.0], (eng.n, 1)).astype(np.float32), np.zeros((1, 2), np.float32),
                               terrain.height_field_raw, cfg.terrain.border_size, cfg.terrain.horizontal_scale, cfg.terrain.vertical_scale)
         st.arr["base_pos"][:, 2] += h[:, 0]
-    if robot == "tron1_pf":
+    if robot in ("tron1_pf", "tron1_sf"):
         st.arr["joint_armature"] = np.random.default_rng(1).uniform(0.11, 0.13, (eng.n, 1)).astype(np.float32)
         st.arr["joint_friction"] = np.random.default_rng(2).uniform(0.0, 0.01, (eng.n, 1)).astype(np.float32)
         st.arr["joint_damping"] = np.random.default_rng(3).uniform(1.4, 1.45, (eng.n, 1)).astype(np.float32)

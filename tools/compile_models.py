@@ -22,7 +22,10 @@ go2.to_json(os.path.join(ASSET_DIR, "go2.json"))
 tron = compile_urdf(os.path.join(REF, "resources/robots/PF_TRON1A/urdf/robot.urdf"), TRON1_DOFS,
                     ["foot_L_Link", "foot_R_Link"], "foot", "base_Link", name="tron1_pf")
 tron.to_json(os.path.join(ASSET_DIR, "tron1_pf.json"))
-for m in (go2, tron):
+SF_DOFS = [f"{j}_{s}_Joint" for s in ("L", "R") for j in ("abad", "hip", "knee", "ankle")]
+sf = compile_urdf(os.path.join(REF, "resources/robots/SF_TRON1A/urdf/robot.urdf"), SF_DOFS, [], "ankle", "base_Link", name="tron1_sf")
+sf.to_json(os.path.join(ASSET_DIR, "tron1_sf.json"))
+for m in (go2, tron, sf):
     a = m.arrays
     print(m.name, "mass", m.total_mass, "links", m.n_links, m.link_names)
     print("  spheres", a["n_spheres"], "per body", list(a["body_sph_start"]))
