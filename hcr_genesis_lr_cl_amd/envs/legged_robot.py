@@ -80,7 +80,7 @@ class _EpisodeExtras(MutableMapping):
         if name.startswith("cstr_"):      # constraint violation counters (go2_cat): logged like reward sums (constraint_manager.py:91-97)
             done = env._engine.buf["cstr_done_sums"][abi.CSTR_NAMES.index(name[5:])]
         else:
-            done = env._engine.buf["episode_done_sums"][abi.REWARD_ID[name]]
+            done = env._engine.buf["episode_done_sums"][abi.reward_id(name, env.simulator._model.joints_per_leg)]
         return torch.mean(done[m]) / env.max_episode_length_s
 
     def _lazy_keys(self):
@@ -310,4 +310,5 @@ class LeggedRobot:
                 self.reward_scales[key] *= self.dt
         self.reward_names = [n for n in self.reward_scales if n != "termination"]
         es = self._engine.buf["episode_sums"]
-        self.episode_sums = {name: es[abi.REWARD_ID[name]] for name in self.reward_scales}
+        jpl = self.simulator._model.joints_per_leg      # four-joint legs: three slots carry the sole-foot terms (include/lgsim.h)
+        self.episode_sums = {name: es[abi.reward_id(name, jpl)] for name in self.reward_scales}

@@ -94,6 +94,30 @@ def feet_terrain_info(feet_pos, hf, border, hscale, vscale):
     return har, nrm.reshape(N, F * 3)
 
 
+def foot_rotations(model, base_quat, dof_pos):
+    """World-from-foot-body rotation matrices (N, F, 3, 3) of the chains' last bodies: base rotation times, joint by joint, the
+    fixed joint frame and the rotation about the joint axis (the link orientation Genesis reports in rigid_body_states[:, :, 3:7])."""
+    a = model.arrays
+    N, F, J = base_quat.shape[0], model.n_legs, model.joints_per_leg
+    q = base_quat.astype(np.float64)
+    x, y, z, w = q[:, 0], q[:, 1], q[:, 2], q[:, 3]
+    Rb = np.stack([np.stack([1 - 2 * (y * y + z * z), 2 * (x * y - z * w), 2 * (x * z + y * w)], -1),
+                   np.stack([2 * (x * y + z * w), 1 - 2 * (x * x + z * z), 2 * (y * z - x * w)], -1),
+                   np.stack([2 * (x * z - y * w), 2 * (y * z + x * w), 1 - 2 * (x * x + y * y)], -1)], 1)
+    out = np.zeros((N, F, 3, 3))
+    for l in range(F):
+        R = Rb
+        for j in range(J):
+            b = 1 + J * l + j
+            ax = a["axis"][b] / np.linalg.norm(a["axis"][b])
+            K = np.array([[0, -ax[2], ax[1]], [ax[2], 0, -ax[0]], [-ax[1], ax[0], 0]])
+            th = dof_pos[:, J * l + j].astype(np.float64)[:, None, None]
+            Rj = np.eye(3) + np.sin(th) * K + (1 - np.cos(th)) * (K @ K)
+            R = R @ a["jrot"][b].reshape(3, 3) @ Rj
+        out[:, l] = R
+    return out
+
+
 class MdpOracle:
     def __init__(self, model, cfg, task, n_envs, env_origins=None):
         self.model, self.cfg, self.task, self.N = model, cfg, task, n_envs
@@ -312,6 +336,7 @@ class MdpOracle:
             self.episode_sums[k] += rew
         R_ = abi.REWARD_ID
         on = lambda n: sc[R_[n]] != 0
+        JPL4 = self.model.joints_per_leg == 4     # sole-foot biped: three quadruped-only slots carry its own terms (include/lgsim.h)
         if on("action_rate"):
             add("action_rate", np.sum((self.last_actions - self.actions) ** 2, axis=1))
         if on("action_smoothness"):
@@ -346,7 +371,7 @@ class MdpOracle:
             first = (self.feet_air_time > 0) * filt
             self.feet_air_time += self.dt
             r = np.sum((self.feet_air_time - f32(T.feet_air_time_threshold)) * first, axis=1)
-            r = r * (cmd_xy > 0.1)
+            r = r * ((cmd_xyz if T.air_time_cmd_dims == 3 else cmd_xy) > 0.1)      # legged_robot.py:553 | tron1_sf.py:264
             self.feet_air_time *= ~filt
             add("feet_air_time", r)
         if on("feet_contact_stand_still"):
@@ -367,21 +392,32 @@ class MdpOracle:
                 zf = zf - np.max(sim["height_around_feet"].reshape(N, F, 9), axis=-1)
             err = np.sum(vxy * (zf - f32(T.foot_clearance_target) - f32(T.foot_height_offset)) ** 2, axis=-1)
             add("foot_clearance", np.exp(-err / f32(T.foot_clearance_sigma)))
+        if JPL4 and on("quad_periodic_gait"):                              # tron1_sf.py:297-308 _reward_foot_flat (slot LG_R_FOOT_FLAT)
+            Rf = foot_rotations(self.model, sim["base_quat"], dof_pos)         # rigid_body_states[:, feet, 3:7] as rotation matrices
+            tilt = np.abs(Rf[:, :, 2, 0]) + np.abs(Rf[:, :, 2, 1])             # x, y of the world z axis seen from the foot
+            add("quad_periodic_gait", np.sum(np.exp(-tilt.astype(f32) / f32(0.1)), axis=1))
         if on("foot_landing_vel"):
             zv = feet_vel[:, :, 2]
             land = ((feet_pos[:, :, 2] - f32(T.foot_height_offset)) < f32(T.about_landing_threshold)) & ~(feet_f[:, :, 2] > 0.1) & (zv < 0)
             add("foot_landing_vel", np.sum(np.where(land, zv, 0) ** 2, axis=1))
         if on("hip_pos"):
-            add("hip_pos", np.sum((dof_pos[:, 0::3] - self.q0[0::3]) ** 2, axis=1))
+            if JPL4:                                                           # tron1_sf.py:281-285 _reward_hip_pos_zero_command
+                add("hip_pos", np.sum((dof_pos[:, [1, 5]] - self.q0[[1, 5]]) ** 2, axis=1) * (cmd_xyz < 0.1))
+            else:
+                add("hip_pos", np.sum((dof_pos[:, 0::3] - self.q0[0::3]) ** 2, axis=1))
+        if JPL4 and on("tracking_foot_clearance"):                         # tron1_sf.py:287-295 _reward_keep_ankle_pitch_zero_in_air
+            c = feet_f[:, :, 2] > 1.0
+            ank = np.abs(dof_pos[:, 3]) * ~c[:, 0] + np.abs(dof_pos[:, 7]) * ~c[:, 1]
+            add("tracking_foot_clearance", np.exp(-np.abs(ank) / f32(0.2)))
         if on("keep_balance"):
             add("keep_balance", np.ones(N, f32))
         if on("lin_vel_z"):
             add("lin_vel_z", blv[:, 2] ** 2)
         if on("no_fly"):                                                   # tron1_pf.py:151-154
-            add("no_fly", 1.0 * (np.sum(1.0 * (feet_f[:, :, 2] > 0.1), axis=1) == 1))
+            add("no_fly", 1.0 * (np.sum(1.0 * (feet_f[:, :, 2] > f32(T.no_fly_contact_threshold)), axis=1) == 1))   # tron1_sf.py:275-278: 1.0
         if on("orientation"):
             add("orientation", np.sum(pg[:, :2] ** 2, axis=1))
-        if on("quad_periodic_gait"):                                       # go2_wtw.py:377-484 ("step" indicator)
+        if not JPL4 and on("quad_periodic_gait"):                          # go2_wtw.py:377-484 ("step" indicator)
             acc = np.zeros(N, f32)
             b_swing = f32(T.b_swing) * f32(2 * np.pi)
             for i in range(4):
@@ -412,7 +448,7 @@ class MdpOracle:
             else:                                                              # tron1_pf_ee.py:435-440
                 d = np.mean(sim["base_pos"][:, 2:3] - sim["measured_heights"], axis=1) - f32(T.base_height_target)
             add("tracking_base_height", np.exp(-(d ** 2) / f32(T.base_height_sigma)))
-        if on("tracking_foot_clearance"):                                  # go2_wtw.py:507-519
+        if not JPL4 and on("tracking_foot_clearance"):                     # go2_wtw.py:507-519
             vxy = np.linalg.norm(feet_vel[:, :, :2], axis=-1)
             err = np.sum(vxy * (feet_pos[:, :, 2] - self.foot_clearance_target - f32(T.foot_height_offset)) ** 2, axis=-1)
             add("tracking_foot_clearance", np.exp(-err / f32(T.foot_clearance_sigma)))
@@ -603,6 +639,8 @@ class MdpOracle:
                 abi.SEG_DR_BASE: dr_base,                                      # tron1_pf.py:37-41
                 abi.SEG_FEET_AIR_TIME: lambda sc_: self.feet_air_time,         # tron1_pf.py:42
                 abi.SEG_FRAME: lambda sc_: frame,
+                abi.SEG_KP: lambda sc_: self.kp_scale - f32(T.kp_offset),           # tron1_sf.py:40-41
+                abi.SEG_KD: lambda sc_: self.kd_scale - f32(T.kd_offset),           # tron1_sf.py:42-43
                 abi.SEG_DR: lambda sc_: np.concatenate([self.friction_values - f32(T.friction_offset), self.added_base_mass, self.base_com_bias,
                                                         self.rand_push_vels[:, :2], self.kp_scale - f32(T.kp_offset),
                                                         self.kd_scale - f32(T.kd_offset)], axis=1),

@@ -85,6 +85,8 @@ class FakeSimulator:
         self._joint_armature, self._joint_friction, self._joint_damping = z(N, 1), z(N, 1), z(N, 1)
         self.dof_names = list(cfg.asset.dof_names)   # tron1_pf_ee.py:171 reads simulator.dof_names (absent from the reference ABC)
         self._global_gravity = torch.tensor([0., 0., -1.]).repeat(N, 1)
+        self._rigid_body_states = z(N, L, 13)                   # only [:, feet, 3:7] is read (tron1_sf.py:300)
+        self._rigid_body_states[:, :, 6] = 1
         self.script, self.t, self.rec = None, -1, None
 
     # -- scripted physics ------------------------------------------------------------------
@@ -98,6 +100,8 @@ class FakeSimulator:
         for k in ("base_pos", "base_quat", "base_lin_vel_w", "base_ang_vel_w", "dof_pos", "dof_vel", "torques",
                   "link_contact_forces", "feet_pos", "feet_vel"):
             getattr(self, "_" + k)[:] = s[k].reshape(getattr(self, "_" + k).shape)
+        if "foot_quat" in s:
+            self._rigid_body_states[:, self._feet_indices, 3:7] = s["foot_quat"]
         self._base_lin_vel[:] = self._qri(self._base_quat, self._base_lin_vel_w)
         self._base_ang_vel[:] = self._qri(self._base_quat, self._base_ang_vel_w)
         self._projected_gravity = self._qri(self._base_quat, self._global_gravity)
@@ -162,7 +166,7 @@ class FakeSimulator:
         pass
 
 
-for _p in ("feet_indices", "termination_contact_indices", "penalized_contact_indices", "dof_pos_limits",
+for _p in ("rigid_body_states", "feet_indices", "termination_contact_indices", "penalized_contact_indices", "dof_pos_limits",
            "base_init_pos", "base_init_quat", "base_lin_vel", "base_ang_vel", "projected_gravity", "dof_pos",
            "dof_vel", "last_dof_vel", "feet_pos", "feet_vel", "last_feet_vel", "base_pos", "base_quat",
            "base_euler", "measured_heights", "link_contact_forces", "torques", "default_dof_pos", "custom_origins",
@@ -735,6 +739,99 @@ def gen_tron1_pf(N=16, T=40, seed=51):
         torch.rand_like = orig_rand_like
 
 
+def _mat_to_quat(R):
+    """xyzw quaternions of rotation matrices (..., 3, 3), w >= 0 branch-free enough for the tilts scripted here."""
+    w = np.sqrt(np.maximum(0.0, 1.0 + R[..., 0, 0] + R[..., 1, 1] + R[..., 2, 2])) / 2
+    x = np.sqrt(np.maximum(0.0, 1.0 + R[..., 0, 0] - R[..., 1, 1] - R[..., 2, 2])) / 2 * np.sign(R[..., 2, 1] - R[..., 1, 2] + 1e-30)
+    y = np.sqrt(np.maximum(0.0, 1.0 - R[..., 0, 0] + R[..., 1, 1] - R[..., 2, 2])) / 2 * np.sign(R[..., 0, 2] - R[..., 2, 0] + 1e-30)
+    z = np.sqrt(np.maximum(0.0, 1.0 - R[..., 0, 0] - R[..., 1, 1] + R[..., 2, 2])) / 2 * np.sign(R[..., 1, 0] - R[..., 0, 1] + 1e-30)
+    q = np.stack([x, y, z, w], -1)
+    return (q / np.linalg.norm(q, axis=-1, keepdims=True)).astype(np.float32)
+
+
+def gen_tron1_sf(N=16, T=44, seed=61):
+    """TRON1SF (tron1_sf.py, experiment "tron1_sf"): the 8-DOF sole-foot biped on the plane: 10-frame actor / critic stacks, the
+    6-DOF index pairs of its `_reset_dofs`, the batch-wide sit-pose coin, `hip_pos_zero_command` / `foot_flat` rewards (and
+    `keep_ankle_pitch_zero_in_air`, given a scale here so that it is pinned too).  The foot orientation the class reads from
+    rigid_body_states is scripted consistently with the scripted base orientation and joint angles (oracle.mdp_oracle.foot_rotations)."""
+    import legged_gym.envs.base.base_task as base_task
+    import legged_gym.envs.base.legged_robot as lr_mod
+    import legged_gym.envs.tron1_sf.tron1_sf as sf_mod
+    from legged_gym.envs.tron1_sf.tron1_sf_config import TRON1SFCfg
+    from legged_gym.utils.helpers import class_to_dict
+    from hcr_genesis_lr_cl_amd.config import TRON1SFCfg as MyCfg
+    from oracle.mdp_oracle import foot_rotations
+
+    rec = rh.DrawRecorder(seed)
+    base_task.GenesisSimulator = FakeSimulator
+    lr_mod.torch_rand_float = rec.rand_float
+    sf_mod.torch_rand_float = rec.rand_float
+    orig = (torch.rand_like, np.random.random)
+    torch.rand_like, np.random.random = rec.rand_like, rec.np_random
+    try:
+        cfg = TRON1SFCfg()
+        cfg.env.num_envs = N
+        cfg.rewards.scales.keep_ankle_pitch_zero_in_air = 0.2     # defined by the class, unscaled in the shipped config
+        env = sf_mod.TRON1SF(cfg, class_to_dict(cfg.sim), "cpu", True)
+        sim = env.simulator
+        sim.rec = rec
+        rng = np.random.default_rng(seed + 1)
+        model = sim.model
+        script = make_script(rng, model, cfg, N, T)
+        script["base_pos"][:, :, 2] += 0.43                       # nominal base height 0.75
+        script["feet_pos"][:, :, :, :2] = script["feet_pos"][:, :, :, :2] * 0.4 + script["base_pos"][:, :, None, :2]
+        script["foot_quat"] = np.stack([_mat_to_quat(foot_rotations(model, script["base_quat"][t], script["dof_pos"][t])) for t in range(T)])
+        sim.script = script
+        mycfg = MyCfg()
+        mycfg.rewards.scales.keep_ankle_pitch_zero_in_air = 0.2
+        task = builders.make_task_cfg(model, mycfg)
+        slots = task.slots
+        groups = [[0, 3], [1, 4], [2, 5], [3, 6]]                  # tron1_sf.py:224-231: the 6-DOF index pairs on the 8-DOF vector
+        env.episode_length_buf[:] = torch.from_numpy(rng.choice([3, 120, 470, 495, 498, 499, 968, 977, 985, 992, 995, 998, 999, 1000], N).astype(np.int32))
+        env.commands[:] = torch.from_numpy((rng.normal(size=(N, 4)) * [0.4, 0.4, 0.5, 1.5]).astype(np.float32))
+        env.commands[::3, :3] *= 0.05                              # ~zero commands: hip_pos_zero_command, the air-time gate
+        env.common_step_counter = 495                              # push interval 10 s = 500 steps
+        env.reset_buf[:] = 0
+        rec.take()
+        init = dict(episode_length_buf=env.episode_length_buf.numpy().copy(), commands=env.commands.numpy().copy(),
+                    env_origins=sim._env_origins.numpy().copy())
+        keys = ("actions_in", "rand", "counter", "obs", "priv", "rew", "reset", "time_out", "commands", "ep_len", "fail_buf", "feet_air_time",
+                "episode_sums", "act_hist", "sim_dof_pos", "sim_base_pos", "sim_base_quat", "sim_base_lin_vel_w", "dr", "dr_pd", "dr_joint",
+                "last_dof_vel_in", "last_feet_vel_in", "esum_override")
+        out = {k: [] for k in keys}
+        names = env.reward_names
+        for t in range(T):
+            act = torch.from_numpy((rng.normal(size=(N, 8)) * (1.0 if t % 7 else 60.0)).astype(np.float32))
+            out["last_dof_vel_in"].append(sim._dof_vel.numpy().copy()); out["last_feet_vel_in"].append(sim._feet_vel.numpy().copy())
+            obs, priv, rew, reset, extras = env.step(act)
+            calls = rec.take()
+            out["actions_in"].append(act.numpy().copy()); out["rand"].append(slots_from_calls(calls, slots, N, 8, groups))
+            out["counter"].append(env.common_step_counter); out["esum_override"].append(0.0)
+            out["obs"].append(obs.numpy().copy()); out["priv"].append(priv.numpy().copy()); out["rew"].append(rew.numpy().copy())
+            out["reset"].append(reset.numpy().astype(np.uint8)); out["time_out"].append(env.time_out_buf.numpy().astype(np.uint8))
+            out["commands"].append(env.commands.numpy().copy()); out["ep_len"].append(env.episode_length_buf.numpy().copy())
+            out["fail_buf"].append(env.fail_buf.numpy().copy()); out["feet_air_time"].append(env.feet_air_time.numpy().copy())
+            out["episode_sums"].append(np.stack([env.episode_sums[n].numpy().copy() for n in names]))
+            out["act_hist"].append(np.stack([env.actions.numpy(), env.last_actions.numpy(), env.llast_actions.numpy()]).copy())
+            out["sim_dof_pos"].append(sim._dof_pos.numpy().copy()); out["sim_base_pos"].append(sim._base_pos.numpy().copy())
+            out["sim_base_quat"].append(sim._base_quat.numpy().copy()); out["sim_base_lin_vel_w"].append(sim._base_lin_vel_w.numpy().copy())
+            out["dr"].append(np.concatenate([sim._friction_values.numpy(), sim._added_base_mass.numpy(), sim._base_com_bias.numpy(),
+                                             sim._rand_push_vels.numpy()[:, :2]], 1).copy())
+            out["dr_pd"].append(np.concatenate([sim._kp_scale.numpy(), sim._kd_scale.numpy()], 1).copy())
+            out["dr_joint"].append(np.concatenate([sim._joint_armature.numpy(), sim._joint_friction.numpy(), sim._joint_damping.numpy()], 1).copy())
+        arrays = {k: np.stack(v) for k, v in out.items()}
+        arrays.update({"script_" + k: v for k, v in sim.script.items()})
+        arrays.update({"init_" + k: v for k, v in init.items()})
+        arrays["reward_names"] = np.array(names)
+        path = os.path.join(HERE, "tron1_sf_mdp.npz")
+        np.savez_compressed(path, **arrays)
+        sit = arrays["reset"].astype(bool) & (np.abs(arrays["sim_dof_pos"][:, :, 2] - 1.35) < 1e-6)
+        print("wrote", path, os.path.getsize(path), arrays["obs"].shape, arrays["priv"].shape, "resets/step", arrays["reset"].sum(1),
+              "sit resets", int(sit.sum()), list(names))
+    finally:
+        torch.rand_like, np.random.random = orig
+
+
 def gen_head(name, N=16, T=36, seed=41):
     """The other Go2-rough heads -- Go2TS, Go2CTS, Go2Dreamwaq, Go2CaT (legged_gym/envs/__init__.py:82-86) -- run AS CONFIGURED
     on the rough fake simulator: same recording as gen_ee.  Stored per step: the clipped actor frame, the newest frame of the
@@ -850,7 +947,9 @@ def gen_head(name, N=16, T=36, seed=41):
 
 
 if __name__ == "__main__":
-    which = sys.argv[1:] or ["go2", "wtw", "ee", "tron1", "go2_ts", "go2_cts", "go2_dreamwaq", "go2_cat", "tron1_pf"]
+    which = sys.argv[1:] or ["go2", "wtw", "ee", "tron1", "go2_ts", "go2_cts", "go2_dreamwaq", "go2_cat", "tron1_pf", "tron1_sf"]
+    if "tron1_sf" in which:
+        gen_tron1_sf()
     if "tron1_pf" in which:
         gen_tron1_pf()
     for h in ("go2_ts", "go2_cts", "go2_dreamwaq", "go2_cat"):

@@ -536,3 +536,64 @@ def test_cat_job_wide_flag_is_raised_by_the_physics_launch():
     env.common_step_counter = c
     with pytest.raises(RuntimeError):
         eng.step(abi.PHASE_ALL, torch.zeros(256, 12, device="cuda"), c + 1)      # CaT cannot run as one launch
+
+
+# ------------------------------- tron1_sf (8-DOF sole-foot biped on the plane) ---------------------
+class SFKernelStepper:
+    def __init__(self, fx, N):
+        from tests.test_mdp_oracle import sf_cfg
+        self.eng, self.model, self.cfg, self.task = make_engine(N, fx["init_env_origins"], sf_cfg)
+        eng = self.eng
+        put(eng, "episode_length_buf", fx["init_episode_length_buf"])
+        put(eng, "commands", fx["init_commands"])
+        eng.buf["friction_values"].fill_(0.0); eng.buf["added_base_mass"].fill_(1.0)    # the fake simulator's initial values
+        for k in ("joint_armature", "joint_friction", "joint_damping"):
+            eng.buf[k].fill_(0.0)
+        self.names = [str(n) for n in fx["reward_names"]]
+
+    def step(self, t, sim, actions, R, counter, override):
+        import torch
+        from hcr_genesis_lr_cl_amd import abi
+        eng = self.eng
+        sim.pop("foot_quat", None)     # the kernel derives the foot orientation from base_quat and dof_pos
+        load_sim(eng, sim)
+        put(eng, "rand_in", R)
+        eng.step(abi.PHASE_PRE | abi.PHASE_POST | abi.PHASE_RESET, torch.from_numpy(actions).cuda(), counter)
+        torch.cuda.synchronize()
+        es = get(eng, "episode_sums")
+        return dict(obs=get(eng, "obs_buf"), priv=get(eng, "priv_obs_buf"), rew=get(eng, "rew_buf"), reset=get(eng, "reset_buf"),
+                    time_out=get(eng, "time_out_buf"), commands=get(eng, "commands"), ep_len=get(eng, "episode_length_buf"),
+                    fail_buf=get(eng, "fail_buf"), feet_air_time=get(eng, "feet_air_time"),
+                    episode_sums=np.stack([es[abi.reward_id(n, 4)] for n in self.names]),
+                    act_hist=np.stack([get(eng, "actions"), get(eng, "last_actions"), get(eng, "llast_actions")]),
+                    sim_dof_pos=get(eng, "dof_pos"), sim_base_pos=get(eng, "base_pos"), sim_base_quat=get(eng, "base_quat"),
+                    sim_base_lin_vel_w=get(eng, "base_lin_vel_w"),
+                    dr=np.concatenate([get(eng, "friction_values"), get(eng, "added_base_mass"), get(eng, "base_com_bias"),
+                                       get(eng, "rand_push_vels")[:, :2]], 1),
+                    dr_pd=np.concatenate([get(eng, "kp_scale"), get(eng, "kd_scale")], 1),
+                    dr_joint=np.concatenate([get(eng, "joint_armature"), get(eng, "joint_friction"), get(eng, "joint_damping")], 1))
+
+
+def test_kernel_reproduces_reference_tron1_sf_golden_vectors():
+    """TRON1SF, golden vectors from the reference's own class (gen_mdp_fixtures.py gen_tron1_sf): four-joint legs in the
+    MDP phases, the sole-foot reward terms, the sit-pose coin, the 10-frame stacks with the kp / kd blocks in the critic frame."""
+    from tests.test_mdp_oracle import GOLD_SF, check_sf
+    replay(SFKernelStepper, lambda t, fx, out: check_sf(t, fx, out, rtol=1e-5, atol=5e-5), GOLD_SF)
+
+
+def test_tron1_sf_env_rollout():
+    """The task through the VecEnv surface: 5-tuple, shapes of tron1_sf_config.py:6-15, physics + MDP in one leg-per-lane launch."""
+    import torch
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    env, cfg = make_env("tron1_sf", 256)
+    obs, priv = env.reset()
+    assert obs.shape == (256, 330) and priv.shape == (256, 720) and env.num_actions == 8
+    g = torch.Generator(device="cuda"); g.manual_seed(1)
+    n_reset = 0
+    for t in range(300):
+        obs, priv, rew, done, extras = env.step(torch.randn(256, 8, generator=g, device="cuda") * 0.5)
+        n_reset += int(done.sum())
+    assert torch.isfinite(obs).all() and torch.isfinite(priv).all() and torch.isfinite(rew).all()
+    keys = list(extras["episode"])
+    assert n_reset > 20 and {"rew_foot_flat", "rew_hip_pos_zero_command", "rew_no_fly"} <= set(keys)
+    assert float(env.simulator.base_pos[:, 2].max()) < 1.6 and float(env.simulator.dof_vel.abs().max()) <= 30.0 + 1e-3

@@ -425,3 +425,69 @@ def test_tron1_pf_fixture_exercises_the_branches():
 
 def test_mdp_oracle_reproduces_reference_tron1_pf():
     replay(PFOracleStepper, check_pf, GOLD_PF)
+
+
+# ------------------------------- tron1_sf (8-DOF sole-foot biped on the plane) ---------------------
+GOLD_SF = os.path.join(os.path.dirname(__file__), "golden", "tron1_sf_mdp.npz")
+
+
+def sf_cfg():
+    from hcr_genesis_lr_cl_amd.config import TRON1SFCfg
+    cfg = TRON1SFCfg()
+    cfg.rewards.scales.keep_ankle_pitch_zero_in_air = 0.2     # as in the generator: the class defines it, the shipped config leaves it unscaled
+    return cfg
+
+
+class SFOracleStepper:
+    def __init__(self, fx, N):
+        model, cfg = load_model("tron1_sf"), sf_cfg()
+        task = builders.make_task_cfg(model, cfg)
+        o = self.o = MdpOracle(model, cfg, task, N, fx["init_env_origins"])
+        o.episode_length_buf[:] = fx["init_episode_length_buf"]
+        o.commands[:] = fx["init_commands"]
+        o.friction_values[:] = 0; o.added_base_mass[:] = 1          # the generator's fake simulator starts like genesis_simulator.py:646-649
+        self.names = [str(n) for n in fx["reward_names"]]
+
+    def step(self, t, sim, actions, R, counter, override):
+        o = self.o
+        sim.pop("foot_quat", None)     # what the reference read from rigid_body_states; here it follows from base_quat and dof_pos
+        o.step(sim, actions, R, counter)
+        return dict(obs=np.clip(o.obs_buf, -100, 100), priv=o.priv_obs_buf, rew=o.rew_buf, reset=o.reset_buf, time_out=o.time_out_buf,
+                    commands=o.commands, ep_len=o.episode_length_buf, fail_buf=o.fail_buf, feet_air_time=o.feet_air_time,
+                    episode_sums=np.stack([o.episode_sums[abi.reward_id(n, 4)] for n in self.names]),
+                    act_hist=np.stack([o.actions, o.last_actions, o.llast_actions]),
+                    sim_dof_pos=sim["dof_pos"], sim_base_pos=sim["base_pos"], sim_base_quat=sim["base_quat"], sim_base_lin_vel_w=sim["base_lin_vel_w"],
+                    dr=np.concatenate([o.friction_values, o.added_base_mass, o.base_com_bias, o.rand_push_vels[:, :2]], 1),
+                    dr_pd=np.concatenate([o.kp_scale, o.kd_scale], 1),
+                    dr_joint=np.concatenate([o.joint_armature, o.joint_friction, o.joint_damping], 1))
+
+
+SF_FLOAT = PF_FLOAT + ("sim_base_quat", "dr_pd", "dr_joint")
+
+
+def check_sf(t, fx, out, rtol=2e-6, atol=2e-6):
+    for k in WTW_EXACT:
+        np.testing.assert_array_equal(np.asarray(out[k]).astype(np.int64), fx[k][t].astype(np.int64), err_msg=f"{k} @ step {t}")
+    for k in SF_FLOAT:
+        np.testing.assert_allclose(np.asarray(out[k]), fx[k][t], rtol=rtol, atol=atol, err_msg=f"{k} @ step {t}")
+
+
+def test_tron1_sf_fixture_exercises_the_branches():
+    fx = np.load(GOLD_SF)
+    names = [str(n) for n in fx["reward_names"]]
+    assert fx["reset"].sum() >= 6 and (fx["counter"] % 500 == 0).any() and len(names) == 21
+    assert {"foot_flat", "hip_pos_zero_command", "keep_ankle_pitch_zero_in_air", "no_fly"} <= set(names)
+    assert fx["obs"].shape[-1] == 10 * 33 and fx["priv"].shape[-1] == 10 * 72
+    r = fx["reset"].astype(bool)
+    sit = r & (np.abs(fx["sim_dof_pos"][:, :, 2] - 1.35) < 1e-6)            # both reset branches (tron1_sf.py:160-166)
+    assert sit.sum() >= 2 and (r & ~sit).sum() >= 2
+    for n in ("foot_flat", "hip_pos_zero_command", "keep_ankle_pitch_zero_in_air"):
+        d = np.diff(fx["episode_sums"][:, names.index(n)], axis=0)
+        assert (np.abs(d) > 0).any(), n
+    # tron1_sf.py:224-231: dof 7 is never offset by a reset, dof 0 moves by at most 0.05
+    nonsit = r & ~sit
+    assert np.all(fx["sim_dof_pos"][:, :, 7][nonsit] == 0) and np.abs(fx["sim_dof_pos"][:, :, 0][nonsit]).max() <= 0.05 + 1e-6
+
+
+def test_mdp_oracle_reproduces_reference_tron1_sf():
+    replay(SFOracleStepper, check_sf, GOLD_SF)
