@@ -23,7 +23,10 @@ BYTES_PER_ENV_STEP = 988          # go2 flat, f32, state read on
 # SURVEY 8(d) persistent-state floats (read once + written once per control step) of the history-stacked tasks; the
 # observation part of their traffic is derived from the task constants in algorithmic_bytes() below (DESIGN.md "Roofline
 # bookkeeping"): the sliding window writes ONE new frame per stack per step instead of re-materialising the whole history
-STATE_FLOATS = {"go2_wtw": 300, "go2_ee": 320, "tron1_pf_ee": 260}
+STATE_FLOATS = {"go2_wtw": 300, "go2_ee": 320, "tron1_pf_ee": 260,
+                # not BASELINE configs (no SURVEY figure): the same count for their robot / terrain -- go2-rough heads as go2_ee, the TRON1
+                # plane tasks as tron1_pf_ee without its terrain samples (49 + 2 x 12), tron1_sf with 2 more dofs (x 7 per-dof arrays)
+                "go2_ts": 320, "go2_cts": 320, "go2_dreamwaq": 320, "go2_cat": 330, "tron1_pf": 190, "tron1_sf": 218}
 HBM_PEAK_GBS = 8000.0             # MI355X_MICROARCH.md: 8 TB/s spec (6.3 TB/s measured copy)
 VALU_PEAK_LANEOPS = 256 * 4 * 16 * 2.4e9   # 256 CUs x 4 SIMDs x 16 lanes per clock x 2.4 GHz = 39.3e12 non-packed f32 lane-ops/s
 
@@ -48,7 +51,11 @@ def algorithmic_bytes(task_name, t):
 
 WORKLOADS = {"go2": "go2_flat, flat-plane contact", "go2_wtw": "go2_wtw, periodic-gait rewards + domain rand, flat plane",
              "go2_ee": "go2_rough (go2_ee), heightfield terrain + terrain curriculum",
-             "tron1_pf_ee": "tron1_pf_rough (tron1_pf_ee), biped, heightfield terrain + terrain curriculum"}
+             "tron1_pf_ee": "tron1_pf_rough (tron1_pf_ee), biped, heightfield terrain + terrain curriculum",
+             "go2_ts": "go2_ts, teacher-student head on go2_rough", "go2_cts": "go2_cts, concurrent teacher-student head on go2_rough",
+             "go2_dreamwaq": "go2_dreamwaq head on go2_rough (3000 envs in the reference's config)",
+             "go2_cat": "go2_cat, constraints as terminations on go2_rough", "tron1_pf": "tron1_pf, point-foot biped, flat plane",
+             "tron1_sf": "tron1_sf, 8-DOF sole-foot biped, flat plane"}
 
 
 def ppo_rollout(task, n, iters, dev, T=24, gamma=0.99, lam=0.95):
@@ -309,7 +316,7 @@ def main():
                     help="wait for each step's all-gather before the next step (default: it overlaps the next step, double-buffered)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-timer-stride", type=int, default=8, help="time the physics kernel of every n-th step (0 = off)")
-    ap.add_argument("--task", default="go2", choices=["go2", "go2_wtw", "go2_ee", "tron1_pf_ee"],
+    ap.add_argument("--task", default="go2", choices=list(WORKLOADS),
                     help="BASELINE config to run (the headline metric is go2; the others are reported under the same keys "
                          "with their own workload string)")
     ap.add_argument("--ppo-rollout", type=int, default=0, metavar="ITERS",
@@ -404,8 +411,12 @@ def main():
         bytes_env = algorithmic_bytes(args.task, env._engine.task)
         achieved = bytes_env * n_local / launch_s / 1e9
         wkey = f"{'go2_flat' if args.task == 'go2' else args.task}_{n_local}"
-        legs = 2 if args.task == "tron1_pf_ee" else 4
-        if n_local * legs * 4 > 2048 * 64:
+        legs = 2 if args.task.startswith("tron1") else 4
+        if args.task == "tron1_sf":
+            layout = "env_step_kernel<2,ALL,0,4> (leg-per-lane, four-joint legs)"
+        elif args.task == "go2_cat":
+            layout = "quad_sim_kernel<4,PRE,0> + env_step_kernel<4,POST|RESET> (the job-wide CaT flag separates physics and MDP; timed together)"
+        elif n_local * legs * 4 > 2048 * 64:
             layout = f"env_step_kernel<{legs},ALL> (leg-per-lane)"
         elif legs == 4:
             layout = "quad_sim_kernel<4,PRE,POST|RESET> (component-per-lane physics, MDP phases in its tail)"

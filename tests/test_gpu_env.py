@@ -234,7 +234,7 @@ def test_full_size_batch_properties():
         assert bad.float().mean() <= frac, (k, int(bad.sum()), float((e1.buf[k] - e2.buf[k]).abs().max()))
 
 
-@pytest.mark.parametrize("task", ["go2", "go2_wtw", "go2_ee", "tron1_pf_ee"])
+@pytest.mark.parametrize("task", ["go2", "go2_wtw", "go2_ee", "tron1_pf_ee", "tron1_sf"])
 def test_long_rollout_stays_sane(task):
     """1500 control steps of aggressive random actions (sigma 2) on every BASELINE task at 1024 envs: state and outputs
     stay finite and bounded, resets keep happening (robots fall) and robots never leave the terrain bounds."""
@@ -289,7 +289,7 @@ def _obs_tensors(out):
 
 
 @pytest.mark.parametrize("slack", ["64", "1"], ids=["default-slack", "min-slack"])
-@pytest.mark.parametrize("task", ["go2", "go2_wtw", "go2_ee", "tron1_pf_ee"])
+@pytest.mark.parametrize("task", ["go2", "go2_wtw", "go2_ee", "tron1_pf_ee", "tron1_sf"])
 def test_returned_observations_survive_the_next_step(task, slack, monkeypatch):
     """The ordering of the reference's rollout loop (rsl_rl/algorithms/ppo.py:103-104 keeps `obs`,
     on_policy_runner.py:118-124 calls env.step, rollout_storage.py:92 copies `obs` only afterwards): what a step
@@ -370,7 +370,7 @@ def test_runner_statements_on_the_env():
     assert len(list(ep_info)) == 16
 
 
-@pytest.mark.parametrize("task", ["go2", "go2_wtw", "go2_ee", "tron1_pf_ee"])
+@pytest.mark.parametrize("task", ["go2", "go2_wtw", "go2_ee", "tron1_pf_ee", "tron1_sf"])
 def test_checkpoint_resume_is_bit_exact(task, tmp_path):
     """save after k steps, keep going, restore into a FRESH env, replay the same actions: every output and every
     buffer identical to the uninterrupted run (curriculum levels, command ranges, episode sums, observation histories and the

@@ -202,7 +202,7 @@ def test_other_sweep_counts_match_oracle(go2, layout, iters):
     assert np.all(err <= 0.3 + 0.01 * np.abs(st.arr["link_contact_forces"].reshape(256, -1))), err.max()
 
 
-@pytest.mark.parametrize("task", ["go2_ee", "tron1_pf_ee"])
+@pytest.mark.parametrize("task", ["go2_ee", "tron1_pf_ee", "tron1_sf"])
 def test_no_robot_is_thrown_by_the_contact_solver(task):
     """Regression (round 2): with friction ratios up to 1.7 the sliding branch of the foot contact could jam -- friction coupling
     cancelling the normal compliance, f_n = rn / (1 + kappa a_eff) with a_eff -> 0 -- and throw a robot (39 kN on one foot, 47 m/s,

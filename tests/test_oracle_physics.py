@@ -174,3 +174,59 @@ def test_joint_limit_and_effort_clamp(go2):
     assert st.arr["torques"].max() > 100.0
     assert np.all(st.arr["dof_pos"][0] < a["q_hi"] + 1.0) and np.all(st.arr["dof_pos"][0] > a["q_lo"] - 1.0)
     assert np.all(np.isfinite(st.arr["dof_pos"]))
+
+
+# ---- four-joint legs and the sole foot (tron1_sf) -------------------------------------------------
+@pytest.fixture(scope="module")
+def sf():
+    from hcr_genesis_lr_cl_amd.model_compiler import load_model
+    from hcr_genesis_lr_cl_amd.config import TRON1SFCfg
+    from hcr_genesis_lr_cl_amd import builders
+    model, cfg = load_model("tron1_sf"), TRON1SFCfg()
+    return dict(model=model, cfg=cfg, desc=builders.make_model_desc(model, cfg), opts=builders.make_sim_options(model, cfg))
+
+
+def test_sole_foot_model_topology(sf):
+    """SF_TRON1A/urdf/robot.urdf through the model compiler: 2 legs x 4 joints, 20.813 kg (sum of the URDF's link masses), the ankle
+    bodies are the feet (tron1_sf_config.py:82-84), each with the sole centre as its foot sphere and the four sole corners 5.5 cm
+    below the ankle axis (foot_height_offset, tron1_sf_config.py:100)."""
+    m, a = sf["model"], sf["model"].arrays
+    assert (m.n_legs, m.n_dof, m.joints_per_leg, m.n_links) == (2, 8, 4, 9) and abs(m.total_mass - 20.813) < 1e-6
+    assert m.foot_names == ["ankle_L_Link", "ankle_R_Link"] and list(a["foot_link"][:2]) == [4, 8]
+    for leg in range(2):
+        fs = int(a["foot_sphere"][leg])
+        assert a["sph_body"][fs] == 4 + 4 * leg and abs(a["sph_pos"][fs][2] - a["sph_r"][fs] + 0.055) < 1e-9
+        corners = [i for i in range(a["n_spheres"]) if a["sph_body"][i] == 4 + 4 * leg and i != fs]
+        assert len(corners) == 4 and np.allclose(a["sph_pos"][corners][:, 2], -0.055) and np.all(a["sph_r"][corners] == 0)
+        assert np.ptp(a["sph_pos"][corners][:, 0]) == pytest.approx(0.2) and np.ptp(a["sph_pos"][corners][:, 1]) == pytest.approx(0.06)
+
+
+def test_aba_matches_dense_solve_for_four_joint_legs(sf):
+    rng = np.random.default_rng(3)
+    for _ in range(12):
+        quat = rng.normal(size=4); quat /= np.linalg.norm(quat)
+        pos, vw, ww = rng.normal(size=3), rng.normal(size=3), rng.normal(size=3) * 2
+        q, qd, tau = rng.uniform(-0.6, 0.6, 8), rng.normal(size=8) * 3, rng.normal(size=8) * 10
+        a = orc.forward_dynamics(sf["desc"], sf["opts"], pos, quat, vw, ww, q, qd, tau, method=0)
+        b = orc.forward_dynamics(sf["desc"], sf["opts"], pos, quat, vw, ww, q, qd, tau, method=1)
+        np.testing.assert_allclose(a[0], b[0], rtol=1e-6, atol=2e-5)
+        np.testing.assert_allclose(a[1], b[1], rtol=1e-6, atol=2e-5)
+
+
+def test_sole_foot_statue_stands_on_its_soles(sf):
+    """With stiff joints the robot is a statue whose centre of mass lies over the soles: it has to stay upright for 10 s, the feet
+    carrying m g -- the sole corners transmit the ankle torque that a point foot could not (a point-foot statue topples).  Armature as
+    the task always randomises it in (tron1_sf_config.py:157-158)."""
+    desc, opts = copy.copy(sf["desc"]), copy.copy(sf["opts"])
+    for k in range(8):
+        desc.armature[k] = 0.12; opts.kp[k] = 400.0; opts.kd[k] = 10.0
+    st = orc.HostState(sf["model"], 1, cfgmod.default_dof_pos(sf["cfg"]), 0.84)
+    st.arr["added_base_mass"][:] = 0
+    act = np.zeros((1, 8), np.float32)
+    for k in range(500):
+        orc.sim_step(desc, opts, st, act, "f32")
+    f = st.arr["link_contact_forces"][0].reshape(9, 3)
+    mg = sf["model"].total_mass * 9.81
+    assert st.arr["projected_gravity"][0, 2] < -0.99 and 0.80 < st.arr["base_pos"][0, 2] < 0.84
+    assert abs(f[[4, 8], 2].sum() - mg) < 0.02 * mg and abs(f[:, 2].sum() - mg) < 0.02 * mg
+    assert np.abs(st.arr["dof_vel"]).max() < 0.05 and np.abs(st.arr["base_lin_vel_w"]).max() < 0.02

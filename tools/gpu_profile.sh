@@ -19,19 +19,19 @@ for T in $TASKS; do
   python tools/pmc_traffic.py "$F" "$W" $T || echo "pmc_traffic failed for $T"
   rocprofv3 --kernel-trace --pmc SQ_WAVES SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_LDS SQ_ACTIVE_INST_VALU SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY -d gpurun_out/pmc_sq_$T --output-format csv -- python3 tools/prof_steady.py 4096 300 128 $T > /dev/null 2> gpurun_out/pmc_sq_$T.err
   S=$(find gpurun_out/pmc_sq_$T -name "*counter_collection.csv" | head -1)
-  python tools/pmc_sq.py "$S" $T profiles/${TAG}_pmc_sq_$T.md > /dev/null || echo "pmc_sq failed for $T"
+  python tools/pmc_sq.py "$S" $T gpurun_out/${TAG}_pmc_sq_$T.md > /dev/null || echo "pmc_sq failed for $T"
 done
 cp profiles/hbm_traffic.json profiles/sq_counters.json gpurun_out/ 2>/dev/null || true
 echo "== bench lines (read the PMC summaries just written)"
 for T in $TASKS; do
   EXTRA=$([ $T = go2 ] && echo "--ppo-rollout 30" || echo "--no-cpu-baseline")
-  python bench.py --task $T $EXTRA > gpurun_out/${TAG}_bench_$T.json 2> gpurun_out/${TAG}_bench_$T.err
-  cp gpurun_out/${TAG}_bench_$T.json profiles/${TAG}_bench_$T.json
+  python bench.py --task $T $EXTRA > gpurun_out/${TAG}_bench_$T.json 2> gpurun_out/${TAG}_bench_$T.err || { echo "bench failed for $T"; continue; }
   python -c "import json;d=json.load(open('gpurun_out/${TAG}_bench_$T.json'));r=d['roofline'];print('$T', round(d['value']/1e6,2),'M env-steps/s', round(r['launch_us'],2),'us frac',round(r['frac'],4),'traffic',r['traffic'],'valu',(r['valu'] or {}).get('frac'))"
 done
 echo "== rocprofv3 kernel stats of the headline command"
 rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats --output-format csv -- python3 bench.py --steps 1000 --no-cpu-baseline > gpurun_out/bench_prof.json 2> gpurun_out/prof_stats.err
 S=$(find gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1)
-head -8 "$S" > profiles/${TAG}_kernel_stats.csv
-cp profiles/*.json profiles/${TAG}_* gpurun_out/ 2>/dev/null || true
-head -4 profiles/${TAG}_kernel_stats.csv | cut -c1-220
+head -8 "$S" > gpurun_out/${TAG}_kernel_stats.csv
+cp profiles/hbm_traffic.json profiles/sq_counters.json gpurun_out/ 2>/dev/null || true
+head -4 gpurun_out/${TAG}_kernel_stats.csv | cut -c1-220
+echo "copy gpurun_out/${TAG}_* + hbm_traffic.json + sq_counters.json into profiles/ (tracked)"

@@ -1,10 +1,14 @@
-"""Kernel-name substrings (as rocprofv3 prints them) of one control step of each BASELINE task at 4096 envs per GPU.
-First entry = the launch that happens exactly once per step."""
+"""Kernel-name prefixes (as rocprofv3 prints them, trailing template arguments left open) of one control step of each task at
+4096 envs per GPU.  First entry = the launch that happens exactly once per step."""
+_QUAD_FUSED = ["quad_sim_kernel<4, true, 12u,", "obs_compact_kernel"]
+_BIPED = ["quad_sim_kernel<2, true, 0u,", "env_step_kernel<2, 12u", "obs_compact_kernel"]
 STEP_KERNELS = {
-    "go2": ["quad_sim_kernel<4, true, 12u, true>"],
-    "go2_wtw": ["quad_sim_kernel<4, true, 12u, false>", "obs_compact_kernel"],
-    "go2_ee": ["quad_sim_kernel<4, true, 12u, false>", "obs_compact_kernel"],
-    "tron1_pf_ee": ["quad_sim_kernel<2, true, 0u, false>", "env_step_kernel<2, 12u>", "obs_compact_kernel"],
+    "go2": ["quad_sim_kernel<4, true, 12u,"],
+    "go2_wtw": _QUAD_FUSED, "go2_ee": _QUAD_FUSED, "tron1_pf_ee": _BIPED,
+    # not BASELINE configs
+    "go2_ts": _QUAD_FUSED, "go2_cts": _QUAD_FUSED, "go2_dreamwaq": _QUAD_FUSED, "tron1_pf": _BIPED,
+    "go2_cat": ["quad_sim_kernel<4, true, 0u,", "env_step_kernel<4, 12u", "obs_compact_kernel"],
+    "tron1_sf": ["env_step_kernel<2, 15u", "obs_compact_kernel"],
 }
 
 
