@@ -298,6 +298,11 @@ template <> struct HotLds<unsigned long long> { static LG_DEV unsigned long long
 template <> struct HotLds<long long> { static LG_DEV long long get(const int *s, int i) { return (long long)HotLds<unsigned long long>::get(s, i); } };
 #define HOT_T(f) typename std::remove_cv<typename std::remove_reference<decltype(((LgHot *)0)->f)>::type>::type
 #define CR(k) (__int_as_float(sHot[256 + (k)]))
+// observation programs (LgTaskCfg.priv_prog / labels_prog, 26 dwords each: n_segs, clip, kind[8], offset[8], scale[8]) staged behind the
+// command ranges: `which` 0 = priv_prog, 1 = labels_prog.  Read from T-> they were ~25 dependent scalar loads per launch.
+#define PRG_I(which, dw) (__builtin_amdgcn_readfirstlane(sHot[256 + BLOCK + 26 * (which) + (dw)]))
+#define PRG_F(which, dw) (__int_as_float(sHot[256 + BLOCK + 26 * (which) + (dw)]))
+static_assert(sizeof(LgObsProgram) == 26 * 4, "program staging assumes 26 dwords");
 #define HOT0(f) (HotGet<HOT_T(f)>::get(hv0, hv1, hv2, hv3, HOT_OFF(f)))   // prologue only (full exec, fresh registers)
 #define HOT(f) (HotLds<HOT_T(f)>::get(sHot, HOT_OFF(f)))
 // prologue accessor of env_step_body: lane registers in a stand-alone launch, LDS when fused behind the physics kernel
@@ -418,6 +423,23 @@ template <int NJ> LG_DEV V6 resp_down(const Joint (&J)[NJ], const V6 &a0, const 
         a = a + J[j].S * dqdd[j];
     }
     return a;
+}
+
+// N consecutive floats with as few store instructions as possible (global_store_dwordx4 / x3 / x2 take dword-aligned addresses).
+// A wave's store costs one cache-line transaction per distinct line it touches; in the leg-per-lane layout every lane writes into a
+// different row, so the observation section's time is its number of store instructions (measured: 18 single-dword puts of the actor
+// frame = 6.7 k cycles of the biped's MDP launch)
+template <int N> LG_DEV void stv(float *p, const float *c) {
+    typedef float v4f __attribute__((ext_vector_type(4)));
+    typedef float v3f __attribute__((ext_vector_type(3)));
+    typedef float v2f __attribute__((ext_vector_type(2)));
+    typedef v4f __attribute__((aligned(4))) u4f;
+    typedef v3f __attribute__((aligned(4))) u3f;
+    typedef v2f __attribute__((aligned(4))) u2f;
+    if constexpr (N >= 4) { const v4f t = {c[0], c[1], c[2], c[3]}; *reinterpret_cast<u4f *>(p) = t; if constexpr (N > 4) stv<N - 4>(p + 4, c + 4); }
+    else if constexpr (N == 3) { const v3f t = {c[0], c[1], c[2]}; *reinterpret_cast<u3f *>(p) = t; }
+    else if constexpr (N == 2) { const v2f t = {c[0], c[1]}; *reinterpret_cast<u2f *>(p) = t; }
+    else if constexpr (N == 1) p[0] = c[0];
 }
 
 struct RandSrc {
@@ -602,6 +624,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
 #pragma unroll
     for (int k = 0; k < LG_R_COUNT; k++) es[k] = 0.f;
     int crv = 0;   // command / behaviour ranges (runtime buffer): lane k holds entry k, read with v_readlane
+    int prw = 0;   // observation programs, one dword per lane (lanes 0-25 priv_prog, 26-51 labels_prog)
     V3 origin_pre = v3(0, 0, 0);
     // physics-side start-of-kernel loads: snapshot sources and per-env dynamics parameters
     V3 snap_fv = v3(0, 0, 0), snap_blv = v3(0, 0, 0), snap_bav = v3(0, 0, 0), dr_com = v3(0, 0, 0), dr_joint = v3(0, 0, 0);
@@ -638,6 +661,8 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         if (DO_RESET && B.obs_dirty) dirty_prev = B.obs_dirty[e];
         origin_pre = ld3(B.env_origins + 3 * e);
         if (!FUSED) crv = reinterpret_cast<const int *>(B.command_ranges)[min(vlane, LG_CMD_RANGE_FLOATS - 1)];
+        if (!FUSED && DO_RESET && !PLANE && !EEP && p.k.obs_layout == LG_OBS_PROGRAM)
+            prw = reinterpret_cast<const int *>(vlane < 26 ? &T->priv_prog : &T->labels_prog)[vlane < 26 ? vlane : min(vlane - 26, 25)];
         if (lead) {
 #pragma unroll
             for (int k = 0; k < LG_R_COUNT; k++) es[k] = ((rmask0 >> k) & 1u) ? B.episode_sums[(size_t)k * N + e] : 0.f;
@@ -667,7 +692,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     // next to its consumer, where its full round trip is exposed); no hardware wait is emitted here
     asm volatile("" ::: "memory");
     if (!FUSED) {
-        sHot[threadIdx.x] = hv0; sHot[threadIdx.x + 64] = hv1; sHot[threadIdx.x + 128] = hv2; sHot[threadIdx.x + 192] = hv3; sHot[threadIdx.x + 256] = crv;
+        sHot[threadIdx.x] = hv0; sHot[threadIdx.x + 64] = hv1; sHot[threadIdx.x + 128] = hv2; sHot[threadIdx.x + 192] = hv3; sHot[threadIdx.x + 256] = crv; sHot[threadIdx.x + 256 + BLOCK] = prw;
         sMraw[threadIdx.x] = stg0; sMraw[threadIdx.x + BLOCK] = stg1; sMraw[threadIdx.x + 2 * BLOCK] = stg2; sMraw[threadIdx.x + 3 * BLOCK] = stg3;
     }
     // MDP working set -> LDS for the duration of the physics (it arrived in the same load burst; parking it here keeps
@@ -1396,6 +1421,33 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         dirty_prev = __float_as_int(SS(c++));
     }
 
+    // Everything the privileged frames (observation section) read back from the state arrays -- DR parameters, terrain around the
+    // feet -- is loaded HERE, in one batch at the start of the MDP phases: the round trips pass under the reward terms, and nothing
+    // is loaded behind the reset block's and the observation section's stores (vmcnt retires loads and stores in order: a load next
+    // to each `putp` cost a store round trip apiece -- tron1: 25 of them, 17 k of the observation section's 24 k cycles).  A push or
+    // a reset updates these copies when it redraws the parameters.
+    float ld_kp[JPL], ld_kd[JPL], ld_nv3[3] = {0.f, 0.f, 0.f}, ld_haf[9];
+#pragma unroll
+    for (int j = 0; j < JPL; j++) ld_kp[j] = ld_kd[j] = 1.f;
+    float ld_fric = 1.f, ld_mass = 0.f, ld_com[3] = {0.f, 0.f, 0.f}, ld_push[2] = {0.f, 0.f}, ld_jnt[3] = {0.f, 0.f, 0.f};
+#pragma unroll
+    for (int k = 0; k < 9; k++) ld_haf[k] = 0.f;
+    if (DO_RESET && hc_obs_layout != LG_OBS_GO2) {   // ahead of the reset block's stores too; a reset updates these copies
+#pragma unroll
+        for (int j = 0; j < JPL; j++) { ld_kp[j] = B.kp_scale[e * A + d0 + j]; ld_kd[j] = B.kd_scale[e * A + d0 + j]; }
+        if (P > 0 && HOT(o_feet_terrain_info)) {
+#pragma unroll
+            for (int k = 0; k < 3; k++) ld_nv3[k] = B.normal_vector_around_feet[((size_t)e * F + foot_slot) * 3 + k];
+#pragma unroll
+            for (int k = 0; k < 9; k++) ld_haf[k] = B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k];
+        }
+        ld_fric = B.friction_values[e]; ld_mass = B.added_base_mass[e];
+#pragma unroll
+        for (int k = 0; k < 3; k++) ld_com[k] = B.base_com_bias[3 * e + k];
+        ld_push[0] = B.rand_push_vels[3 * e]; ld_push[1] = B.rand_push_vels[3 * e + 1];
+        if (B.joint_armature) { ld_jnt[0] = B.joint_armature[e]; ld_jnt[1] = B.joint_friction[e]; ld_jnt[2] = B.joint_damping[e]; }
+        asm volatile("" ::: "memory");
+    }
     // ======================= MDP: legged_robot.py:55-168, 300-334 ============================
     RandSrc rs;
     rs.in = B.rand_in ? B.rand_in + (size_t)e * HOT(slots.n_slots) : nullptr;
@@ -1468,6 +1520,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             const float m = hc_max_push_vel_xy;
             const float px = (m + m) * rs.draw(HOT(slots.push)) - m, py = (m + m) * rs.draw(HOT(slots.push) + 1) - m;
             vw.x += px; vw.y += py;
+            ld_push[0] = px; ld_push[1] = py;
             if (lead) {
                 B.rand_push_vels[3 * e] = px; B.rand_push_vels[3 * e + 1] = py;
                 B.base_lin_vel_w[3 * e] = vw.x; B.base_lin_vel_w[3 * e + 1] = vw.y;
@@ -1740,33 +1793,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     }
 
     STAMP(8);
-    // Everything the privileged frames (observation section below) read back from the state arrays -- DR parameters, terrain
-    // around the feet -- is loaded HERE, in one batch, ahead of the reset block's and the observation section's stores; a
-    // reset updates these copies when it redraws the parameters.  vmcnt retires loads and stores in order: a load issued
-    // after a run of stores is only usable once those stores have drained, so a load next to each `putp` cost a store
-    // round trip apiece (tron1: 25 of them, 17 k of the observation section's 24 k cycles).
-    float ld_kp[JPL], ld_kd[JPL], ld_nv3[3] = {0.f, 0.f, 0.f}, ld_haf[9];
-#pragma unroll
-    for (int j = 0; j < JPL; j++) ld_kp[j] = ld_kd[j] = 1.f;
-    float ld_fric = 1.f, ld_mass = 0.f, ld_com[3] = {0.f, 0.f, 0.f}, ld_push[2] = {0.f, 0.f}, ld_jnt[3] = {0.f, 0.f, 0.f};
-#pragma unroll
-    for (int k = 0; k < 9; k++) ld_haf[k] = 0.f;
-    if (DO_RESET && hc_obs_layout != LG_OBS_GO2) {   // ahead of the reset block's stores too; a reset updates these copies
-#pragma unroll
-        for (int j = 0; j < JPL; j++) { ld_kp[j] = B.kp_scale[e * A + d0 + j]; ld_kd[j] = B.kd_scale[e * A + d0 + j]; }
-        if (P > 0 && HOT(o_feet_terrain_info)) {
-#pragma unroll
-            for (int k = 0; k < 3; k++) ld_nv3[k] = B.normal_vector_around_feet[((size_t)e * F + foot_slot) * 3 + k];
-#pragma unroll
-            for (int k = 0; k < 9; k++) ld_haf[k] = B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k];
-        }
-        ld_fric = B.friction_values[e]; ld_mass = B.added_base_mass[e];
-#pragma unroll
-        for (int k = 0; k < 3; k++) ld_com[k] = B.base_com_bias[3 * e + k];
-        ld_push[0] = B.rand_push_vels[3 * e]; ld_push[1] = B.rand_push_vels[3 * e + 1];
-        if (B.joint_armature) { ld_jnt[0] = B.joint_armature[e]; ld_jnt[1] = B.joint_friction[e]; ld_jnt[2] = B.joint_damping[e]; }
-        asm volatile("" ::: "memory");
-    }
+    // Every load issued so far has long landed; say so.  vmcnt retires loads and stores in issue order, and the compiler's
+    // scoreboard keeps a prologue load "pending" until some wait formally covers it: the first use of such a value after the
+    // conditional stores below (joins with path-dependent store counts) then became `s_waitcnt vmcnt(0..2)`, i.e. a drain of the
+    // stores just issued -- five store round trips in the actor-frame section alone (~4 k cycles of the biped's MDP launch).
+    if (DO_RESET) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0), expcnt / lgkmcnt untouched
     // ---- reset_idx (legged_robot.py:94-148) + simulator.reset_idx (genesis_simulator.py:62-82) ----
     if (DO_RESET) {
         V3 pos_origin_override = v3(0, 0, 0);
@@ -1987,6 +2018,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     for (int i = leg; i < PF; i += LEGS) pv[f * PF + i] = reset ? 0.f : sp[(f + 1) * PF + i];
             }
         }
+        STAMP(25);
         // the frame written now also goes into the other set's row (same frame index): that set's window covers it at the
         // next launch
         float *on2 = (two && SL > 0 && ST > 1) ? oset_x + (size_t)e * orow + (size_t)p.obs_win * FR + (size_t)(ST - 1) * FR : nullptr;
@@ -2049,39 +2081,113 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 rs.block3(3 * LEGS + 2 + leg, uclk[0], uclk[1], dummy);
             }
         }
+        STAMP(26);
         // observation programs: where the noise-free actor frame sits inside the critic frame (0 in the fixed layouts, -1: not at
         // all) and where the "next state" copy goes in the labels row (-1: none)
         int pfo = 0, nxo = -1;
         float *labp = nullptr;
         if (hc_obs_layout == LG_OBS_PROGRAM) {
             pfo = -1;
-            for (int s_ = 0; s_ < T->priv_prog.n_segs; s_++) if (T->priv_prog.kind[s_] == LG_SEG_FRAME) pfo = T->priv_prog.offset[s_];
-            for (int s_ = 0; s_ < T->labels_prog.n_segs; s_++) if (T->labels_prog.kind[s_] == LG_SEG_NEXT_STATE) nxo = T->labels_prog.offset[s_];
+            for (int s_ = 0; s_ < PRG_I(0, 0); s_++) if (PRG_I(0, 2 + s_) == LG_SEG_FRAME) pfo = PRG_I(0, 10 + s_);
+            for (int s_ = 0; s_ < PRG_I(1, 0); s_++) if (PRG_I(1, 2 + s_) == LG_SEG_NEXT_STATE) nxo = PRG_I(1, 10 + s_);
             if (B.labels_buf) labp = B.labels_buf + ((size_t)cs * N + e) * hc_num_labels;
         }
-        const float pclip = (hc_obs_layout == LG_OBS_PROGRAM && !T->priv_prog.clip) ? 3.0e38f : co;
-        auto put = [&](int idx, float v, float u, float nscale) {   // critic copy of the frame is noise-free
-            if (has_pn && pfo >= 0) { const float c = clampf(v, -pclip, pclip); pn[pfo + idx] = c; if (has_pn2) pn2[pfo + idx] = c; }
-            if (nxo >= 0) labp[nxo + idx] = idx >= 9 + 2 * A ? v * HOT(o_action_scale) : v;     // go2_dreamwaq.py:66-74, not clipped
-            if (nz) v += (2.f * u - 1.f) * nscale;
-            const float c = clampf(v, -co, co);
-            on[idx] = c;
-            if (has_on2) on2[idx] = c;
+        const float pclip = (hc_obs_layout == LG_OBS_PROGRAM && !PRG_I(0, 1)) ? 3.0e38f : co;
+        // NV consecutive entries of the actor frame starting at idx0: noise + clip into this launch's window (and the other set's),
+        // the noise-free copy into the critic frame (and the "next state" labels); one store instruction per destination (stv)
+        auto putv = [&](auto nv_, const int idx0, const float *v, const float *u, const float *nscale) {
+            constexpr int NV = decltype(nv_)::value;
+            float cn[NV];
+            if (has_pn && pfo >= 0) {   // critic copy of the frame is noise-free
+#pragma unroll
+                for (int k = 0; k < NV; k++) cn[k] = clampf(v[k], -pclip, pclip);
+                stv<NV>(pn + pfo + idx0, cn);
+                if (has_pn2) stv<NV>(pn2 + pfo + idx0, cn);
+            }
+            if (nxo >= 0) {             // go2_dreamwaq.py:66-74, not clipped; the action entries scaled
+                const float sc = idx0 >= 9 + 2 * A ? HOT(o_action_scale) : 1.f;
+#pragma unroll
+                for (int k = 0; k < NV; k++) cn[k] = idx0 >= 9 + 2 * A ? v[k] * sc : v[k];
+                stv<NV>(labp + nxo + idx0, cn);
+            }
+#pragma unroll
+            for (int k = 0; k < NV; k++) {
+                float x = v[k];
+                if (nz) x += (2.f * u[k] - 1.f) * nscale[k];
+                cn[k] = clampf(x, -co, co);
+            }
+            stv<NV>(on + idx0, cn);
+            if (has_on2) stv<NV>(on2 + idx0, cn);
         };
-        auto putp = [&](int idx, float v) { const float c = clampf(v, -co, co); pn[idx] = c; if (has_pn2) pn2[idx] = c; };
-        if (live) {
+        // NV consecutive entries of the critic frame (clipped like the reference's step() output)
+        auto putpv = [&](auto nv_, const int idx0, const float *v) {
+            constexpr int NV = decltype(nv_)::value;
+            float cn[NV];
+#pragma unroll
+            for (int k = 0; k < NV; k++) cn[k] = clampf(v[k], -co, co);
+            stv<NV>(pn + idx0, cn);
+            if (has_pn2) stv<NV>(pn2 + idx0, cn);
+        };
+        auto put = [&](int idx, float v, float u, float nscale) { putv(std::integral_constant<int, 1>{}, idx, &v, &u, &nscale); };
+        auto putp = [&](int idx, float v) { putpv(std::integral_constant<int, 1>{}, idx, &v); };
+        constexpr std::integral_constant<int, JPL> NJ{};
+        constexpr std::integral_constant<int, 3> N3{};
+        {   // The actor frame: 3 x JPL joint entries per lane, 9 base entries on the lead lane.  Every value is formed FIRST, then
+            // the stores go out back to back, destination by destination: a store's data registers stay locked until the store has
+            // completed (the compiler waits on vmcnt before overwriting them), so computing the next group into registers the previous
+            // group had just stored from cost a store round trip (~1 k cycles) per group.
+            float vj[3][JPL], nj[3][JPL], fj[3][JPL], vl[9], nl[9], fl[9];
+#pragma unroll
+            for (int j = 0; j < JPL; j++) { vj[0][j] = (q[j] - q0l[j]) * hc_obs_scale_dof_pos; vj[1][j] = qd[j] * hc_obs_scale_dof_vel; vj[2][j] = act[j]; }
 #pragma unroll
             for (int j = 0; j < JPL; j++) {
-                put(9 + d0 + j, (q[j] - q0l[j]) * hc_obs_scale_dof_pos, uq[j], nv_q[j]);
-                put(9 + A + d0 + j, qd[j] * hc_obs_scale_dof_vel, uqd[j], nv_qd[j]);
-                put(9 + 2 * A + d0 + j, act[j], uact[j], nv_act[j]);
+                const float un[3] = {uq[j], uqd[j], uact[j]}, sn[3] = {nv_q[j], nv_qd[j], nv_act[j]};
+#pragma unroll
+                for (int g = 0; g < 3; g++) {
+                    fj[g][j] = clampf(vj[g][j], -pclip, pclip);
+                    nj[g][j] = clampf(nz ? vj[g][j] + (2.f * un[g] - 1.f) * sn[g] : vj[g][j], -co, co);
+                }
+            }
+            vl[0] = cmd0 * hc_obs_scale_lin_vel; vl[1] = cmd1 * hc_obs_scale_lin_vel; vl[2] = cmd2 * hc_obs_scale_ang_vel;
+            vl[3] = pg.x; vl[4] = pg.y; vl[5] = pg.z;
+            vl[6] = bav.x * hc_obs_scale_ang_vel; vl[7] = bav.y * hc_obs_scale_ang_vel; vl[8] = bav.z * hc_obs_scale_ang_vel;
+#pragma unroll
+            for (int k = 0; k < 9; k++) {
+                fl[k] = clampf(vl[k], -pclip, pclip);
+                const float x = (nz && k >= 3) ? vl[k] + (2.f * ub[k - 3] - 1.f) * HOT(noise_lead[k - 3]) : vl[k];
+                nl[k] = clampf(x, -co, co);
+            }
+            const bool crit = has_pn && pfo >= 0;
+            if (live) {
+#pragma unroll
+                for (int g = 0; g < 3; g++) stv<JPL>(on + 9 + g * A + d0, nj[g]);
+                if (has_on2) {
+#pragma unroll
+                    for (int g = 0; g < 3; g++) stv<JPL>(on2 + 9 + g * A + d0, nj[g]);
+                }
+                if (crit) {   // critic copy of the frame is noise-free
+#pragma unroll
+                    for (int g = 0; g < 3; g++) stv<JPL>(pn + pfo + 9 + g * A + d0, fj[g]);
+                    if (has_pn2) {
+#pragma unroll
+                        for (int g = 0; g < 3; g++) stv<JPL>(pn2 + pfo + 9 + g * A + d0, fj[g]);
+                    }
+                }
+                if (nxo >= 0) {   // go2_dreamwaq.py:66-74: the "next state" labels, not clipped, actions scaled
+                    float sa[JPL];
+#pragma unroll
+                    for (int j = 0; j < JPL; j++) sa[j] = vj[2][j] * HOT(o_action_scale);
+                    stv<JPL>(labp + nxo + 9 + d0, vj[0]); stv<JPL>(labp + nxo + 9 + A + d0, vj[1]); stv<JPL>(labp + nxo + 9 + 2 * A + d0, sa);
+                }
+            }
+            if (lead) {
+                stv<9>(on, nl);
+                if (has_on2) stv<9>(on2, nl);
+                if (crit) { stv<9>(pn + pfo, fl); if (has_pn2) stv<9>(pn2 + pfo, fl); }
+                if (nxo >= 0) stv<9>(labp + nxo, vl);
             }
         }
-        if (lead) {
-            put(0, cmd0 * hc_obs_scale_lin_vel, 0.5f, 0.f); put(1, cmd1 * hc_obs_scale_lin_vel, 0.5f, 0.f); put(2, cmd2 * hc_obs_scale_ang_vel, 0.5f, 0.f);
-            put(3, pg.x, ub[0], HOT(noise_lead[0])); put(4, pg.y, ub[1], HOT(noise_lead[1])); put(5, pg.z, ub[2], HOT(noise_lead[2]));
-            put(6, bav.x * hc_obs_scale_ang_vel, ub[3], HOT(noise_lead[3])); put(7, bav.y * hc_obs_scale_ang_vel, ub[4], HOT(noise_lead[4])); put(8, bav.z * hc_obs_scale_ang_vel, ub[5], HOT(noise_lead[5]));
-        }
+        STAMP(27);
         if (hc_obs_layout == LG_OBS_GO2_WTW) {
             const float ang = 6.283185307179586f * (phi + theta);      // clock inputs (go2_wtw.py:251-256)
             if (live) {
@@ -2089,20 +2195,17 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 put(45 + foot_slot, sn, 0.5f, 0.f);
                 put(49 + foot_slot, cs, 0.5f, 0.f);
                 put(57 + foot_slot, theta, 0.5f, 0.f);
-#pragma unroll
-                for (int j = 0; j < JPL; j++) {
-                    putp(FR + 10 + d0 + j, ld_kp[j]);
-                    putp(FR + 10 + A + d0 + j, ld_kd[j]);
-                }
+                putpv(NJ, FR + 10 + d0, ld_kp);
+                putpv(NJ, FR + 10 + A + d0, ld_kd);
                 putp(FR + 10 + 2 * A + foot_slot, expC);
                 ts[6 + foot_slot] = theta; ts[10 + foot_slot] = sn; ts[14 + foot_slot] = cs; ts[18 + foot_slot] = expC;
             }
             if (lead) {
-                put(53, gait_period, 0.5f, 0.f); put(54, bh_tgt, 0.5f, 0.f); put(55, fc_tgt, 0.5f, 0.f); put(56, pitch_tgt, 0.5f, 0.f);
-                putp(FR + 0, blv.x * hc_obs_scale_lin_vel); putp(FR + 1, blv.y * hc_obs_scale_lin_vel); putp(FR + 2, blv.z * hc_obs_scale_lin_vel);
-                putp(FR + 3, ld_push[0]); putp(FR + 4, ld_push[1]);
-                putp(FR + 5, ld_mass); putp(FR + 6, ld_fric);
-                putp(FR + 7, ld_com[0]); putp(FR + 8, ld_com[1]); putp(FR + 9, ld_com[2]);
+                const float vb[4] = {gait_period, bh_tgt, fc_tgt, pitch_tgt}, hb[4] = {0.5f, 0.5f, 0.5f, 0.5f}, zb[4] = {0.f, 0.f, 0.f, 0.f};
+                putv(std::integral_constant<int, 4>{}, 53, vb, hb, zb);
+                const float vp[10] = {blv.x * hc_obs_scale_lin_vel, blv.y * hc_obs_scale_lin_vel, blv.z * hc_obs_scale_lin_vel, ld_push[0], ld_push[1],
+                                      ld_mass, ld_fric, ld_com[0], ld_com[1], ld_com[2]};
+                putpv(std::integral_constant<int, 10>{}, FR, vp);
             }
         } else if (hc_obs_layout == LG_OBS_GO2_EE) {
             // critic frame (go2_ee.py:21-48): obs 45 | DR 31 | contact states K | heights P
@@ -2110,11 +2213,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             const int l0 = foot_link - 3;
             float *lab = B.labels_buf + ((size_t)cs * N + e) * hc_num_labels;
             if (live) {
+                float vkp[JPL], vkd[JPL];
 #pragma unroll
-                for (int j = 0; j < JPL; j++) {
-                    putp(FR + 7 + d0 + j, ld_kp[j] - HOT(kp_offset));
-                    putp(FR + 7 + A + d0 + j, ld_kd[j] - HOT(kd_offset));
-                }
+                for (int j = 0; j < JPL; j++) { vkp[j] = ld_kp[j] - HOT(kp_offset); vkd[j] = ld_kd[j] - HOT(kd_offset); }
+                putpv(NJ, FR + 7 + d0, vkp);
+                putpv(NJ, FR + 7 + A + d0, vkd);
                 // contact states are those of the physics read-back (stale for a just-reset env, as in the reference)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -2145,11 +2248,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmean - hc_foot_height_offset, -1.f, 1.f);
             }
             if (lead) {
-                putp(FR + 0, ld_fric - HOT(friction_offset)); putp(FR + 1, ld_mass);
-                putp(FR + 2, ld_com[0]); putp(FR + 3, ld_com[1]); putp(FR + 4, ld_com[2]);
-                putp(FR + 5, ld_push[0]); putp(FR + 6, ld_push[1]);
+                const float vdr[7] = {ld_fric - HOT(friction_offset), ld_mass, ld_com[0], ld_com[1], ld_com[2], ld_push[0], ld_push[1]};
+                putpv(std::integral_constant<int, 7>{}, FR, vdr);
                 if (M->state_link_mask & 1u) { const float cs = norm(f_base) > 1.f ? 1.f : 0.f; putp(FR + 7 + 2 * A, cs); lab[3] = cs; }
-                lab[0] = blv.x * hc_obs_scale_lin_vel; lab[1] = blv.y * hc_obs_scale_lin_vel; lab[2] = blv.z * hc_obs_scale_lin_vel;
+                const float vl[3] = {blv.x * hc_obs_scale_lin_vel, blv.y * hc_obs_scale_lin_vel, blv.z * hc_obs_scale_lin_vel};
+                stv<3>(lab, vl);
             }
         } else if (hc_obs_layout == LG_OBS_TRON1_EE) {
             // tron1_pf_ee.py:53-141.  actor frame: 9 + 3A + clock 2F.  critic frame: frame | DR (7 + 2A + 3) |
@@ -2164,11 +2267,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 put(9 + 3 * A + foot_slot, sn, uclk[0], nv_clk[0]);
                 put(9 + 3 * A + F + foot_slot, cs, uclk[1], nv_clk[1]);
                 ts[4 + foot_slot] = theta; ts[6 + foot_slot] = sn; ts[6 + F + foot_slot] = cs; ts[10 + foot_slot] = expC;
+                float vkp[JPL], vkd[JPL];
 #pragma unroll
-                for (int j = 0; j < JPL; j++) {
-                    putp(oDR + 7 + d0 + j, ld_kp[j] - HOT(kp_offset));
-                    putp(oDR + 7 + A + d0 + j, ld_kd[j] - HOT(kd_offset));
-                }
+                for (int j = 0; j < JPL; j++) { vkp[j] = ld_kp[j] - HOT(kp_offset); vkd[j] = ld_kd[j] - HOT(kd_offset); }
+                putpv(NJ, oDR + 7 + d0, vkp);
+                putpv(NJ, oDR + 7 + A + d0, vkd);
                 putp(oG + foot_slot, expC);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -2195,53 +2298,65 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                         putp(oH + k, hv);
                     }
                 }
-                const float (&nv3)[3] = ld_nv3;
+                putpv(N3, oN + 3 * foot_slot, ld_nv3);
+                stv<3>(lab + 3 + K + F + 3 * foot_slot, ld_nv3);
+                float vrel[9];
 #pragma unroll
-                for (int k = 0; k < 3; k++) { putp(oN + 3 * foot_slot + k, nv3[k]); lab[3 + K + F + 3 * foot_slot + k] = nv3[k]; }
-#pragma unroll
-                for (int k = 0; k < 9; k++)
-                    putp(oR + 9 * foot_slot + k, clampf(foot_p.z - ld_haf[k], -1.f, 1.f));
+                for (int k = 0; k < 9; k++) vrel[k] = clampf(foot_p.z - ld_haf[k], -1.f, 1.f);
+                putpv(std::integral_constant<int, 9>{}, oR + 9 * foot_slot, vrel);
                 lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmax - hc_foot_height_offset, -1.f, 1.f);
             }
             if (lead) {
-                putp(oDR + 0, ld_fric - HOT(friction_offset)); putp(oDR + 1, ld_mass);
-                putp(oDR + 2, ld_com[0]); putp(oDR + 3, ld_com[1]); putp(oDR + 4, ld_com[2]);
-                putp(oDR + 5, ld_push[0]); putp(oDR + 6, ld_push[1]);
-                putp(oDR + 7 + 2 * A, ld_jnt[0]);
-                putp(oDR + 8 + 2 * A, ld_jnt[1]);
-                putp(oDR + 9 + 2 * A, ld_jnt[2]);
+                const float vdr[7] = {ld_fric - HOT(friction_offset), ld_mass, ld_com[0], ld_com[1], ld_com[2], ld_push[0], ld_push[1]};
+                putpv(std::integral_constant<int, 7>{}, oDR, vdr);
+                putpv(N3, oDR + 7 + 2 * A, ld_jnt);
                 if (M->state_link_mask & 1u) { const float cst = norm(f_base) > 1.f ? 1.f : 0.f; putp(oK, cst); lab[3] = cst; }
-                lab[0] = blv.x * hc_obs_scale_lin_vel; lab[1] = blv.y * hc_obs_scale_lin_vel; lab[2] = blv.z * hc_obs_scale_lin_vel;
+                const float vl[3] = {blv.x * hc_obs_scale_lin_vel, blv.y * hc_obs_scale_lin_vel, blv.z * hc_obs_scale_lin_vel};
+                stv<3>(lab, vl);
             }
         } else if (hc_obs_layout == LG_OBS_PROGRAM) {
             // go2_ts / go2_cts / go2_dreamwaq / go2_cat: actor frame = go2's 45 (written above); the critic frame and the
             // auxiliary output are concatenations of the blocks of LgObsSeg at the offsets the task's programs give
             const int K = __popc(M->state_link_mask);
             const int l0 = foot_link - 3;
-            auto run = [&](const LgObsProgram &pr, const bool to_lab) {
-                const float cl = pr.clip ? co : 3.0e38f;
-                auto Wr = [&](int idx, float v) {
-                    v = clampf(v, -cl, cl);
-                    if (to_lab) labp[idx] = v;
-                    else { pn[idx] = v; if (has_pn2) pn2[idx] = v; }
-                };
-                for (int s_ = 0; s_ < pr.n_segs; s_++) {
-                    const int kind = pr.kind[s_], off = pr.offset[s_];
-                    const float sc = pr.scale[s_];
-                    if (kind == LG_SEG_DR) {
-                        if (live) {
+            // `which`: 0 = critic frame (priv_prog), 1 = auxiliary row (labels_prog); the program words come from LDS (PRG_I / PRG_F)
+            auto run = [&](const int which, const bool to_lab) {
+                const float cl = PRG_I(which, 1) ? co : 3.0e38f;
+                auto WrV = [&](auto nv_, const int idx0, const float *v) {     // NV consecutive entries, one store per destination
+                    constexpr int NV = decltype(nv_)::value;
+                    float cn[NV];
 #pragma unroll
-                            for (int j = 0; j < JPL; j++) { Wr(off + 7 + d0 + j, ld_kp[j] - HOT(kp_offset)); Wr(off + 7 + A + d0 + j, ld_kd[j] - HOT(kd_offset)); }
+                    for (int k = 0; k < NV; k++) cn[k] = clampf(v[k], -cl, cl);
+                    if (to_lab) stv<NV>(labp + idx0, cn);
+                    else { stv<NV>(pn + idx0, cn); if (has_pn2) stv<NV>(pn2 + idx0, cn); }
+                };
+                auto Wr = [&](int idx, float v) { WrV(std::integral_constant<int, 1>{}, idx, &v); };
+                constexpr std::integral_constant<int, 7> N7{};
+                constexpr std::integral_constant<int, 9> N9{};
+                const int n_segs = PRG_I(which, 0);
+                for (int s_ = 0; s_ < n_segs; s_++) {
+                    const int kind = PRG_I(which, 2 + s_), off = PRG_I(which, 10 + s_);
+                    const float sc = PRG_F(which, 18 + s_);
+                    const float vdr[7] = {ld_fric - HOT(friction_offset), ld_mass, ld_com[0], ld_com[1], ld_com[2], ld_push[0], ld_push[1]};
+                    if (kind == LG_SEG_DR || kind == LG_SEG_KP || kind == LG_SEG_KD) {
+                        if (live) {
+                            float vkp[JPL], vkd[JPL];
+#pragma unroll
+                            for (int j = 0; j < JPL; j++) { vkp[j] = ld_kp[j] - HOT(kp_offset); vkd[j] = ld_kd[j] - HOT(kd_offset); }
+                            if (kind == LG_SEG_DR) { WrV(NJ, off + 7 + d0, vkp); WrV(NJ, off + 7 + A + d0, vkd); }
+                            else {
+                                float vs[JPL];
+#pragma unroll
+                                for (int j = 0; j < JPL; j++) vs[j] = kind == LG_SEG_KP ? vkp[j] : vkd[j];
+                                WrV(NJ, off + d0, vs);
+                            }
                         }
-                        if (lead) {
-                            Wr(off + 0, ld_fric - HOT(friction_offset)); Wr(off + 1, ld_mass);
-                            Wr(off + 2, ld_com[0]); Wr(off + 3, ld_com[1]); Wr(off + 4, ld_com[2]);
-                            Wr(off + 5, ld_push[0]); Wr(off + 6, ld_push[1]);
-                        }
+                        if (lead && kind == LG_SEG_DR) WrV(N7, off, vdr);
                     } else if (kind == LG_SEG_DR_JOINT) {
-                        if (lead) { Wr(off + 0, ld_jnt[0]); Wr(off + 1, ld_jnt[1]); Wr(off + 2, ld_jnt[2]); }
+                        if (lead) WrV(N3, off, ld_jnt);
                     } else if (kind == LG_SEG_BASE_LIN_VEL) {
-                        if (lead) { Wr(off + 0, blv.x * hc_obs_scale_lin_vel * sc); Wr(off + 1, blv.y * hc_obs_scale_lin_vel * sc); Wr(off + 2, blv.z * hc_obs_scale_lin_vel * sc); }
+                        const float vb[3] = {blv.x * hc_obs_scale_lin_vel * sc, blv.y * hc_obs_scale_lin_vel * sc, blv.z * hc_obs_scale_lin_vel * sc};
+                        if (lead) WrV(N3, off, vb);
                     } else if (kind == LG_SEG_CONTACT_STATES) {
                         // contact states are those of the physics read-back (stale for a just-reset env, as in the reference)
                         if (live) {
@@ -2270,46 +2385,28 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                                 }
                             }
                         }
-                    } else if (kind == LG_SEG_FEET_REL_HEIGHTS) {
+                    } else if (kind == LG_SEG_FEET_REL_HEIGHTS || kind == LG_SEG_FEET_HEIGHTS) {
                         if (live) {
+                            float vh[9];
 #pragma unroll
-                            for (int k = 0; k < 9; k++) Wr(off + 9 * foot_slot + k, clampf(foot_p.z - ld_haf[k], -1.f, 1.f));
-                        }
-                    } else if (kind == LG_SEG_FEET_HEIGHTS) {
-                        if (live) {
-#pragma unroll
-                            for (int k = 0; k < 9; k++) Wr(off + 9 * foot_slot + k, ld_haf[k]);
+                            for (int k = 0; k < 9; k++) vh[k] = kind == LG_SEG_FEET_HEIGHTS ? ld_haf[k] : clampf(foot_p.z - ld_haf[k], -1.f, 1.f);
+                            WrV(N9, off + 9 * foot_slot, vh);
                         }
                     } else if (kind == LG_SEG_FEET_NORMALS) {
-                        if (live) {
-#pragma unroll
-                            for (int k = 0; k < 3; k++) Wr(off + 3 * foot_slot + k, ld_nv3[k]);
-                        }
+                        if (live) WrV(N3, off + 3 * foot_slot, ld_nv3);
                     } else if (kind == LG_SEG_LAST_ACTIONS) {     // a_{t-1}: zero for an env that was just reset
-                        if (live) {
-#pragma unroll
-                            for (int j = 0; j < JPL; j++) Wr(off + d0 + j, last_act[j]);
-                        }
+                        if (live) WrV(NJ, off + d0, last_act);
                     } else if (kind == LG_SEG_DR_BASE) {
-                        if (lead) {
-                            Wr(off + 0, ld_fric - HOT(friction_offset)); Wr(off + 1, ld_mass);
-                            Wr(off + 2, ld_com[0]); Wr(off + 3, ld_com[1]); Wr(off + 4, ld_com[2]);
-                            Wr(off + 5, ld_push[0]); Wr(off + 6, ld_push[1]);
-                        }
+                        if (lead) WrV(N7, off, vdr);
                     } else if (kind == LG_SEG_FEET_AIR_TIME) {
                         if (live) Wr(off + foot_slot, air);
-                    } else if (kind == LG_SEG_KP || kind == LG_SEG_KD) {
-                        if (live) {
-#pragma unroll
-                            for (int j = 0; j < JPL; j++) Wr(off + d0 + j, kind == LG_SEG_KP ? ld_kp[j] - HOT(kp_offset) : ld_kd[j] - HOT(kd_offset));
-                        }
                     } else if (kind == LG_SEG_FOOT_CLEARANCE) {
                         if (live) Wr(off + foot_slot, clampf(foot_p.z - foot_hmean - hc_foot_height_offset, -1.f, 1.f));
-                    }   // LG_SEG_FRAME / LG_SEG_NEXT_STATE: written entry by entry in put()
+                    }   // LG_SEG_FRAME / LG_SEG_NEXT_STATE: written group by group in putv()
                 }
             };
-            if (pn) run(T->priv_prog, false);
-            if (labp) run(T->labels_prog, true);
+            if (pn) run(0, false);
+            if (labp) run(1, true);
         }
     }
     if (WTW && lead) {
@@ -2353,7 +2450,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
 template <int LEGS, unsigned PH, int PROF = 0, int JPL = 3>
 __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_STG * BLOCK];
-    __shared__ int sHot[256 + BLOCK];
+    __shared__ int sHot[256 + 2 * BLOCK];
     env_step_body<LEGS, PH, false, PROF, JPL>(p, sMraw, sHot, nullptr, nullptr, blockIdx.x * BLOCK + threadIdx.x, threadIdx.x & 63);
 }
 

@@ -317,7 +317,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_STG * BLOCK];
     const LgModelDesc *M = reinterpret_cast<const LgModelDesc *>(sMraw);
     const LgSimOptions *__restrict__ O = p.O;
-    __shared__ int sHot[256 + BLOCK];
+    __shared__ int sHot[256 + 2 * BLOCK];
     int hv0, hv1, hv2, hv3;
     {
         const int GAS *hp = KPTR(const int GAS *, offsetof(KParams, H)) + (threadIdx.x & 63);
@@ -411,6 +411,11 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     const float origin = k_env_origins ? k_env_origins[3 * e + cj] : 0.f;
     int crv = 0;
     if (MPH != 0) crv = reinterpret_cast<const int GAS *>(k_command_ranges)[min((int)threadIdx.x, LG_CMD_RANGE_FLOATS - 1)];
+    int prw = 0;   // observation programs for the MDP tail (lg_kernel.hip PRG_I / PRG_F)
+    if ((MPH & LG_PHASE_RESET) != 0 && (PROF == 4 || (PROF == 0 && KINT(k.obs_layout) == LG_OBS_PROGRAM))) {
+        const int tl = (int)threadIdx.x;
+        prw = reinterpret_cast<const int GAS *>(tl < 26 ? &kT->priv_prog : &kT->labels_prog)[tl < 26 ? tl : min(tl - 26, 25)];
+    }
     // MDP working set of the wave's 16 legs, fetched by lanes 0..15 in this same burst and parked in LDS: the MDP tail
     // (env_step_body<.., FUSED>) reads it back after the physics instead of paying the round trips then.  Layout = the
     // stash of env_step_body (NST values x 16 lanes).
@@ -468,6 +473,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     sHot[threadIdx.x] = hv0; sHot[threadIdx.x + 64] = hv1; sHot[threadIdx.x + 128] = hv2; sHot[threadIdx.x + 192] = hv3;
     if (MPH != 0) {
         sHot[threadIdx.x + 256] = crv;
+        sHot[threadIdx.x + 256 + BLOCK] = prw;
         if (!QTAIL && threadIdx.x < 16) {
             const unsigned rm = p.k.reward_mask;
             const bool leadL = (blockIdx.x * 16 + threadIdx.x) % LEGS == 0;
