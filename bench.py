@@ -412,9 +412,7 @@ def main():
         achieved = bytes_env * n_local / launch_s / 1e9
         wkey = f"{'go2_flat' if args.task == 'go2' else args.task}_{n_local}"
         legs = 2 if args.task.startswith("tron1") else 4
-        if args.task == "tron1_sf":
-            layout = "env_step_kernel<2,ALL,0,4> (leg-per-lane, four-joint legs)"
-        elif args.task == "go2_cat":
+        if args.task == "go2_cat":
             layout = "quad_sim_kernel<4,PRE,0> + env_step_kernel<4,POST|RESET> (the job-wide CaT flag separates physics and MDP; timed together)"
         elif n_local * legs * 4 > 2048 * 64:
             layout = f"env_step_kernel<{legs},ALL> (leg-per-lane)"

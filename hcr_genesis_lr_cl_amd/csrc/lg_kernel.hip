@@ -324,7 +324,7 @@ struct KParams {
     // front of the burst
     struct { int m_n_links, m_foot_link[4], obs_layout, o_n_height_points; unsigned reward_mask; float clip_actions;
              int cat_enable;      // LgTaskCfg.cat_enable: tested on every step, so not behind a memory round trip
-             int joint_axis[3];   // per joint index: 0/1/2 if that joint's axis is +-e_x/e_y/e_z on every leg, else -1 (lg_quad.h joint_rot)
+             int joint_axis[4];   // per joint index: 0/1/2 if that joint's axis is +-e_x/e_y/e_z on every leg, else -1 (lg_quad.h joint_rot)
     } k;
     int obs_win;         // first frame of the observation window this launch writes (sliding history, LgTaskCfg.obs_slack)
     int obs_set;         // copy of obs_buf / priv_obs_buf / labels_buf this launch writes (LgTaskCfg.obs_sets)
@@ -881,10 +881,10 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     const V3 v = V.l + cross(V.a, r);
                     float wi = sp.w;
                     if (JPL == 4 && ank) { const float g = dot(n, ank->S.l + cross(ank->S.a, r - n * rad)); wi += 2.f * g * g * ank->dinv; }
-                    const float vn = dot(v, n) - vref;
+                    const float vnf = dot(v, n), vn = vnf - vref;
                     const float fn = (kc * depth - kappa * vn) * rcp(1.f + kappa * dt * wi);
                     if (fn > 0.f) {
-                        const V3 vt = v - n * vn;
+                        const V3 vt = v - n * vnf;
                         const float vtn = norm(vt);
                         const float ft = fminf(vtn * rcp(dt * wi), mu * fn);
                         V3 f = n * fn;
@@ -1145,6 +1145,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         }  // sub-steps
 
         STAMP(4);
+        __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): the start-of-kernel loads have landed; nothing queues behind the read-back stores (see lg_quad.h)
         if (!PLANE && p.k.cat_enable) {   // go2_cat's job-wide "some joint faster than 4 rad/s" flag (LG_CR_ANY_FAST): every wave that sees one raises it
             bool fast = false;
 #pragma unroll
@@ -1448,6 +1449,21 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         if (B.joint_armature) { ld_jnt[0] = B.joint_armature[e]; ld_jnt[1] = B.joint_friction[e]; ld_jnt[2] = B.joint_damping[e]; }
         asm volatile("" ::: "memory");
     }
+    // go2_cat: the task's constraint limits and this env's violation counters, in the same batch (read at the point of use each was an
+    // exposed round trip, the nine counters a load -> add -> store chain behind the stores before it: 7 k of the launch's cycles)
+    float cat_lim[JPL], cat_tql[JPL], cat_ar = 0.f, cat_minh = 0.f, cat_maxg = 0.f, cat_sp = 0.f, cat_cnt[LG_NUM_CSTR];
+#pragma unroll
+    for (int j = 0; j < JPL; j++) cat_lim[j] = cat_tql[j] = 0.f;
+#pragma unroll
+    for (int k = 0; k < LG_NUM_CSTR; k++) cat_cnt[k] = 0.f;
+    if (DO_POST && !PLANE && !EEP && p.k.cat_enable) {
+#pragma unroll
+        for (int j = 0; j < JPL; j++) { cat_lim[j] = T->dof_vel_limits[d0 + j]; cat_tql[j] = M->effort[d0 + j]; }
+        cat_ar = T->cat_action_rate; cat_minh = T->cat_min_base_height; cat_maxg = T->cat_max_projected_gravity; cat_sp = T->cat_soft_p;
+#pragma unroll
+        for (int k = 0; k < LG_NUM_CSTR; k++) cat_cnt[k] = B.cstr_sums[(size_t)k * N + e];
+        asm volatile("" ::: "memory");
+    }
     // ======================= MDP: legged_robot.py:55-168, 300-334 ============================
     RandSrc rs;
     rs.in = B.rand_in ? B.rand_in + (size_t)e * HOT(slots.n_slots) : nullptr;
@@ -1556,9 +1572,9 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             int c_tq = 0, c_qd = 0, c_ar = 0, lo_any = 0, hi_any = 0, c_fast = 0;
 #pragma unroll
             for (int j = 0; j < JPL; j++) {
-                c_tq |= fabsf(torque[j]) > M->effort[d0 + j] ? 1 : 0;
-                c_qd |= fabsf(qd[j]) > T->dof_vel_limits[d0 + j] ? 1 : 0;
-                c_ar |= fabsf(act[j] - last_act[j]) / cdt > T->cat_action_rate ? 1 : 0;
+                c_tq |= fabsf(torque[j]) > cat_tql[j] ? 1 : 0;
+                c_qd |= fabsf(qd[j]) > cat_lim[j] ? 1 : 0;
+                c_ar |= fabsf(act[j] - last_act[j]) / cdt > cat_ar ? 1 : 0;
                 lo_any |= q[j] < soft_lo[j] ? 1 : 0;
                 hi_any |= q[j] > soft_hi[j] ? 1 : 0;
                 c_fast |= fabsf(qd[j]) > 4.0f ? 1 : 0;
@@ -1572,19 +1588,19 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             int bits = c_tq | (c_qd << 1) | (c_ar << 2) | (c_col << 4) | (c_stb << 5) | (lo_any << 9) | (hi_any << 10) | (c_fast << 11);
             bits = quad_or<LEGS>(bits);
             if (M->pen_link_mask & 1u) bits |= norm(f_base) > 10.0f ? (1 << 4) : 0;
-            if (((P > 0 ? mean_height : pos.z)) < T->cat_min_base_height) bits |= 1 << 3;
+            if (((P > 0 ? mean_height : pos.z)) < cat_minh) bits |= 1 << 3;
             if ((bits & (1 << 9)) && (bits & (1 << 10))) bits |= 1 << 6;                 // any(q < lo) * any(q > hi)  (go2_cat.py:170-171)
-            if (pg.z > T->cat_max_projected_gravity) bits |= 1 << 7;
+            if (pg.z > cat_maxg) bits |= 1 << 7;
             const float cmdn = sqrtf(cmd0 * cmd0 + cmd1 * cmd1 + cmd2 * cmd2);
             if (CR(LG_CR_ANY_FAST + (int)(p.counter & 1)) != 0.f && cmdn < 0.1f) bits |= 1 << 8;   // job-wide motion flag x own zero command
             if (blockIdx.x == 0 && threadIdx.x == 0) B.command_ranges[LG_CR_ANY_FAST + (int)((p.counter + 1) & 1)] = 0.f;   // next step's slot
             bits &= 0x1FF;
-            cstr_p = (bits & 0xF0) ? 1.f : ((bits & 0x10F) ? T->cat_soft_p : 0.f);
+            cstr_p = (bits & 0xF0) ? 1.f : ((bits & 0x10F) ? cat_sp : 0.f);
             cat_keep = 1.0f - cstr_p;
             if (lead) {
                 B.cstr_prob[e] = cstr_p;
 #pragma unroll
-                for (int k = 0; k < LG_NUM_CSTR; k++) B.cstr_sums[(size_t)k * N + e] += (float)((bits >> k) & 1);
+                for (int k = 0; k < LG_NUM_CSTR; k++) { cat_cnt[k] += (float)((bits >> k) & 1); B.cstr_sums[(size_t)k * N + e] = cat_cnt[k]; }
             }
         }
         // ---- compute_reward (legged_robot.py:150-168), alphabetical order ----
@@ -1961,7 +1977,11 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 B.episode_done_step[e] = (int)p.counter;
                 if (B.cstr_sums) {      // the constraint counters live in episode_sums in the reference and are logged / zeroed with them
 #pragma unroll
-                    for (int k = 0; k < LG_NUM_CSTR; k++) { B.cstr_done_sums[(size_t)k * N + e] = B.cstr_sums[(size_t)k * N + e]; B.cstr_sums[(size_t)k * N + e] = 0.f; }
+                    for (int k = 0; k < LG_NUM_CSTR; k++) {
+                        // POST in this launch: its counters are in registers; RESET alone: read them back
+                        B.cstr_done_sums[(size_t)k * N + e] = (DO_POST && p.k.cat_enable) ? cat_cnt[k] : B.cstr_sums[(size_t)k * N + e];
+                        B.cstr_sums[(size_t)k * N + e] = 0.f;
+                    }
                 }
             }
         }
@@ -2673,7 +2693,8 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
         p.k.obs_layout = hot.obs_layout; p.k.o_n_height_points = hot.o_n_height_points;
         p.k.reward_mask = (unsigned)hot.reward_mask; p.k.clip_actions = hot.clip_actions;
         p.k.cat_enable = h->task.cat_enable;
-        for (int j = 0; j < 3; j++) {
+        p.k.joint_axis[3] = -1;
+        for (int j = 0; j < JPL; j++) {
             int code = -2;
             for (int l = 0; l < LEGS; l++) {
                 const float *ax = h->model.axis[1 + JPL * l + j];
@@ -2717,9 +2738,26 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
     // auto: component-per-lane while that needs at most two waves per SIMD (1024 SIMDs).  Measured go2, us per step,
     // component vs leg layout: 4096 envs 34.7 / 56.6, 8192: 50.9 / 55.2, 12288: 69.2 / 55.5, 16384: 92 / 60
     // the component-per-lane kernel is specialised for identity joint frames and hip-x / thigh-y / knee-y axes (lg_quad.h)
-    const bool quad_ok = JPL == 3 && p.jrot_identity && p.k.joint_axis[0] == 0 && p.k.joint_axis[1] == 1 && p.k.joint_axis[2] == 1;
-    if (h->opts.sim_layout == 2 && !quad_ok) return fail("lg_step: sim_layout 2 needs identity joint frames and x / y / y joint axes");
+    const bool quad_ok = p.jrot_identity && p.k.joint_axis[0] == 0 && p.k.joint_axis[1] == 1 && p.k.joint_axis[2] == 1 && (JPL == 3 || p.k.joint_axis[3] == 1);
+    if (h->opts.sim_layout == 2 && !quad_ok) return fail("lg_step: sim_layout 2 needs identity joint frames and x / y / y (/ y) joint axes");
     const int layout = h->opts.sim_layout ? h->opts.sim_layout : ((quad_ok && (long long)threads * 4 <= 2048LL * BLOCK) ? 2 : 1);
+    if constexpr (JPL == 4) if (layout == 2 && (ph & LG_PHASE_SIM)) {   // four-joint legs: physics in component layout, then the MDP phases
+        dim3 qgrid((threads * 4 + BLOCK - 1) / BLOCK);
+        const bool pre = (ph & LG_PHASE_PRE) != 0;
+        if (!pre && !actions) p.actions = nullptr;
+        const int pi = prof_begin(h, st);
+        const uint32_t rest = ph & (LG_PHASE_POST | LG_PHASE_RESET);
+        if (pre && rest) LG_LAUNCH_FIRST(pi, (quad_sim_kernel<LEGS, true, 0u, 0, 4>), qgrid);
+        else if (pre) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, 0u, 0, 4>), qgrid);
+        else if (rest) LG_LAUNCH_FIRST(pi, (quad_sim_kernel<LEGS, false, 0u, 0, 4>), qgrid);
+        else LG_LAUNCH(pi, (quad_sim_kernel<LEGS, false, 0u, 0, 4>), qgrid);
+        HIPCHK(hipGetLastError());
+        if (rest == (LG_PHASE_POST | LG_PHASE_RESET)) LG_LAUNCH_LAST(pi, (env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET, 0, 4>), grid);
+        else if (rest == LG_PHASE_POST) LG_LAUNCH_LAST(pi, (env_step_kernel<LEGS, LG_PHASE_POST, 0, 4>), grid);
+        else if (rest) return fail("lg_step: unsupported phase combination");
+        HIPCHK(hipGetLastError());
+        return 0;
+    }
     if constexpr (JPL == 3) if (layout == 2 && (ph & LG_PHASE_SIM)) {
         dim3 qgrid((threads * 4 + BLOCK - 1) / BLOCK);
         const bool pre = (ph & LG_PHASE_PRE) != 0;

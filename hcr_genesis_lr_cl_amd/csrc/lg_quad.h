@@ -25,7 +25,7 @@
 
 namespace q4 {
 
-constexpr int QUAD_AXES[3] = {0, 1, 1};
+constexpr int QUAD_AXES[4] = {0, 1, 1, 1};   // hip-x / thigh-y / knee-y (/ ankle-y: four-joint legs)
 
 LG_DEV float fsqrt(float x) { return __builtin_amdgcn_sqrtf(x); }   // v_sqrt_f32 (1 ulp) without the denormal-range rescue of sqrtf
 
@@ -34,6 +34,7 @@ template <int CTRL> LG_DEV float dpp(float v) {
     return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xF, 0xF, true));
 }
 template <int J> LG_DEV float bc(float v) { return dpp<J * 0x55>(v); }    // lane J of the quad, to all four
+LG_DEV float bcj(float v, int j) { return j == 0 ? bc<0>(v) : (j == 1 ? bc<1>(v) : (j == 2 ? bc<2>(v) : bc<3>(v))); }   // j: compile time after unrolling
 LG_DEV float rot1(float v) { return dpp<QP(1, 2, 0, 3)>(v); }              // lane c <- lane (c+1)%3
 LG_DEV float rot2(float v) { return dpp<QP(2, 0, 1, 3)>(v); }              // lane c <- lane (c+2)%3
 LG_DEV float sum3(float t) { return t + rot1(t) + rot2(t); }               // x+y+z in lanes 0..2
@@ -72,6 +73,7 @@ struct QI6 { QM A, B, Bt, C; };        // [A B; B^T C]: rows c of (A|B) and of (
 struct Lane {
     int c; bool is0, is1, is2, is3; float d0, d1, d2;
     LG_DEV float sel(float a0, float a1, float a2) const { return is0 ? a0 : (is1 ? a1 : a2); }
+    LG_DEV float sel4(float a0, float a1, float a2, float a3) const { return is0 ? a0 : (is1 ? a1 : (is2 ? a2 : a3)); }
 };
 
 LG_DEV float dot3(float a, float b) { return sum3(a * b); }
@@ -271,19 +273,19 @@ LG_DEV void terrain(const Terr &T, float x, float y, float &h, float &nx, float 
 }
 
 // response sweeps (see resp_up / resp_down in lg_kernel.hip); du replicated, tl / dqdd in joint lanes
-LG_DEV QV6 resp_up(const QJoint (&J)[3], const QV6 &fspat, float tl, float (&du)[3]) {
+template <int NJ> LG_DEV QV6 resp_up(const QJoint (&J)[NJ], const QV6 &fspat, float tl, float (&du)[NJ]) {
     QV6 dp = {-fspat.a, -fspat.l};
-    du[2] = bc<2>(tl) - dot6(J[2].S, dp); dp = dp + J[2].U * (du[2] * J[2].dinv);
-    du[1] = bc<1>(tl) - dot6(J[1].S, dp); dp = dp + J[1].U * (du[1] * J[1].dinv);
-    du[0] = bc<0>(tl) - dot6(J[0].S, dp); dp = dp + J[0].U * (du[0] * J[0].dinv);
+#pragma unroll
+    for (int j = NJ - 1; j >= 0; j--) { du[j] = bcj(tl, j) - dot6(J[j].S, dp); dp = dp + J[j].U * (du[j] * J[j].dinv); }
     return dp;
 }
-LG_DEV QV6 resp_down(const Lane &L, const QJoint (&J)[3], const QV6 &a0, const float (&du)[3], float &dqdd) {
+template <int NJ> LG_DEV QV6 resp_down(const Lane &L, const QJoint (&J)[NJ], const QV6 &a0, const float (&du)[NJ], float &dqdd) {
     QV6 a = a0;
-    const float d0 = (du[0] - dot6(J[0].U, a)) * J[0].dinv; a = a + J[0].S * d0;
-    const float d1 = (du[1] - dot6(J[1].U, a)) * J[1].dinv; a = a + J[1].S * d1;
-    const float d2 = (du[2] - dot6(J[2].U, a)) * J[2].dinv; a = a + J[2].S * d2;
-    dqdd = L.sel(d0, d1, d2);
+    float d[NJ];
+#pragma unroll
+    for (int j = 0; j < NJ; j++) { d[j] = (du[j] - dot6(J[j].U, a)) * J[j].dinv; a = a + J[j].S * d[j]; }
+    // dot products are only formed in lanes 0-2: the fourth joint's lane takes its value from lane 0
+    dqdd = NJ == 4 ? L.sel4(d[0], d[1], d[2], bc<0>(d[NJ - 1])) : L.sel(d[0], d[1], d[2]);
     return a;
 }
 
@@ -293,11 +295,15 @@ LG_DEV QV6 resp_down(const Lane &L, const QJoint (&J)[3], const QV6 &a0, const f
 // MPH: MDP phases (LG_PHASE_POST, LG_PHASE_POST | LG_PHASE_RESET or 0) run in the tail of the same launch by the first
 // 16 lanes of each wave, one per leg of the wave's envs, through env_step_body: one launch per control step, no second
 // ramp-up, tables already in LDS.  The hand-off goes through the state arrays themselves (written above, L2-hot).
-template <int LEGS, bool DO_PRE, unsigned MPH, int PROF = 0>
+// JPL = 4 (TRON1 sole foot: two legs of four joints, physics only -- its MDP phases are the leg-per-lane launch): the fourth joint's
+// scalars live in lane 3 of the quad, the chain arrays have four entries, the foot body's sole corners take the calf's second sphere
+// slot with the sole law of lg_kernel.hip's sphere_contact.
+template <int LEGS, bool DO_PRE, unsigned MPH, int PROF = 0, int JPL = 3>
 __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     using namespace q4;
+    static_assert(JPL == 3 || (JPL == 4 && LEGS == 2 && MPH == 0 && PROF == 0), "four-joint legs: biped physics only");
     constexpr bool FLAT = PROF == 1, PLANE = PROF == 1 || PROF == 2;   // host-checked task profiles (lg_kernel.hip flat_profile / wtw_profile)
-    constexpr int A = 3 * LEGS;
+    constexpr int A = JPL * LEGS;
     // The kernel argument block (KParams, ~800 B of pointers) through ONE vector load: lane i holds bytes [16 i, 16 i + 16).
     // Fetched with scalar loads it arrives as a dozen dependent dwordx16 chunks (SGPR pressure), each a device-memory round
     // trip in front of the start-of-kernel burst: ~4 k of the prologue's cycles.  Pointers needed by the burst are rebuilt
@@ -339,16 +345,18 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     Lane L;
     L.c = tid & 3; L.is0 = L.c == 0; L.is1 = L.c == 1; L.is2 = L.c == 2; L.is3 = L.c == 3;
     L.d0 = L.is0 ? 1.f : 0.f; L.d1 = L.is1 ? 1.f : 0.f; L.d2 = L.is2 ? 1.f : 0.f;
-    const int cj = min(L.c, 2);               // lane 3 shadows lane 2's addresses; it never stores
+    const int cj = min(L.c, 2);               // vector component of this lane; lane 3 shadows lane 2's addresses and never stores one
+    const int cjj = JPL == 4 ? L.c : cj;      // joint of this lane (four-joint legs: lane 3 carries the fourth)
     const int quad = tid >> 2, leg = quad % LEGS;
     int e = quad / LEGS;
     const int N = KINT(B.n_envs);
     const bool live = e < N;
     if (!live) e = N - 1;
-    const bool st = live && !L.is3;           // this lane stores vector components / joint values
+    const bool st = live && !L.is3;           // this lane stores vector components
+    const bool stj = JPL == 4 ? live : st;    // ... joint values
     const bool lead = st && leg == 0;         // ... and the per-env ones
     const int nL = KINT(k.m_n_links), F = LEGS;
-    const int b0 = 1 + 3 * leg, d0 = 3 * leg;
+    const int b0 = 1 + JPL * leg, d0 = JPL * leg;
     const int foot_link = leg == 0 ? KINT(k.m_foot_link[0]) : (leg == 1 ? KINT(k.m_foot_link[1]) : (leg == 2 ? KINT(k.m_foot_link[2]) : KINT(k.m_foot_link[3])));
     int foot_slot = 0;
 #pragma unroll
@@ -387,7 +395,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     const float GAS *const k_actions_in = KPTR(const float GAS *, offsetof(KParams, actions));
     const LgSimOptions GAS *kO = KPTR(const LgSimOptions GAS *, offsetof(KParams, O));
     const LgTaskCfg GAS *kT = KPTR(const LgTaskCfg GAS *, offsetof(KParams, T));
-    const int ja = e * A + d0 + cj;           // this lane's joint
+    const int ja = e * A + d0 + cjj;          // this lane's joint
     float act, last_act = 0.f, llast_act = 0.f;
     if (DO_PRE) {
         const float ca = KFLT(k.clip_actions);
@@ -405,7 +413,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     const float dr_com = k_base_com_bias ? k_base_com_bias[3 * e + cj] : 0.f;
     const float dr_fric = k_friction_values ? k_friction_values[e] : 1.f;
     const float dr_kp = k_kp_scale ? k_kp_scale[ja] : 1.f, dr_kd = k_kd_scale ? k_kd_scale[ja] : 1.f;
-    const float gain_p = kO->kp[d0 + cj], gain_d = kO->kd[d0 + cj], q0 = kO->default_dof_pos[d0 + cj];
+    const float gain_p = kO->kp[d0 + cjj], gain_d = kO->kd[d0 + cjj], q0 = kO->default_dof_pos[d0 + cjj];
     float dr_arm = 0.f, dr_jf = 0.f, dr_jd = 0.f;
     if (k_joint_armature) { dr_arm = k_joint_armature[e]; dr_jf = k_joint_friction[e]; dr_jd = k_joint_damping[e]; }
     const float origin = k_env_origins ? k_env_origins[3 * e + cj] : 0.f;
@@ -488,14 +496,14 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     STAMP(23);
 
     // ---------------- prologue stores ---------------------------------------------------------------
-    if (DO_PRE && st) {
+    if (DO_PRE && stj) {
         B.llast_actions[ja] = llast_act;
         B.last_actions[ja] = last_act;
         B.actions[ja] = act;
     }
     const float last_foot_v = snap_fv, qd_start = qd;   // kept for the MDP tail (dof_acc, foot_acc)
-    if (st) {   // "last" snapshots (genesis_simulator.py:21-24)
-        B.last_dof_vel[ja] = qd;
+    if (stj) B.last_dof_vel[ja] = qd;   // "last" snapshots (genesis_simulator.py:21-24)
+    if (st) {
         B.last_feet_vel[(e * F + foot_slot) * 3 + cj] = snap_fv;
         if (leg == 0) { B.last_base_lin_vel[3 * e + cj] = snap_blv; B.last_base_ang_vel[3 * e + cj] = snap_bav; }
     }
@@ -518,39 +526,50 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         return r;
     };
     const QM I0 = sym_row(M->inertia[0]);
-    float Lm[3], Lcom[3], Ljpos[3], Lax[3];
-    QM LIc[3];
+    float Lm[JPL], Lcom[JPL], Ljpos[JPL], Lax[JPL];
+    QM LIc[JPL];
 #pragma unroll
-    for (int j = 0; j < 3; j++) {
+    for (int j = 0; j < JPL; j++) {
         const int b = b0 + j;
         Lm[j] = M->mass[b]; Lcom[j] = M->com[b][cj]; Ljpos[j] = M->jpos[b][cj]; Lax[j] = M->axis[b][cj];
         LIc[j] = sym_row(M->inertia[b]);
     }
     // joint-lane constants
-    const float Lqlo = M->q_lo[d0 + cj], Lqhi = M->q_hi[d0 + cj], Leff = M->effort[d0 + cj];
-    const float Lvlim = HOT(o_joint_vel_clamp) * M->vel_limit[d0 + cj];
+    const float Lqlo = M->q_lo[d0 + cjj], Lqhi = M->q_hi[d0 + cjj], Leff = M->effort[d0 + cjj];
+    const float Lvlim = HOT(o_joint_vel_clamp) * M->vel_limit[d0 + cjj];
     const float kps = dr_kp * gain_p, kds = dr_kd * gain_d;
-    const float arm = B.joint_armature ? dr_arm : M->armature[d0 + cj];
-    const float jfric = B.joint_friction ? dr_jf : M->frictionloss[d0 + cj];
-    const float jdamp = B.joint_damping ? dr_jd : M->damping[d0 + cj];
+    const float arm = B.joint_armature ? dr_arm : M->armature[d0 + cjj];
+    const float jfric = B.joint_friction ? dr_jf : M->frictionloss[d0 + cjj];
+    const float jdamp = B.joint_damping ? dr_jd : M->damping[d0 + cjj];
     const int fs = leg == 0 ? HOT(m_foot_sphere[0]) : (leg == 1 ? HOT(m_foot_sphere[1]) : (leg == 2 ? HOT(m_foot_sphere[2]) : HOT(m_foot_sphere[3])));
     const float foot_c_loc = M->sph_pos[fs][cj], foot_r = M->sph_r[fs];
 
     // collision spheres (foot excluded): five "slots", in each the four lanes of the quad test four different
-    // spheres of the SAME body in scalar form.  slot 0: hip, 1: thigh, 2-3: calf, 4: base (4 per quad)
+    // spheres of the SAME body in scalar form.  slot 0: hip, 1: thigh, 2-3: calf, 4: base (4 per quad); four-joint legs:
+    // 0: abad, 1: hip, 2: knee, 3: the sole corners of the foot body, 4: base
     constexpr int NSLOT = 5;
     float sx[NSLOT], sy[NSLOT], sz[NSLOT], srad[NSLOT], sden[NSLOT], sidw[NSLOT];   // sden = 1/(1 + kappa dt w), sidw = 1/(dt w)
+    float sole_w = 0.f;                        // sph_w of this lane's sole corner (four-joint legs: its inverse mass is formed per sub-step)
     {
         const int a0 = M->body_sph_start[b0], a1 = M->body_sph_start[b0 + 1], a2 = M->body_sph_start[b0 + 2], a3 = M->body_sph_start[b0 + 3];
         const int e0 = M->body_sph_start[0], e1 = M->body_sph_start[1];
         int idx[NSLOT];
         idx[0] = a0 + L.c < a1 ? a0 + L.c : -1;
         idx[1] = a1 + L.c < a2 ? a1 + L.c : -1;
+        if (JPL == 4) {
+            const int a4 = M->body_sph_start[b0 + JPL];
+            idx[2] = a2 + L.c < a3 ? a2 + L.c : -1;
+            int s = a3 + L.c;                  // c-th non-foot sphere of the foot body
+            if (s >= fs) s++;
+            idx[3] = s < a4 ? s : -1;
+            sole_w = M->sph_w[max(idx[3], 0)];
+        } else {
 #pragma unroll
-        for (int k = 0; k < 2; k++) {          // n-th non-foot sphere of the calf, n = 4k + c
-            int s = a2 + 4 * k + L.c;
-            if (s >= fs) s++;                  // the foot sphere is one of [a2, a3): skip over it
-            idx[2 + k] = s < a3 ? s : -1;
+            for (int k = 0; k < 2; k++) {      // n-th non-foot sphere of the calf, n = 4k + c
+                int s = a2 + 4 * k + L.c;
+                if (s >= fs) s++;              // the foot sphere is one of [a2, a3): skip over it
+                idx[2 + k] = s < a3 ? s : -1;
+            }
         }
         idx[4] = e0 + leg * 4 + L.c < e1 ? e0 + leg * 4 + L.c : -1;
 #pragma unroll
@@ -575,27 +594,27 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     STAMP(12);
     for (int sub = 0; sub < decim; sub++) {
         const QM Rb = quat_rows(L, quat);
-        QKin K[3];
-        QJoint J[3];
+        QKin K[JPL];
+        QJoint J[JPL];
         // ---- chain kinematics (root -> leaf) --------------------------------------------------------
         {
             float sv, cv;
-            __sincosf(q, &sv, &cv);      // the three joint angles of the leg at once
+            __sincosf(q, &sv, &cv);      // the joint angles of the leg at once
             QM Rp = Rb;
             float Pp = 0.f;
             QV6 Vp = {ww, vw};
 #pragma unroll
-            for (int j = 0; j < 3; j++) {
+            for (int j = 0; j < JPL; j++) {
                 K[j].P = Pp + mulv(Rp, Ljpos[j]);
-                const float cq = j == 0 ? bc<0>(cv) : (j == 1 ? bc<1>(cv) : bc<2>(cv));
-                const float sq = j == 0 ? bc<0>(sv) : (j == 1 ? bc<1>(sv) : bc<2>(sv));
+                const float cq = bcj(cv, j), sq = bcj(sv, j);
                 float s;
                 if (j == 0) joint_rot<QUAD_AXES[0]>(L, Rp, Lax[j], cq, sq, K[j].R, s);
                 else if (j == 1) joint_rot<QUAD_AXES[1]>(L, Rp, Lax[j], cq, sq, K[j].R, s);
-                else joint_rot<QUAD_AXES[2]>(L, Rp, Lax[j], cq, sq, K[j].R, s);
+                else if (j == 2) joint_rot<QUAD_AXES[2]>(L, Rp, Lax[j], cq, sq, K[j].R, s);
+                else joint_rot<QUAD_AXES[3]>(L, Rp, Lax[j], cq, sq, K[j].R, s);
                 J[j].S.a = s;
                 J[j].S.l = cross(K[j].P, s);
-                const float qdj = j == 0 ? bc<0>(qd) : (j == 1 ? bc<1>(qd) : bc<2>(qd));
+                const float qdj = bcj(qd, j);
                 K[j].V.a = Vp.a + s * qdj;
                 K[j].V.l = Vp.l + J[j].S.l * qdj;
                 J[j].c.a = cross(K[j].V.a, s) * qdj;
@@ -606,12 +625,14 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         if (sub == 0) STAMP(13);
         // ---- body collision spheres -----------------------------------------------------------------
         // ext[b]: spatial force about O on chain body b from its spheres; extb: on the base (this quad's share)
-        QV6 ext[3] = {{0.f, 0.f}, {0.f, 0.f}, {0.f, 0.f}}, extb = {0.f, 0.f};
+        QV6 ext[JPL], extb = {0.f, 0.f};
+#pragma unroll
+        for (int j = 0; j < JPL; j++) ext[j] = QV6{0.f, 0.f};
         {
             const float px = bc<0>(pos), py = bc<1>(pos), pz = bc<2>(pos);
             // broad phase of one slot: this lane's sphere of body (R, P); returns the penetration depth (and centre / terrain)
             struct Hit { float rx, ry, rz, h, nx, ny, nz, depth; bool on; };
-            auto probe = [&](int k, const QM &R, float P) {
+            auto probe = [&](int k, const QM &R, float P, const float dref = 0.f) {
                 Hit t;
                 t.rx = t.ry = 0.f; t.h = 0.f; t.nx = t.ny = 0.f; t.nz = 1.f;
                 t.rz = bc<2>(P) + bc<2>(R.c0) * sx[k] + bc<2>(R.c1) * sy[k] + bc<2>(R.c2) * sz[k];
@@ -620,7 +641,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                     t.ry = bc<1>(P) + bc<1>(R.c0) * sx[k] + bc<1>(R.c1) * sy[k] + bc<1>(R.c2) * sz[k];
                     terrain(TR, px + t.rx, py + t.ry, t.h, t.nx, t.ny, t.nz);
                 }
-                t.depth = srad[k] - (pz + t.rz - t.h) * t.nz;
+                t.depth = srad[k] - (pz + t.rz - t.h) * t.nz - dref;
                 t.on = t.depth > -margin;
                 return t;
             };
@@ -631,20 +652,34 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                            bc<0>(V.a), bc<1>(V.a), bc<2>(V.a), bc<0>(V.l), bc<1>(V.l), bc<2>(V.l)};
                 return g;
             };
-            auto force = [&](int k, Hit t, const BodyS &g, float (&m)[3], float (&f)[3]) {
+            // `sole` (four-joint legs, slot 3): the sole law of lg_kernel.hip's sphere_contact -- inverse mass = sph_w + twice the
+            // ankle joint's own compliance at the contact point, approach velocity relative to the sole centre's (vref)
+            struct Sole { float sax, say, saz, slx, sly, slz, dinv, vref; };
+            auto force = [&](int k, Hit t, const BodyS &g, float (&m)[3], float (&f)[3], const Sole *sole = nullptr) {
                 if (!hfmode) {
                     t.rx = g.Px + g.x0 * sx[k] + g.x1 * sy[k] + g.x2 * sz[k];
                     t.ry = g.Py + g.y0 * sx[k] + g.y1 * sy[k] + g.y2 * sz[k];
                 }
                 const float vx = g.vx + (g.wy * t.rz - g.wz * t.ry), vy = g.vy + (g.wz * t.rx - g.wx * t.rz), vz = g.vz + (g.wx * t.ry - g.wy * t.rx);
-                const float vn = vx * t.nx + vy * t.ny + vz * t.nz;
-                const float fn = (kc * t.depth - kappa * vn) * sden[k];
+                float vn = vx * t.nx + vy * t.ny + vz * t.nz;
+                float den = sden[k], idw = sidw[k];
+                if (JPL == 4 && sole) {
+                    const float cx_ = t.rx - t.nx * srad[k], cy_ = t.ry - t.ny * srad[k], cz_ = t.rz - t.nz * srad[k];
+                    // n . (S.l + S.a x c)
+                    const float gq = t.nx * (sole->slx + sole->say * cz_ - sole->saz * cy_) + t.ny * (sole->sly + sole->saz * cx_ - sole->sax * cz_) +
+                                     t.nz * (sole->slz + sole->sax * cy_ - sole->say * cx_);
+                    const float wi = sole_w + 2.f * gq * gq * sole->dinv;
+                    den = rcp(1.f + kappa * dt * wi); idw = rcp(dt * wi);
+                    vn -= sole->vref;
+                }
+                const float fn = (kc * t.depth - kappa * vn) * den;
                 float fx = 0.f, fy = 0.f, fz = 0.f;
                 if (t.on && fn > 0.f) {
-                    const float tx = vx - t.nx * vn, ty = vy - t.ny * vn, tz = vz - t.nz * vn;
+                    const float vnf = vx * t.nx + vy * t.ny + vz * t.nz;
+                    const float tx = vx - t.nx * vnf, ty = vy - t.ny * vnf, tz = vz - t.nz * vnf;
                     // |f_t| = min(|v_t| / (dt w), mu f_n) along -v_t: one rsq, no sqrt / division
                     const float s2 = tx * tx + ty * ty + tz * tz;
-                    const float gg = s2 > 1e-18f ? fminf(sidw[k], mu * fn * rsqrtf(s2)) : 0.f;
+                    const float gg = s2 > 1e-18f ? fminf(idw, mu * fn * rsqrtf(s2)) : 0.f;
                     fx = t.nx * fn - tx * gg; fy = t.ny * fn - ty * gg; fz = t.nz * fn - tz * gg;
                 }
                 const float cx = t.rx - t.nx * srad[k], cy = t.ry - t.ny * srad[k], cz = t.rz - t.nz * srad[k];
@@ -668,7 +703,33 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             slot(4, Rb, 0.f, V0, extb);
             slot(0, K[0].R, K[0].P, K[0].V, ext[0]);
             slot(1, K[1].R, K[1].P, K[1].V, ext[1]);
-            {   // the calf's two slots share one gather and one reduction
+            if constexpr (JPL == 4) {
+                slot(2, K[2].R, K[2].P, K[2].V, ext[2]);
+                // the sole corners: penetration / approach velocity relative to the sole centre's while that one is in the ground
+                const BodyS g = gather(K[3].R, K[3].P, K[3].V);
+                const float rc = K[3].P + mulv(K[3].R, foot_c_loc);
+                const float rcx = bc<0>(rc), rcy = bc<1>(rc), rcz = bc<2>(rc);
+                float hc = 0.f, ncx = 0.f, ncy = 0.f, ncz = 1.f;
+                if (hfmode) terrain(TR, px + rcx, py + rcy, hc, ncx, ncy, ncz);
+                const float dc = foot_r - (pz + rcz - hc) * ncz;
+                const float vcx = g.vx + (g.wy * rcz - g.wz * rcy), vcy = g.vy + (g.wz * rcx - g.wx * rcz), vcz = g.vz + (g.wx * rcy - g.wy * rcx);
+                const float dref = dc > 0.f ? dc : 0.f;
+                const Hit t3 = probe(3, K[3].R, K[3].P, dref);
+                if (__builtin_amdgcn_ballot_w64(t3.on) != 0ull) {
+                    // ankle compliance: 1 / (S^T I_foot S + armature) with the foot body's own rigid inertia
+                    const float cw = K[3].P + mulv(K[3].R, Lcom[3]);
+                    const QM Icw = mulmmt(mulmm(K[3].R, LIc[3]), K[3].R);
+                    const QI6 Ifoot = rigid(L, Lm[3], cw, Icw);
+                    Sole so;
+                    so.dinv = rcp(bc<0>(dot6(J[3].S, muli6(Ifoot, J[3].S))) + bc<3>(arm));   // replicated over the quad (lane 3 tests a sphere too)
+                    so.sax = bc<0>(J[3].S.a); so.say = bc<1>(J[3].S.a); so.saz = bc<2>(J[3].S.a);
+                    so.slx = bc<0>(J[3].S.l); so.sly = bc<1>(J[3].S.l); so.slz = bc<2>(J[3].S.l);
+                    so.vref = dc > 0.f ? vcx * ncx + vcy * ncy + vcz * ncz : 0.f;
+                    float m[3] = {0.f, 0.f, 0.f}, f[3] = {0.f, 0.f, 0.f};
+                    force(3, t3, g, m, f, &so);
+                    reduce(m, f, ext[3]);
+                }
+            } else {   // the calf's two slots share one gather and one reduction
                 const Hit t2 = probe(2, K[2].R, K[2].P), t3 = probe(3, K[2].R, K[2].P);
                 if (__builtin_amdgcn_ballot_w64(t2.on || t3.on) != 0ull) {
                     float m[3] = {0.f, 0.f, 0.f}, f[3] = {0.f, 0.f, 0.f};
@@ -679,7 +740,8 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 }
             }
         }
-        f_link[0] = ext[0].l; f_link[1] = ext[1].l; f_link[2] = ext[2].l;
+#pragma unroll
+        for (int j = 0; j < JPL; j++) f_link[j] = ext[j].l;
 
         if (sub == 0) STAMP(14);
         // ---- actuation (genesis_simulator.py:630-642), three joints at once ---------------------------
@@ -689,9 +751,9 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         // ---- ABA pass 2 (leaf -> root) ------------------------------------------------------------
         QI6 IA;
         QV6 pacc;
-        float dinvv = 0.f;      // 1/D of the three joints in joint lanes
+        float dinvv = 0.f;      // 1/D of the joints in joint lanes
 #pragma unroll
-        for (int j = 2; j >= 0; j--) {
+        for (int j = JPL - 1; j >= 0; j--) {
             const float m = Lm[j];
             const float cw = K[j].P + mulv(K[j].R, Lcom[j]);
             const QM Icw = mulmmt(mulmm(K[j].R, LIc[j]), K[j].R);
@@ -703,18 +765,17 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             pb.a = cross(K[j].V.a, Lmo) + cross(K[j].V.l, Pm) - cross(cw, fg) - ext[j].a;
             pb.l = cross(K[j].V.a, Pm) - fg - ext[j].l;
             const QI6 Ib = rigid(L, m, cw, Icw);
-            if (j == 2) { IA = Ib; pacc = pb; }
+            if (j == JPL - 1) { IA = Ib; pacc = pb; }
             else { IA = IA + Ib; pacc = pacc + pb; }
             J[j].U = muli6(IA, J[j].S);
-            const float armj = j == 0 ? bc<0>(arm) : (j == 1 ? bc<1>(arm) : bc<2>(arm));
-            const float tauj = j == 0 ? bc<0>(tau) : (j == 1 ? bc<1>(tau) : bc<2>(tau));
+            const float armj = bcj(arm, j), tauj = bcj(tau, j);
             J[j].dinv = rcp(dot6(J[j].S, J[j].U) + armj);
             J[j].u = tauj - dot6(J[j].S, pacc);
             const QV6 Ic6 = muli6(IA, J[j].c);
             const float k = (J[j].u - dot6(J[j].U, J[j].c)) * J[j].dinv;
             pacc = pacc + Ic6 + J[j].U * k;
             IA = rank1_down(IA, J[j].U, J[j].dinv);
-            if (L.c == j) dinvv = J[j].dinv;
+            { const float dj = j == 3 ? bc<0>(J[j].dinv) : J[j].dinv; if (L.c == j) dinvv = dj; }   // lane 3 holds no dot product of its own
         }
         if (sub == 0) STAMP(15);
         // ---- base ---------------------------------------------------------------------------------
@@ -743,10 +804,10 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         QV6 a_calf;
         {
             QV6 a = a0;
-            a = a + J[0].c; const float g0 = (J[0].u - dot6(J[0].U, a)) * J[0].dinv; a = a + J[0].S * g0;
-            a = a + J[1].c; const float g1 = (J[1].u - dot6(J[1].U, a)) * J[1].dinv; a = a + J[1].S * g1;
-            a = a + J[2].c; const float g2 = (J[2].u - dot6(J[2].U, a)) * J[2].dinv; a = a + J[2].S * g2;
-            qdd = L.sel(g0, g1, g2);
+            float gj[JPL];
+#pragma unroll
+            for (int j = 0; j < JPL; j++) { a = a + J[j].c; gj[j] = (J[j].u - dot6(J[j].U, a)) * J[j].dinv; a = a + J[j].S * gj[j]; }
+            qdd = JPL == 4 ? L.sel4(gj[0], gj[1], gj[2], bc<0>(gj[JPL - 1])) : L.sel(gj[0], gj[1], gj[2]);
             a_calf = a;
         }
         if (sub == 0) STAMP(17);
@@ -755,7 +816,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         float cn, ct1 = L.d0, ct2 = L.d1, cp, depth;
         bool fact;
         {
-            const float r = K[2].P + mulv(K[2].R, foot_c_loc);
+            const float r = K[JPL - 1].P + mulv(K[JPL - 1].R, foot_c_loc);
             float h, nx, ny, nz;
             terrain(TR, bc<0>(pos) + bc<0>(r), bc<1>(pos) + bc<1>(r), h, nx, ny, nz);
             depth = foot_r - (bc<2>(pos) + bc<2>(r) - h) * nz;
@@ -771,7 +832,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             }
         }
         float lim_e = 0.f, lim_s = 0.f, lim_T = 0.f;
-        if (!L.is3) {
+        if (JPL == 4 || !L.is3) {
             if (q < Lqlo + lmargin) { lim_s = 1.f; lim_e = Lqlo - q; }
             else if (q > Lqhi - lmargin) { lim_s = -1.f; lim_e = q - Lqhi; }
         }
@@ -786,7 +847,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const QM ET = {cn, ct1, ct2};
             QM Ac;      // dt * W, contact frame, rows
             {
-                float du[3], dq;
+                float du[JPL], dq;
                 const float axs[3] = {cn, ct1, ct2};
                 float col[3];
 #pragma unroll
@@ -802,8 +863,8 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             }
             float vfree;
             {
-                const float vpt = K[2].V.l + cross(K[2].V.a, cp);
-                const float apt = a_calf.l + cross(a_calf.a, cp) + cross(K[2].V.a, vpt);
+                const float vpt = K[JPL - 1].V.l + cross(K[JPL - 1].V.a, cp);
+                const float apt = a_calf.l + cross(a_calf.a, cp) + cross(K[JPL - 1].V.a, vpt);
                 vfree = mulv(E, vpt + apt * dt);
             }
             if (sub == 0) STAMP(18);
@@ -848,7 +909,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 // exact response of the whole robot to the current force set
                 const float fw = mulv(ET, fc);
                 const QV6 fsp = {cross(cp, fw), fw};
-                float du[3];
+                float du[JPL];
                 QV6 dp = resp_up(J, fsp, tl, du);
                 dp.a = legsum<LEGS>(dp.a); dp.l = legsum<LEGS>(dp.l);
                 da0 = muli6(Inv, QV6{-dp.a, -dp.l});
@@ -856,8 +917,9 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 const float ra = ac.l + cross(ac.a, cp);
                 resp_c = mulv(E, ra);
             }
-            f_link[3] = mulv(ET, fc);
-        } else {
+            if (JPL == 4) f_link[3] += mulv(ET, fc);   // the foot is the last body's own link: on top of its sole corners
+            else f_link[3] = mulv(ET, fc);
+        } else if (JPL != 4) {
             f_link[3] = 0.f;
         }
         if (sub == 0) STAMP(19);
@@ -885,12 +947,17 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     }  // sub-steps
 
     STAMP(21);
+    // Every load of the start-of-kernel burst landed during the sub-steps; say so before the read-back stores go out.  vmcnt
+    // retires loads and stores in issue order, and the compiler keeps a load "pending" until a wait formally covers it: the first
+    // use of a prologue value behind the ~60 read-back stores (episode sums, soft limits, noise scales of the MDP tail) otherwise
+    // becomes `s_waitcnt vmcnt(k)` with k = the stores issued since on the shortest path, i.e. a drain of most of those stores.
+    __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0); expcnt / lgkmcnt untouched
     if (!PLANE && p.k.cat_enable) {   // go2_cat's job-wide "some joint faster than 4 rad/s" flag (LG_CR_ANY_FAST)
-        if (__builtin_amdgcn_ballot_w64(st && fabsf(qd) > 4.0f) != 0ull && threadIdx.x == 0) B.command_ranges[LG_CR_ANY_FAST + (int)(p.counter & 1)] = 1.0f;
+        if (__builtin_amdgcn_ballot_w64(stj && fabsf(qd) > 4.0f) != 0ull && threadIdx.x == 0) B.command_ranges[LG_CR_ANY_FAST + (int)(p.counter & 1)] = 1.0f;
     }
     // ---------------- read-back (genesis_simulator.py:35-60) ---------------------------------------
     {   // non-finite guard: re-seat the robot
-        const float chk = quat + (L.is3 ? 0.f : pos + vw + ww + q + qd);
+        const float chk = quat + (L.is3 ? (JPL == 4 ? q + qd : 0.f) : pos + vw + ww + q + qd);
         const int bad = env_or<LEGS>(isfinite(chk) ? 0 : 1);
         const float reseat = HOT(o_base_init_pos[0]) * L.d0 + HOT(o_base_init_pos[1]) * L.d1 + HOT(o_base_init_pos[2]) * L.d2 + origin;
         if (bad) {
@@ -923,16 +990,15 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         float Pp = 0.f;
         QV6 Vp = {ww, vw};
 #pragma unroll
-        for (int j = 0; j < 3; j++) {
+        for (int j = 0; j < JPL; j++) {
             const float P = Pp + mulv(Rp, Ljpos[j]);
-            const float cq = j == 0 ? bc<0>(cv) : (j == 1 ? bc<1>(cv) : bc<2>(cv));
-            const float sq = j == 0 ? bc<0>(sv) : (j == 1 ? bc<1>(sv) : bc<2>(sv));
-            const float qdj = j == 0 ? bc<0>(qd) : (j == 1 ? bc<1>(qd) : bc<2>(qd));
+            const float cq = bcj(cv, j), sq = bcj(sv, j), qdj = bcj(qd, j);
             float s;
             QM Rn;
             if (j == 0) joint_rot<QUAD_AXES[0]>(L, Rp, Lax[j], cq, sq, Rn, s);
             else if (j == 1) joint_rot<QUAD_AXES[1]>(L, Rp, Lax[j], cq, sq, Rn, s);
-            else joint_rot<QUAD_AXES[2]>(L, Rp, Lax[j], cq, sq, Rn, s);
+            else if (j == 2) joint_rot<QUAD_AXES[2]>(L, Rp, Lax[j], cq, sq, Rn, s);
+            else joint_rot<QUAD_AXES[3]>(L, Rp, Lax[j], cq, sq, Rn, s);
             Vp.a = Vp.a + s * qdj;
             Vp.l = Vp.l + cross(P, s) * qdj;
             Rp = Rn;
@@ -942,8 +1008,8 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         foot_p = pos + r;
         foot_v = Vp.l + cross(Vp.a, r);
     }
+    if (stj) { B.dof_pos[ja] = q; B.dof_vel[ja] = qd; B.torques[ja] = torque; }
     if (st) {
-        B.dof_pos[ja] = q; B.dof_vel[ja] = qd; B.torques[ja] = torque;
         const int l0 = foot_link - 3;
 #pragma unroll
         for (int k = 0; k < 4; k++) B.link_contact_forces[(e * nL + l0 + k) * 3 + cj] = f_link[k];

@@ -133,6 +133,9 @@ class Go2CaT(LeggedRobotTS):
         self.cstr_prob = b["cstr_prob"]
         for k, n in enumerate(abi.CSTR_NAMES):                     # constraint_manager.py:91-97 logs them into episode_sums
             self.episode_sums["cstr_" + n] = b["cstr_sums"][k]
+        # go2_cat.py:98-101 puts mean(cstr_prob) into extras["episode"] every step; here it is formed when that entry is read (the
+        # value of the latest step: read it before stepping again, as the runner does) -- a reduction launch per step otherwise
+        self._lazy_episode_extras = {"cstr_probs": lambda: torch.mean(self.cstr_prob)}
 
     def _engine_step(self, actions, c):
         e = self._engine
@@ -148,7 +151,3 @@ class Go2CaT(LeggedRobotTS):
         else:
             e.step(abi.PHASE_POST | abi.PHASE_RESET, None, c)
 
-    def step(self, actions):
-        out = super().step(actions)
-        out[-1]["episode"]["cstr_probs"] = torch.mean(self.cstr_prob)      # go2_cat.py:98-101
-        return out

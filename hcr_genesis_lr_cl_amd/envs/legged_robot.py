@@ -71,6 +71,8 @@ class _EpisodeExtras(MutableMapping):
             return env.command_ranges["lin_vel_x"][1]
         if key == "terrain_level":
             return torch.mean(env.simulator.terrain_levels.float())
+        if key in env._lazy_episode_extras:      # task-specific entries formed on access (go2_cat: "cstr_probs")
+            return env._lazy_episode_extras[key]()
         name = key[4:]
         if not key.startswith("rew_") or name not in env.episode_sums:
             raise KeyError(key)
@@ -91,6 +93,7 @@ class _EpisodeExtras(MutableMapping):
             yield "terrain_level"
         if env.cfg.commands.curriculum:
             yield "max_command_x"
+        yield from env._lazy_episode_extras
 
     def __iter__(self):
         seen = set()
@@ -107,6 +110,8 @@ class _EpisodeExtras(MutableMapping):
 
 
 class LeggedRobot:
+    _lazy_episode_extras = {}      # key -> callable, evaluated when extras["episode"][key] is read (see _EpisodeExtras)
+
     def __init__(self, cfg, sim_params=None, sim_device="cuda:0", headless=True, inject_rand=False,
                  env_id_offset=0, global_num_envs=None):
         self.cfg = cfg

@@ -458,7 +458,7 @@ static void env_step(const LgModelDesc *m, const LgSimOptions *o, const int16_t 
             if (depth <= -o->contact_margin) continue;
             real v[3];
             point_velocity(&w, i, rl, v);
-            real vn = dot3(v, n) - vref, wi = m->sph_w[s];
+            real vnf = dot3(v, n), vn = vnf - vref, wi = m->sph_w[s];
             if (sole) {
                 /* inverse mass: twice the ankle joint's own compliance at the contact point (the two corners of an edge share that
                  * rotation), 2 (n . (s x (c - P)))^2 / (S^T I_foot S + armature), plus the model's sph_w */
@@ -475,7 +475,7 @@ static void env_step(const LgModelDesc *m, const LgSimOptions *o, const int16_t 
             real fn = (kc * depth - kappa * vn) / (1 + kappa * dt * wi);
             if (fn <= 0) continue;
             real vt[3];
-            for (int k = 0; k < 3; k++) vt[k] = v[k] - vn * n[k];
+            for (int k = 0; k < 3; k++) vt[k] = v[k] - vnf * n[k];
             real vtn = sqrt(dot3(vt, vt));
             real ft = vtn / (dt * wi);
             if (ft > mu * fn) ft = mu * fn;

@@ -136,11 +136,11 @@ def _setup(robot, rough, layout):
 
 
 @pytest.mark.parametrize("robot,rough,layout", [("tron1_pf", False, 1), ("tron1_pf", False, 2), ("go2", True, 1), ("go2", True, 2),
-                                                ("tron1_pf", True, 1), ("tron1_pf", True, 2), ("tron1_sf", False, 1)])
+                                                ("tron1_pf", True, 1), ("tron1_pf", True, 2), ("tron1_sf", False, 1), ("tron1_sf", False, 2)])
 def test_one_control_step_matches_oracle_other_configs(robot, rough, layout):
     """TRON1 exercises the 2-lanes-per-env instantiation, joint_rot/armature/damping tables; `rough` the
     heightfield contact (bilinear height + gradient normal) on stairs / slopes / obstacles; tron1_sf the four-joint chains and
-    the sole contact (leg-per-lane layout only)."""
+    the sole contact."""
     import torch
     from hcr_genesis_lr_cl_amd import abi
     from oracle import oracle as orc

@@ -8,7 +8,7 @@ STEP_KERNELS = {
     # not BASELINE configs
     "go2_ts": _QUAD_FUSED, "go2_cts": _QUAD_FUSED, "go2_dreamwaq": _QUAD_FUSED, "tron1_pf": _BIPED,
     "go2_cat": ["quad_sim_kernel<4, true, 0u,", "env_step_kernel<4, 12u", "obs_compact_kernel"],
-    "tron1_sf": ["env_step_kernel<2, 15u", "obs_compact_kernel"],
+    "tron1_sf": _BIPED,
 }
 
 
