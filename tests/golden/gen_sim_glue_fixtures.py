@@ -384,3 +384,5 @@ if __name__ == "__main__":
     gen_task("go2_wtw", GO2WTWCfg, seed=111)
     gen_task("go2_ee", Go2EECfg, seed=121)
     gen_task("tron1_pf_ee", TRON1PF_EECfg, seed=131)
+    from legged_gym.envs.tron1_sf.tron1_sf_config import TRON1SFCfg
+    gen_task("tron1_sf", TRON1SFCfg, seed=141)

@@ -22,7 +22,7 @@ from oracle import mdp_oracle as mo
 pytestmark = pytest.mark.gpu
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TASKS = ["go2", "go2_wtw", "go2_ee", "tron1_pf_ee"]
+TASKS = ["go2", "go2_wtw", "go2_ee", "tron1_pf_ee", "tron1_sf"]
 LAYOUTS = [pytest.param(1, id="leg-per-lane"), pytest.param(2, id="component-per-lane")]
 
 

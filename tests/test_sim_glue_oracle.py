@@ -13,7 +13,7 @@ from oracle import mdp_oracle as mo
 from oracle import sim_glue_oracle as sg
 
 GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
-TASKS = {"go2": cfgmod.GO2Cfg, "go2_wtw": cfgmod.GO2WTWCfg, "go2_ee": cfgmod.GO2EECfg, "tron1_pf_ee": cfgmod.TRON1PFEECfg}
+TASKS = {"go2": cfgmod.GO2Cfg, "go2_wtw": cfgmod.GO2WTWCfg, "go2_ee": cfgmod.GO2EECfg, "tron1_pf_ee": cfgmod.TRON1PFEECfg, "tron1_sf": cfgmod.TRON1SFCfg}
 TOL = dict(rtol=2e-6, atol=2e-6)
 
 
