@@ -2668,7 +2668,13 @@ static bool wtw_profile(const LgEngine *h) {
     const LgBuffers &b = h->bufs;
     return t.obs_layout == LG_OBS_GO2_WTW && t.gait_mode == 1 && t.double_shift == 1 && t.terrain_curriculum == 0 && t.custom_origins == 0 &&
            t.sit_percent == 0.f && t.num_labels == 0 && t.cat_enable == 0 && t.noise_vec[9 + 6 * h->model.n_legs] == 0.f &&
-           o.n_height_points == 0 && o.terrain_rows == 0 && o.feet_terrain_info == 0 && !b.link_contact_states && !h->hf && b.task_state;
+           o.n_height_points == 0 && o.terrain_rows == 0 && o.feet_terrain_info == 0 && !b.link_contact_states && !h->hf && b.task_state &&
+           // what the component-layout tail of lg_quad.h (PROF 2) hard-wires: sliding-window stacks of 61 | 99-wide frames, Philox draws,
+           // no per-env joint parameters, no noise on commands / actions
+           t.obs_slack > 0 && t.obs_frame == 61 && t.priv_frame == 61 + 10 + 6 * h->model.n_legs + h->model.n_legs && t.obs_stack > 1 && t.priv_stack > 1 &&
+           t.obs_sets <= 2 && (t.obs_sets < 2 || b.obs_dirty) && !b.rand_in && !b.joint_armature && !t.dr_joint_on && flat_noise_ok(h) &&
+           h->model.n_legs == 4 && h->model.n_bodies == 13 && b.priv_obs_buf && b.rand_push_vels &&
+           ((unsigned)h->hot.reward_mask & ((1u << LG_R_BIPED_PERIODIC_GAIT) | (1u << LG_R_FEET_DISTANCE))) == 0;
 }
 
 // the Go2-rough family (PROF 3: go2_ee packaging, PROF 4: observation programs -- go2_ts / go2_cts / go2_dreamwaq / go2_cat): no gait

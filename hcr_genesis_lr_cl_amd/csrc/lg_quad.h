@@ -428,7 +428,8 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     // (env_step_body<.., FUSED>) reads it back after the physics instead of paying the round trips then.  Layout = the
     // stash of env_step_body (NST values x 16 lanes).
     constexpr int NST = LG_R_COUNT + 36;
-    constexpr bool QTAIL = FLAT && MPH == (LG_PHASE_POST | LG_PHASE_RESET);   // MDP phases in component layout on all 64 lanes (below)
+    constexpr bool QTAIL = (FLAT || PROF == 2) && MPH == (LG_PHASE_POST | LG_PHASE_RESET);   // MDP phases in component layout on all 64 lanes (below)
+    constexpr bool WQ = PROF == 2 && QTAIL;   // ... of the go2_wtw task: gait clock, behaviour targets, 61 x 5 | 99 x 5 observation stacks
     __shared__ float sStF[(MPH != 0 && !QTAIL) ? NST * 16 : 1];
     float wsv[(MPH != 0 && !QTAIL) ? NST : 1];
     // QTAIL working set, one value per lane: command component c, the two episode sums this lane owns (terms ei and ei + 16 of its
@@ -448,6 +449,17 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         m_slo = kT->soft_dof_lo[d0 + cj]; m_shi = kT->soft_dof_hi[d0 + cj];
         m_rlo = kT->reset_dof_lo[d0 + cj]; m_rsp = kT->reset_dof_span[d0 + cj];
         m_nq = kT->noise_vec[9 + d0 + cj]; m_nqd = kT->noise_vec[9 + A + d0 + cj];
+    }
+    // go2_wtw: gait clock and behaviour targets (per-env scalars replicated, per-foot entries by leg), the latest push, the deferred-
+    // blanking flag of the observation stacks
+    float w_gt = 0.f, w_phi = 0.f, w_gp = 1.f, w_bh = 0.f, w_fc = 0.f, w_pt = 0.f, w_th = 0.f, w_ec = 0.f, w_push = 0.f;
+    int w_dirty = 0;
+    if (WQ) {
+        const float GAS *ts = KB(const float GAS *, task_state) + (size_t)e * LG_TASK_STATE_WTW;
+        w_gt = ts[0]; w_phi = ts[1]; w_gp = ts[2]; w_bh = ts[3]; w_fc = ts[4]; w_pt = ts[5];
+        w_th = ts[6 + foot_slot]; w_ec = ts[18 + foot_slot];
+        w_push = KB(const float GAS *, rand_push_vels)[3 * e + cj];
+        if (k_obs_dirty) w_dirty = (int)k_obs_dirty[e];
     }
     if (MPH != 0 && !QTAIL && threadIdx.x < 16) {
         const LgTaskCfg GAS *T = kT;
@@ -1170,6 +1182,29 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         const auto h_tracking_sigma = HOT(tracking_sigma);
         const auto h_yaw_clip_0 = HOT(yaw_clip[0]);
         const auto h_yaw_clip_1 = HOT(yaw_clip[1]);
+        // go2_wtw only (the reads fold away in the go2 instantiation)
+        const auto h_b_swing = WQ ? HOT(b_swing) : 0.f;
+        const auto h_base_height_sigma = WQ ? HOT(base_height_sigma) : 1.f;
+        const auto h_euler_sigma = WQ ? HOT(euler_sigma) : 1.f;
+        const auto h_behavior_resample_steps = WQ ? HOT(behavior_resample_steps) : 0;
+        const auto h_slots_task_cb = WQ ? HOT(slots.task_cb) : 0;
+        const auto h_slots_task_reset = WQ ? HOT(slots.task_reset) : 0;
+        const auto h_slots_dr_kp = WQ ? HOT(slots.dr_kp) : 0;
+        const auto h_slots_dr_kd = WQ ? HOT(slots.dr_kd) : 0;
+        const auto h_dr_pd_on = WQ ? HOT(dr_pd_on) : 0;
+        const auto h_dr_kp_lo = WQ ? HOT(dr_kp_lo) : 0.f;
+        const auto h_dr_kp_span = WQ ? HOT(dr_kp_span) : 0.f;
+        const auto h_dr_kd_lo = WQ ? HOT(dr_kd_lo) : 0.f;
+        const auto h_dr_kd_span = WQ ? HOT(dr_kd_span) : 0.f;
+        const auto h_reset_lin_vel_span = WQ ? HOT(reset_lin_vel_span) : 0.f;
+        const auto h_reset_ang_vel_span = WQ ? HOT(reset_ang_vel_span) : 0.f;
+        const auto h_obs_frame = WQ ? HOT(obs_frame) : 0;
+        const auto h_priv_frame = WQ ? HOT(priv_frame) : 0;
+        const auto h_obs_stack = WQ ? HOT(obs_stack) : 1;
+        const auto h_priv_stack = WQ ? HOT(priv_stack) : 1;
+        const auto h_obs_slack = WQ ? HOT(obs_slack) : 0;
+        const auto h_num_obs = WQ ? HOT(num_obs) : 0;
+        const auto h_num_priv_obs = WQ ? HOT(num_priv_obs) : 0;
         asm volatile("" ::: "memory");
         const float cdt = h_control_dt;
         const unsigned rmask = (unsigned)p.k.reward_mask;
@@ -1190,6 +1225,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         auto vnorm2 = [&](float v) { return bc<0>(sum3(v * v)); };               // |v|^2 of a component-layout vector, to the quad
 
         float cmdv = m_cmd, air = m_air, es0 = m_es0, es1 = m_es1;
+        float o_fric = dr_fric, o_mass = dr_mass, o_com = dr_com, o_kp = dr_kp, o_kd = dr_kd, o_push = w_push;   // what the critic frame shows (go2_wtw)
         int ep_len = m_ep + 1, failb = m_fail, last_contact = m_lc;              // legged_robot.py:60
         const float CRlo = L.is0 ? CR(0) : (L.is1 ? CR(2) : (L.is2 ? CR(4) : CR(6)));
         const float CRhi = L.is0 ? CR(1) : (L.is1 ? CR(3) : (L.is2 ? CR(5) : CR(7)));
@@ -1225,7 +1261,39 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 const float pv = (m + m) * u01(pick(r, slot & 3)) - m;
                 const bool xy = L.c < 2;
                 vw = xy ? vw + pv : vw;
+                o_push = xy ? pv : o_push;
                 if (live && leg == 0 && xy) { B.rand_push_vels[3 * e + L.c] = pv; B.base_lin_vel_w[3 * e + L.c] = vw; }
+            }
+        }
+        // ---- go2_wtw behaviour parameters (go2_wtw.py:180-218): lane c of every quad evaluates the block that holds draw `slot + c` and
+        //      picks it -- gait period, base-height, foot-clearance and pitch targets side by side --, one more call with the
+        //      env-independent counter picks the gait (one index per call for the whole batch, as in the reference)
+        float gait_time = w_gt, phi = w_phi, gait_period = w_gp, bh_tgt = w_bh, fc_tgt = w_fc, pitch_tgt = w_pt, theta = w_th, expC = w_ec;
+        // `u`: lane c holds the uniform of parameter c (gait period, base height, clearance, pitch); `ug`: the gait draw, replicated
+        auto behavior_apply = [&](const float u, const float ug, const bool who) {
+            const float lo = L.is0 ? CR(8) : (L.is1 ? CR(10) : (L.is2 ? CR(12) : CR(14)));
+            const float hi = L.is0 ? CR(9) : (L.is1 ? CR(11) : (L.is2 ? CR(13) : CR(15)));
+            const float val = (hi - lo) * u + lo;
+            const int ng = (int)CR(16);
+            const int sel = __builtin_amdgcn_readfirstlane(min((int)floorf(ug * (float)ng), ng - 1));
+            const float GAS *tt = &kT->theta_table[sel][0];
+            const float nth = tt[foot_slot];
+            const float t0 = tt[0], t1 = tt[1], t2 = tt[2], t3 = tt[3];
+            float nfc = bc<2>(val);
+            // pronk / bound gaits keep the lowest clearance target (go2_wtw.py:212-218)
+            if (t0 == 0.f && t1 == 0.f && ((t2 == 0.f && t3 == 0.f) || (t2 == 0.5f && t3 == 0.5f))) nfc = CR(12);
+            const float ngp = bc<0>(val), nbh = bc<1>(val), npt = bc<3>(val);
+            if (who) { gait_period = ngp; bh_tgt = nbh; fc_tgt = nfc; pitch_tgt = npt; theta = nth; }
+        };
+        auto philox_e = [&](unsigned elo, unsigned ehi, unsigned c3) { const U4 c = {elo, ehi, rstep, c3}; return philox4x32_10(c, k0, k1); };
+        if constexpr (WQ) {
+            const int brs = h_behavior_resample_steps;
+            const bool needb = brs > 0 && (ep_len % brs) == 0;                  // go2_wtw.py:258-263
+            if (anyl(needb)) {   // rare (every resampling_time): two calls, the parameters' blocks side by side in the quad's lanes
+                const int s = h_slots_task_cb + L.c;
+                const U4 r = philox((unsigned)(s >> 2));
+                const U4 rg = philox_e(0xFFFFFFFFu, 0xFFFFFFFFu, (unsigned)((h_slots_task_cb + 4) >> 2));
+                behavior_apply(u01(pick(r, s & 3)), u01(pick(rg, (h_slots_task_cb + 4) & 3)), needb);
             }
         }
         const float cmd0 = bc<0>(cmdv), cmd1 = bc<1>(cmdv), cmd2 = bc<2>(cmdv);
@@ -1315,31 +1383,89 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         if (RON(LG_R_LIN_VEL_Z)) { const float z = bc<2>(blv); add(LG_R_LIN_VEL_Z, z * z); }                                     // :458-460
         if (RON(LG_R_NO_FLY)) add(LG_R_NO_FLY, legsum<LEGS>(fz > 0.1f ? 1.f : 0.f) == 1.f ? 1.f : 0.f);                         // tron1_pf.py:151-154
         if (RON(LG_R_ORIENTATION)) { const float x = bc<0>(pg), y = bc<1>(pg); add(LG_R_ORIENTATION, x * x + y * y); }           // :466-468
+        if (WQ && RON(LG_R_QUAD_PERIODIC_GAIT)) {                                                                              // go2_wtw.py:377-484 ("step" indicator)
+            const float two_pi = 6.283185307179586f;
+            float ph = phi + theta;
+            ph = (ph - floorf(ph)) * two_pi;
+            const float b_sw = h_b_swing * two_pi;
+            const float c_frc = (ph >= 0.f && ph < b_sw) ? -1.f : 0.f;
+            const float c_spd = (ph >= b_sw && ph < two_pi) ? -1.f : 0.f;
+            expC = c_frc;
+            add(LG_R_QUAD_PERIODIC_GAIT, __expf(legsum<LEGS>(c_spd * sqrtf(vnorm2(foot_v)) + c_frc * sqrtf(n2[3]))));
+        }
         if (RON(LG_R_TORQUES)) add(LG_R_TORQUES, jsum(torque * torque));                                                         // :478-480
         if (RON(LG_R_TRACKING_ANG_VEL)) { const float d = cmd2 - bc<2>(bav); add(LG_R_TRACKING_ANG_VEL, __expf(-(d * d) / h_tracking_sigma)); }   // :539-543
+        if (WQ && RON(LG_R_TRACKING_BASE_HEIGHT)) { const float d = bc<2>(pos) - bh_tgt; add(LG_R_TRACKING_BASE_HEIGHT, __expf(-(d * d) / h_base_height_sigma)); }   // go2_wtw.py:495-500
+        if (WQ && RON(LG_R_TRACKING_FOOT_CLEARANCE)) {                                                                           // go2_wtw.py:507-519
+            const float vxy = sqrtf(fvx * fvx + fvy * fvy);
+            const float d = fpz - fc_tgt - h_foot_height_offset;
+            add(LG_R_TRACKING_FOOT_CLEARANCE, __expf(-legsum<LEGS>(vxy * (d * d)) / h_foot_clearance_sigma));
+        }
         if (RON(LG_R_TRACKING_LIN_VEL)) {                                                                                        // :533-537
             const float dx = cmd0 - bc<0>(blv), dy = cmd1 - bc<1>(blv);
             add(LG_R_TRACKING_LIN_VEL, __expf(-(dx * dx + dy * dy) / h_tracking_sigma));
         }
+        if (WQ && RON(LG_R_TRACKING_ORIENTATION)) {                                                                              // go2_wtw.py:502-505
+            const float ex = bc<0>(eul), dp = bc<1>(eul) - pitch_tgt;
+            add(LG_R_TRACKING_ORIENTATION, __expf(-(ex * ex + dp * dp) / h_euler_sigma));
+        }
         if (h_only_positive_rewards) total = fmaxf(total, 0.f);                                                               // :161-162
         if (RON(LG_R_TERMINATION)) add(LG_R_TERMINATION, (reset && !time_out) ? 1.f : 0.f);                                      // :163-168
+        if constexpr (WQ) {   // gait clock (go2_wtw.py:29-36)
+            gait_time += cdt;
+            if (gait_time >= gait_period - cdt / 2.f) gait_time = 0.f;
+            phi = gait_time / gait_period;
+        }
 
         STAMP(7);
+        // ONE Philox call per step and lane for everything drawn every step or at a reset: the four lanes of a quad evaluate four
+        // different blocks side by side -- lane 0 / 1: the observation-noise blocks 2 leg / 2 leg + 1 of env_step_body, lane 2: the
+        // leg's `_reset_dofs` block, lane 3: the env-level reset block 0x200 + leg.  A launch ends with its slowest wave, and that is
+        // always one with a reset in it: with the reset draws inside the call every wave makes anyway, a reset costs no Philox call
+        // (a call is ~800 cycles of quarter-rate multiplies).
+        const U4 rall = philox(L.is0 ? 0x80000000u + (unsigned)(2 * leg) : (L.is1 ? 0x80000000u + (unsigned)(2 * leg) + 1u
+                               : (L.is2 ? 0x40000000u + (unsigned)(h_slots_reset_dof + d0) : 0x80000000u + 0x200u + (unsigned)leg)));
+        const float rux = u01(rall.x), ruy = u01(rall.y), ruz = u01(rall.z), ruw = u01(rall.w);
+        const float ud = L.sel(bc<2>(rux), bc<2>(ruy), bc<2>(ruz));                          // element c of lane 2's block
+        const float rc = L.sel4(bc<3>(rux), bc<3>(ruy), bc<3>(ruz), bc<3>(ruw));             // element c of lane 3's block
         // ---- reset_idx (legged_robot.py:94-148, go2.py:17-37, 119-134) + simulator.reset_idx (genesis_simulator.py:62-82) ----
         if (anyl(reset)) {
-            // env-level uniforms: block 0x200 + leg in the lanes of quad `leg` (all four blocks in one pass), then the element
-            // each lane needs is fetched from the quad that holds it: v0 = (cmd u0 u1 u2 | friction), v1 = (CoM xyz | mass)
-            // (slots of env_step_body's eu[]; the root twist draws are not needed: flat_profile demands zero spans)
-            const U4 rb = philox(0x80000000u + 0x200u + (unsigned)leg);
-            const float rc = u01(pick(rb, L.c));
+            // env-level uniforms (block 0x200 + leg sits in quad `leg`): the element each lane needs is fetched from the quad that
+            // holds it: v0 = (cmd u0 u1 u2 | friction), v1 = (CoM xyz | mass), v2 / v3 = root twist (slots of env_step_body's eu[])
             const float v0 = fetch(rc, L.c), v1 = fetch(rc, 4 + L.c);
+            const float v2 = WQ ? fetch(rc, 8 + L.c) : 0.f, v3 = WQ ? fetch(rc, 12 + L.c) : 0.f;   // root twist draws (slots 8-10, 12-14)
+            // go2_wtw: ONE more call for what only a reset of this task draws -- lane 0 / 1: the leg's kp / kd blocks
+            // (genesis_simulator.py:735-739), lanes 2 / 3 of quads 0 and 1: the four behaviour parameters' draws, lane 2 of quad 2: the
+            // gait draw with the env-independent counter (go2_wtw.py:124-142, 180-218)
+            float nkp = 1.f, nkd = 1.f;
+            if constexpr (WQ) {
+                const int sb = h_slots_task_reset + (leg == 2 ? 4 : 2 * leg + (L.c - 2));    // lanes 2 / 3: behaviour draw index
+                const bool gl = leg == 2;
+                const unsigned c3 = L.is0 ? 0x40000000u + (unsigned)(h_slots_dr_kp + d0)
+                                          : (L.is1 ? 0x40000000u + (unsigned)(h_slots_dr_kd + d0) : (unsigned)(sb >> 2));
+                const bool envc = L.c < 2 || !gl;      // this lane's block is keyed on the env (the gait draw is not)
+                const U4 rB = philox_e(envc ? e_lo : 0xFFFFFFFFu, envc ? e_hi : 0xFFFFFFFFu, c3);
+                const float bx = u01(rB.x), by = u01(rB.y), bz = u01(rB.z);
+                nkp = h_dr_kp_span * L.sel(bc<0>(bx), bc<0>(by), bc<0>(bz)) + h_dr_kp_lo;       // element c of lane 0's block
+                nkd = h_dr_kd_span * L.sel(bc<1>(bx), bc<1>(by), bc<1>(bz)) + h_dr_kd_lo;       // element c of lane 1's block
+                const float ub = u01(pick(rB, sb & 3));                                            // valid in lanes 2 / 3
+                // parameter c was drawn in lane 2 + (c & 1) of quad c >> 1; the gait draw in lane 2 of quad 2
+                behavior_apply(fetch(ub, (L.c < 2 ? 2 : 4) + L.c), fetch(ub, 10), reset);
+            }
             const float ncmd = resample(cmdv, bc<0>(v0), bc<1>(v0), bc<2>(v0));
-            const U4 rd = philox(0x40000000u + (unsigned)(h_slots_reset_dof + d0));      // _reset_dofs: one block per leg
-            const float ud = u01(pick(rd, cj));
             const float ipos = L.sel(h_o_base_init_pos_0, h_o_base_init_pos_1, h_o_base_init_pos_2) + origin;
             const float iq = L.is3 ? h_base_init_quat_3 : L.sel(h_base_init_quat_0, h_base_init_quat_1, h_base_init_quat_2);
-            const float nvw = h_reset_lin_vel_lo, nww = h_reset_ang_vel_lo;      // go2.py:131-133 draws U(0, 0) (flat_profile: zero spans)
+            // go2.py:131-133 draws U(0, 0) (flat_profile: zero spans); go2_wtw: legged_robot.py:289-292
+            const float nvw = h_reset_lin_vel_span * v2 + h_reset_lin_vel_lo, nww = h_reset_ang_vel_span * v3 + h_reset_ang_vel_lo;
+            // quad broadcasts stay outside the divergent branch
+            const float nfric = bc<3>(h_dr_friction_span * v0 + h_dr_friction_lo), nmass = bc<3>(h_dr_mass_span * v1 + h_dr_mass_lo);
+            const float ncom = L.sel(h_dr_com_span_0, h_dr_com_span_1, h_dr_com_span_2) * v1 + L.sel(h_dr_com_lo_0, h_dr_com_lo_1, h_dr_com_lo_2);
             if (reset) {
+                if (WQ) { gait_time = 0.f; phi = 0.f; }
+                if (WQ && h_dr_pd_on) { o_kp = nkp; o_kd = nkd; }
+                if (h_dr_friction_on) o_fric = nfric;
+                if (h_dr_mass_on) o_mass = nmass;
+                if (h_dr_com_on) o_com = ncom;
                 cmdv = ncmd;
                 q = q0 + (m_rsp * ud + m_rlo); qd = 0.f;
                 act = 0.f; last_act = 0.f; llast_act = 0.f;
@@ -1354,6 +1480,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             if (reset && st) {
                 B.dof_pos[ja] = q; B.dof_vel[ja] = 0.f; B.last_dof_vel[ja] = 0.f;
                 B.actions[ja] = 0.f; B.last_actions[ja] = 0.f; B.llast_actions[ja] = 0.f;
+                if (WQ && h_dr_pd_on) { B.kp_scale[ja] = o_kp; B.kd_scale[ja] = o_kd; }
                 B.last_feet_vel[(e * F + foot_slot) * 3 + cj] = 0.f;
                 if (leg == 0) {
                     B.base_pos[3 * e + cj] = pos; B.base_lin_vel_w[3 * e + cj] = vw; B.base_ang_vel_w[3 * e + cj] = ww;
@@ -1377,6 +1504,89 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             }
         }
         STAMP(9);
+        if constexpr (WQ) {
+            // ---- compute_observations + clip, go2_wtw.py:53-111: actor frame 61 = go2's 45 | clock sin 4, cos 4 | gait period, base-height,
+            //      clearance, pitch targets | theta 4; critic frame 99 = the frame without noise | v_b 3, push 2, mass, friction, CoM 3 |
+            //      kp 12 | kd 12 | exp_C_frc 4.  Five-frame stacks as sliding windows over rows with slack, in `obs_sets` copies: the new
+            //      frame goes to this launch's window in this set and to the same frame index of the other set; an env that resets
+            //      blanks the older frames of its window, one that reset at the previous launch the frames older than that (`dirty`) --
+            //      the same bookkeeping as env_step_body's, with the env's 16 lanes writing consecutive columns.
+            const float co = h_clip_obs;
+            const bool nz = h_add_noise != 0;
+            const int FR = h_obs_frame, PF = h_priv_frame, ST = h_obs_stack, PST = h_priv_stack, SL = h_obs_slack;
+            const size_t orow = (size_t)(h_num_obs + SL * FR), prow = (size_t)(h_num_priv_obs + SL * PF);
+            const bool two = h_obs_sets > 1;
+            const int cs = two ? p.obs_set : 0, xs = two ? 1 - cs : 0;
+            float *oc = B.obs_buf + ((size_t)cs * N + e) * orow + (size_t)p.obs_win * FR;
+            float *ox = B.obs_buf + ((size_t)xs * N + e) * orow + (size_t)p.obs_win * FR;
+            float *pc = B.priv_obs_buf + ((size_t)cs * N + e) * prow + (size_t)p.obs_win * PF;
+            float *px = B.priv_obs_buf + ((size_t)xs * N + e) * prow + (size_t)p.obs_win * PF;
+            if (anyl(reset)) {                         // go2_wtw.py:174-178
+                if (reset && live) {
+                    for (int i = ei; i < (ST - 1) * FR; i += 16) oc[i] = 0.f;
+                    for (int i = ei; i < (PST - 1) * PF; i += 16) pc[i] = 0.f;
+                }
+            }
+            if (two && anyl(!reset && w_dirty != 0)) {
+                if (!reset && w_dirty != 0 && live) {
+                    for (int i = ei; i < (ST - 2) * FR; i += 16) oc[i] = 0.f;
+                    for (int i = ei; i < (PST - 2) * PF; i += 16) pc[i] = 0.f;
+                }
+            }
+            float *on = oc + (ST - 1) * FR, *on2 = ox + (ST - 1) * FR, *pn = pc + (PST - 1) * PF, *pn2 = px + (PST - 1) * PF;
+            const bool w2o = two && ST > 1, w2p = two && PST > 1;
+            float uq = 0.5f, uqd = 0.5f, ug = 0.5f, ua = 0.5f;
+            if (nz) {   // same blocks as the go2 frame below
+                const float ux = rux, uy = ruy, uz = ruz, uw = ruw;   // lanes 0 / 1 hold blocks 2 leg / 2 leg + 1 (shared call above)
+                uq = L.sel(bc<0>(ux), bc<0>(uy), bc<0>(uz));
+                uqd = L.sel(bc<1>(ux), bc<1>(uy), bc<1>(uz));
+                ug = fetch(uw, 4 * (cj >> 1) + (cj & 1));
+                ua = fetch(uw, 4 * ((3 + cj) >> 1) + ((3 + cj) & 1));
+            }
+            // W: an actor-frame entry (noisy into the actor windows, noise-free into the critic frame); WP: a critic-only entry
+            auto W = [&](int idx, float v, float u, float ns) {
+                const float cl = clampf(v, -co, co);
+                const float nv = clampf(nz ? v + (2.f * u - 1.f) * ns : v, -co, co);
+                on[idx] = nv; if (w2o) on2[idx] = nv;
+                pn[idx] = cl; if (w2p) pn2[idx] = cl;
+            };
+            auto WP = [&](int idx, float v) { const float cl = clampf(v, -co, co); pn[idx] = cl; if (w2p) pn2[idx] = cl; };
+            const float ang = 6.283185307179586f * (phi + theta);        // clock inputs (go2_wtw.py:251-256)
+            const float sn = sinf(ang), csn = cosf(ang);
+            if (st) {
+                W(9 + d0 + cj, (q - q0) * h_obs_scale_dof_pos, uq, m_nq);
+                W(9 + A + d0 + cj, qd * h_obs_scale_dof_vel, uqd, m_nqd);
+                W(9 + 2 * A + d0 + cj, act, 0.5f, 0.f);
+                W((L.is0 ? 45 : (L.is1 ? 49 : 57)) + foot_slot, L.sel(sn, csn, theta), 0.5f, 0.f);
+                WP(FR + 10 + d0 + cj, o_kp);
+                WP(FR + 10 + A + d0 + cj, o_kd);
+                if (L.is0) WP(FR + 10 + 2 * A + foot_slot, expC);
+                if (leg == 0) {
+                    W(cj, cmdv * (L.is2 ? h_obs_scale_ang_vel : h_obs_scale_lin_vel), 0.5f, 0.f);
+                    W(3 + cj, pg, ug, L.sel(h_noise_lead_0, h_noise_lead_1, h_noise_lead_2));
+                    W(6 + cj, bav * h_obs_scale_ang_vel, ua, L.sel(h_noise_lead_3, h_noise_lead_4, h_noise_lead_5));
+                    WP(FR + cj, blv * h_obs_scale_lin_vel);
+                }
+                if (leg == 2) WP(FR + 7 + cj, o_com);
+            }
+            const float env4 = L.sel4(bc<0>(o_push), bc<1>(o_push), o_mass, o_fric);   // quad broadcasts outside the divergent branches
+            if (live && leg == 0) W(53 + L.c, L.sel4(gait_period, bh_tgt, fc_tgt, pitch_tgt), 0.5f, 0.f);
+            if (live && leg == 1) WP(FR + 3 + L.c, env4);
+            // task state as the env class exposes it (go2_wtw.py:295-346), the deferred-blanking flag, the second action-history shift
+            // (go2_wtw.py:45-46: afterwards last == llast == a_t)
+            float *ts = B.task_state + (size_t)e * LG_TASK_STATE_WTW;
+            if (st) {
+                ts[(L.is0 ? 6 : (L.is1 ? 10 : 14)) + foot_slot] = L.sel(theta, sn, csn);
+                if (L.is0) ts[18 + foot_slot] = expC;
+                B.llast_actions[ja] = reset ? 0.f : last_act;
+                B.last_actions[ja] = act;
+            }
+            if (live && leg == 0) {
+                ts[L.c] = L.sel4(gait_time, phi, gait_period, bh_tgt);
+                if (L.c < 2) ts[4 + L.c] = L.is0 ? fc_tgt : pitch_tgt;
+                if (L.is0 && B.obs_dirty) B.obs_dirty[e] = reset ? 1 : 0;
+            }
+        } else
         // ---- compute_observations + clip (go2.py:40-64, legged_robot.py:48-49) ----
         {
             const float co = h_clip_obs;
@@ -1385,8 +1595,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             if (nz) {
                 // blocks 2 leg and 2 leg + 1 of env_step_body in lanes 0 and 1 of the quad, side by side: (x, y, z) = the three joints'
                 // uniforms (positions / velocities), w = one of the base's six
-                const U4 rn = philox(0x80000000u + (unsigned)(2 * leg) + (L.is1 ? 1u : 0u));
-                const float ux = u01(rn.x), uy = u01(rn.y), uz = u01(rn.z), uw = u01(rn.w);
+                const float ux = rux, uy = ruy, uz = ruz, uw = ruw;   // lanes 0 / 1 hold blocks 2 leg / 2 leg + 1 (shared call above)
                 uq = L.sel(bc<0>(ux), bc<0>(uy), bc<0>(uz));
                 uqd = L.sel(bc<1>(ux), bc<1>(uy), bc<1>(uz));
                 // base uniform k sits in quad k / 2, lane k % 2: gravity component c takes k = c, angular velocity k = 3 + c

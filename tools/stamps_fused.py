@@ -4,11 +4,12 @@ sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."
 import torch
 from hcr_genesis_lr_cl_amd.envs import make_env
 NE = int(os.environ.get("NE", "4096"))
-env, cfg = make_env("go2", NE)
+TASK = os.environ.get("TASK", "go2")
+env, cfg = make_env(TASK, NE)
 env.reset()
 g = torch.Generator(device="cuda"); g.manual_seed(1)
 env.episode_length_buf[:] = torch.randint(0, 1000, (NE,), generator=g, device="cuda", dtype=torch.int32)
-bank = [torch.randn(NE, 12, generator=g, device="cuda") for _ in range(8)]
+bank = [torch.randn(NE, env.num_actions, generator=g, device="cuda") for _ in range(8)]
 acc = torch.zeros(32); n = 0
 for i in range(800):
     env.step(bank[i % 8])
