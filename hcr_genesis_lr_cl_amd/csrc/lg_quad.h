@@ -16,8 +16,10 @@
 //
 // All control flow is wave-uniform (ballot + scalar branch): a DPP read from a lane switched off by EXEC is
 // undefined, so lanes are never masked off; dead lanes (past the last env) shadow the last env and only their
-// stores are predicated.  Lane 3 of a quad carries no vector component; its values are "don't care" and never
-// reach lanes 0-2 (quad permutes used for vector work map lane 3 onto itself).
+// stores are predicated.  Lane 3 of a quad carries no vector component; its vector values are "don't care" and never
+// reach lanes 0-2 (quad permutes used for vector work map lane 3 onto itself).  It does carry the quaternion's w, and with
+// four-joint legs (JPL = 4) the fourth joint's scalars; reductions are only formed in lanes 0-2, so what lane 3 needs from one
+// is fetched from lane 0.
 //
 // Algorithm = lg_kernel.hip's SIM phase statement for statement (same world-aligned ABA about the base origin,
 // same contact / limit laws); tests/test_gpu_physics.py checks both layouts against the same f64 CPU restatement.
@@ -1113,7 +1115,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
 
     STAMP(22);
     STAMPB(8192);
-    // ---------------- MDP phases in the same launch, go2-flat profile: component layout, all 64 lanes ------------
+    // ---------------- MDP phases in the same launch, go2-flat and go2_wtw profiles: component layout, all 64 lanes ------------
     // Same statements as env_step_body's POST / RESET phases (legged_robot.py:55-168, 300-348, go2.py:17-134) for the plain go2
     // task, computed on the registers the physics left behind: per-joint values sit in joint lanes, vectors one component per
     // lane, per-env scalars replicated over the env's 16 lanes.  No LDS hand-off, every lane loads / stores its own share of the
