@@ -2683,6 +2683,7 @@ static int rough_profile(const LgEngine *h) {
     const LgTaskCfg &t = h->task;
     if (t.gait_mode != 0 || t.sit_percent != 0.f || t.behavior_resample_steps != 0 || t.noise_vec[9 + 6 * h->model.n_legs] != 0.f || h->bufs.task_state)
         return 0;
+    if (!h->hf || h->opts.terrain_rows <= 0) return 0;     // the profiles hard-wire "there is a heightfield" (lg_quad.h HFC)
     if (t.obs_layout == LG_OBS_GO2_EE && t.double_shift == 0 && t.cat_enable == 0) return 3;
     if (t.obs_layout == LG_OBS_PROGRAM) return 4;
     return 0;
@@ -2773,15 +2774,21 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
         // MDP phases: in the tail of the same launch for the quadruped (measured 39.5 vs 40.6 us for go2, 69.6 vs 72.5
         // for go2_ee), as a second launch for the biped (84.7 vs 90.6 us for tron1_pf_ee: 8 envs per wave there)
         const bool fuse = LEGS == 4 && pre && rest != 0;
+        const bool hfb = h->hf != nullptr && h->opts.terrain_rows > 0;
         if (fuse && rest == (LG_PHASE_POST | LG_PHASE_RESET) && flat_profile(h)) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET, 1>), qgrid);
         else if (fuse && rest == (LG_PHASE_POST | LG_PHASE_RESET) && wtw_profile(h)) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET, 2>), qgrid);
         else if (fuse && rest == (LG_PHASE_POST | LG_PHASE_RESET) && rough_profile(h) == 3) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET, 3>), qgrid);
         else if (fuse && rest == (LG_PHASE_POST | LG_PHASE_RESET) && rough_profile(h) == 4) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET, 4>), qgrid);
         else if (fuse && rest == (LG_PHASE_POST | LG_PHASE_RESET)) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET>), qgrid);
         else if (fuse && rest == LG_PHASE_POST) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, LG_PHASE_POST>), qgrid);
+        // physics-only launches: PROF 3 here only says "a heightfield is bound" (lg_quad.h HFC: no branch in front of the terrain loads)
+        else if (pre && rest && hfb) LG_LAUNCH_FIRST(pi, (quad_sim_kernel<LEGS, true, 0u, 3>), qgrid);
         else if (pre && rest) LG_LAUNCH_FIRST(pi, (quad_sim_kernel<LEGS, true, 0u>), qgrid);
+        else if (pre && hfb) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, 0u, 3>), qgrid);
         else if (pre) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, true, 0u>), qgrid);
+        else if (rest && hfb) LG_LAUNCH_FIRST(pi, (quad_sim_kernel<LEGS, false, 0u, 3>), qgrid);
         else if (rest) LG_LAUNCH_FIRST(pi, (quad_sim_kernel<LEGS, false, 0u>), qgrid);
+        else if (hfb) LG_LAUNCH(pi, (quad_sim_kernel<LEGS, false, 0u, 3>), qgrid);
         else LG_LAUNCH(pi, (quad_sim_kernel<LEGS, false, 0u>), qgrid);
         HIPCHK(hipGetLastError());
         if (!fuse && rest) {

@@ -258,8 +258,10 @@ struct QKin { QM R; float P; QV6 V; };
 struct Terr { int rows, cols; float border, ihs, vscale; const int16_t *hf; };
 
 // terrain height and unit normal at world (x, y) -- scalar form, any lane
-LG_DEV void terrain(const Terr &T, float x, float y, float &h, float &nx, float &ny, float &nz) {
-    if (T.rows <= 0) { h = 0.f; nx = ny = 0.f; nz = 1.f; return; }
+// HF: the caller knows there is a heightfield (rough task profiles, host-checked): no branch in front of the loads, so the loads of
+// several lookups can be scheduled together
+template <bool HF = false> LG_DEV void terrain(const Terr &T, float x, float y, float &h, float &nx, float &ny, float &nz) {
+    if (!HF && T.rows <= 0) { h = 0.f; nx = ny = 0.f; nz = 1.f; return; }
     const float gx = (x + T.border) * T.ihs, gy = (y + T.border) * T.ihs;
     int ix = (int)floorf(gx), iy = (int)floorf(gy);
     ix = min(max(ix, 0), T.rows - 2);
@@ -532,7 +534,8 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     Terr TR;
     TR.rows = PLANE ? 0 : HOT(o_terrain_rows); TR.cols = HOT(o_terrain_cols); TR.border = HOT(o_border); TR.ihs = 1.f / HOT(o_hscale);
     TR.vscale = HOT(o_vscale); TR.hf = p.hf;
-    const bool hfmode = !PLANE && TR.rows > 0;
+    constexpr bool HFC = PROF == 3 || PROF == 4;   // rough task profiles: a heightfield is bound (lg_kernel.hip rough_profile)
+    const bool hfmode = HFC ? true : (!PLANE && TR.rows > 0);
     const float mass0 = M->mass[0] + dr_mass;
     const float com0 = M->com[0][cj] + dr_com;
     auto sym_row = [&](const float *s6) {   // rows of a symmetric 3x3 stored (xx, yy, zz, xy, xz, yz)
@@ -642,6 +645,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         QV6 ext[JPL], extb = {0.f, 0.f};
 #pragma unroll
         for (int j = 0; j < JPL; j++) ext[j] = QV6{0.f, 0.f};
+        float ft_h = 0.f, ft_nx = 0.f, ft_ny = 0.f, ft_nz = 1.f;   // terrain under the foot sphere (looked up with the broad phase below, used in stage 2)
         {
             const float px = bc<0>(pos), py = bc<1>(pos), pz = bc<2>(pos);
             // broad phase of one slot: this lane's sphere of body (R, P); returns the penetration depth (and centre / terrain)
@@ -653,7 +657,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 if (hfmode) {
                     t.rx = bc<0>(P) + bc<0>(R.c0) * sx[k] + bc<0>(R.c1) * sy[k] + bc<0>(R.c2) * sz[k];
                     t.ry = bc<1>(P) + bc<1>(R.c0) * sx[k] + bc<1>(R.c1) * sy[k] + bc<1>(R.c2) * sz[k];
-                    terrain(TR, px + t.rx, py + t.ry, t.h, t.nx, t.ny, t.nz);
+                    terrain<HFC>(TR, px + t.rx, py + t.ry, t.h, t.nx, t.ny, t.nz);
                 }
                 t.depth = srad[k] - (pz + t.rz - t.h) * t.nz - dref;
                 t.on = t.depth > -margin;
@@ -705,8 +709,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 acc.l += L.sel(sum4(f[0]), sum4(f[1]), sum4(f[2]));
             };
             // one slot of a body; the force branch runs only if some sphere of the slot touches somewhere in the wave
-            auto slot = [&](int k, const QM &R, float P, const QV6 &V, QV6 &acc) {
-                const Hit t = probe(k, R, P);
+            auto slot = [&](int k, const Hit &t, const QM &R, float P, const QV6 &V, QV6 &acc) {
                 if (__builtin_amdgcn_ballot_w64(t.on) != 0ull) {
                     float m[3] = {0.f, 0.f, 0.f}, f[3] = {0.f, 0.f, 0.f};
                     force(k, t, gather(R, P, V), m, f);
@@ -714,17 +717,28 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 }
             };
             const QV6 V0 = {ww, vw};
-            slot(4, Rb, 0.f, V0, extb);
-            slot(0, K[0].R, K[0].P, K[0].V, ext[0]);
-            slot(1, K[1].R, K[1].P, K[1].V, ext[1]);
+            // Broad phase of EVERY slot first.  On a heightfield each probe is a dependent round trip (cell index -> four int16 loads ->
+            // bilinear height and normal): probe, force, probe, force ... exposed one L2 round trip per slot and sub-step in the serial
+            // chain (rough terrain: +14 k cycles per control step over the plane); issued together the loads overlap.
+            const Hit tb = probe(4, Rb, 0.f), ta = probe(0, K[0].R, K[0].P), tc = probe(1, K[1].R, K[1].P);
+            const Hit td = probe(2, K[2].R, K[2].P);
+            Hit te = td;
+            if constexpr (JPL == 3) te = probe(3, K[2].R, K[2].P);   // the calf's second slot
+            if (HFC) {   // the foot's lookup rides in the same batch of loads
+                const float rf = K[JPL - 1].P + mulv(K[JPL - 1].R, foot_c_loc);
+                terrain<HFC>(TR, px + bc<0>(rf), py + bc<1>(rf), ft_h, ft_nx, ft_ny, ft_nz);
+            }
+            slot(4, tb, Rb, 0.f, V0, extb);
+            slot(0, ta, K[0].R, K[0].P, K[0].V, ext[0]);
+            slot(1, tc, K[1].R, K[1].P, K[1].V, ext[1]);
             if constexpr (JPL == 4) {
-                slot(2, K[2].R, K[2].P, K[2].V, ext[2]);
+                slot(2, td, K[2].R, K[2].P, K[2].V, ext[2]);
                 // the sole corners: penetration / approach velocity relative to the sole centre's while that one is in the ground
                 const BodyS g = gather(K[3].R, K[3].P, K[3].V);
                 const float rc = K[3].P + mulv(K[3].R, foot_c_loc);
                 const float rcx = bc<0>(rc), rcy = bc<1>(rc), rcz = bc<2>(rc);
                 float hc = 0.f, ncx = 0.f, ncy = 0.f, ncz = 1.f;
-                if (hfmode) terrain(TR, px + rcx, py + rcy, hc, ncx, ncy, ncz);
+                if (hfmode) terrain<HFC>(TR, px + rcx, py + rcy, hc, ncx, ncy, ncz);
                 const float dc = foot_r - (pz + rcz - hc) * ncz;
                 const float vcx = g.vx + (g.wy * rcz - g.wz * rcy), vcy = g.vy + (g.wz * rcx - g.wx * rcz), vcz = g.vz + (g.wx * rcy - g.wy * rcx);
                 const float dref = dc > 0.f ? dc : 0.f;
@@ -744,7 +758,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                     reduce(m, f, ext[3]);
                 }
             } else {   // the calf's two slots share one gather and one reduction
-                const Hit t2 = probe(2, K[2].R, K[2].P), t3 = probe(3, K[2].R, K[2].P);
+                const Hit t2 = td, t3 = te;
                 if (__builtin_amdgcn_ballot_w64(t2.on || t3.on) != 0ull) {
                     float m[3] = {0.f, 0.f, 0.f}, f[3] = {0.f, 0.f, 0.f};
                     const BodyS g = gather(K[2].R, K[2].P, K[2].V);
@@ -831,8 +845,8 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         bool fact;
         {
             const float r = K[JPL - 1].P + mulv(K[JPL - 1].R, foot_c_loc);
-            float h, nx, ny, nz;
-            terrain(TR, bc<0>(pos) + bc<0>(r), bc<1>(pos) + bc<1>(r), h, nx, ny, nz);
+            float h = ft_h, nx = ft_nx, ny = ft_ny, nz = ft_nz;
+            if (!HFC) terrain<HFC>(TR, bc<0>(pos) + bc<0>(r), bc<1>(pos) + bc<1>(r), h, nx, ny, nz);
             depth = foot_r - (bc<2>(pos) + bc<2>(r) - h) * nz;
             fact = depth > -margin;
             cn = L.sel(nx, ny, nz);
