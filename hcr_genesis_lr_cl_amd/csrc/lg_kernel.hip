@@ -555,8 +555,12 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     const int tid = vtid;
     const int leg = tid % LEGS;
     int e = tid / LEGS;
-    const bool live = e < B.n_envs;
-    if (!live) e = B.n_envs - 1;  // dead lanes shadow the last env (keeps DPP quads uniform), never store
+    // FUSED: the wave runs four replicas of its 16 leg-lanes (lg_quad.h); replica `sub` > 0 computes the same values and stores only
+    // its share of the observation outputs
+    const int sub = FUSED ? ((int)threadIdx.x >> 4) : 0;
+    const bool live_all = e < B.n_envs;
+    const bool live = live_all && sub == 0;
+    if (!live_all) e = B.n_envs - 1;  // dead lanes shadow the last env (keeps DPP quads uniform), never store
     const bool lead = live && leg == 0;
     const int L = p.k.m_n_links, F = LEGS;
     const int b0 = 1 + JPL * leg;          // first body of this lane's chain
@@ -2011,17 +2015,17 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             // biped resets often.  With two sets an env reset at the PREVIOUS observation launch still carries its old
             // history in this set (that launch blanked the other one): everything older than the frame that launch
             // wrote goes now (`dirty`).
-            const int nl = FUSED ? 16 : BLOCK;
+            const int nl = BLOCK, wl = (int)threadIdx.x & (BLOCK - 1);   // every lane of the wave (all replicas when FUSED)
             auto blank = [&](unsigned long long rm, int keep) {   // zero all but the newest `keep` frames of the window
                 while (rm) {
                     const int bit = __builtin_ctzll(rm);
                     rm &= rm - 1;
                     const int er = (vtid - vlane + bit) / LEGS;
                     float *orw = oset_c + (size_t)er * orow + (size_t)p.obs_win * FR;
-                    for (int i = vlane; i < (ST - keep) * FR; i += nl) orw[i] = 0.f;
+                    for (int i = wl; i < (ST - keep) * FR; i += nl) orw[i] = 0.f;
                     if (pset_c) {
                         float *prw = pset_c + (size_t)er * prow + (size_t)p.obs_win * PF;
-                        for (int i = vlane; i < (PST - keep) * PF; i += nl) prw[i] = 0.f;
+                        for (int i = wl; i < (PST - keep) * PF; i += nl) prw[i] = 0.f;
                     }
                 }
             };
@@ -2178,6 +2182,33 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 nl[k] = clampf(x, -co, co);
             }
             const bool crit = has_pn && pfo >= 0;
+            if constexpr (FUSED) {   // replica 0: this window, 1: the other set's, 2: the critic frame's copy, 3: the other set's critic copy
+                float *const dst = sub == 0 ? on : (sub == 1 ? on2 : (sub == 2 ? pn + pfo : pn2 + pfo));
+                const bool en = sub == 0 || (sub == 1 && has_on2) || (sub == 2 && crit) || (sub == 3 && crit && has_pn2);
+                const bool noisy = sub < 2;
+                if (live_all && en) {
+#pragma unroll
+                    for (int g = 0; g < 3; g++) {
+                        float w[JPL];
+#pragma unroll
+                        for (int j = 0; j < JPL; j++) w[j] = noisy ? nj[g][j] : fj[g][j];
+                        stv<JPL>(dst + 9 + g * A + d0, w);
+                    }
+                    if (leg == 0) {
+                        float w[9];
+#pragma unroll
+                        for (int k = 0; k < 9; k++) w[k] = noisy ? nl[k] : fl[k];
+                        stv<9>(dst, w);
+                    }
+                }
+                if (nxo >= 0) {   // go2_dreamwaq.py:66-74: the "next state" labels, not clipped, actions scaled (replica 0)
+                    float sa[JPL];
+#pragma unroll
+                    for (int j = 0; j < JPL; j++) sa[j] = vj[2][j] * HOT(o_action_scale);
+                    if (live) { stv<JPL>(labp + nxo + 9 + d0, vj[0]); stv<JPL>(labp + nxo + 9 + A + d0, vj[1]); stv<JPL>(labp + nxo + 9 + 2 * A + d0, sa); }
+                    if (lead) stv<9>(labp + nxo, vl);
+                }
+            } else {
             if (live) {
 #pragma unroll
                 for (int g = 0; g < 3; g++) stv<JPL>(on + 9 + g * A + d0, nj[g]);
@@ -2206,6 +2237,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 if (crit) { stv<9>(pn + pfo, fl); if (has_pn2) stv<9>(pn2 + pfo, fl); }
                 if (nxo >= 0) stv<9>(labp + nxo, vl);
             }
+            }
         }
         STAMP(27);
         if (hc_obs_layout == LG_OBS_GO2_WTW) {
@@ -2232,12 +2264,26 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             const int K = __popc(M->state_link_mask);
             const int l0 = foot_link - 3;
             float *lab = B.labels_buf + ((size_t)cs * N + e) * hc_num_labels;
-            if (live) {
+            // FUSED: the critic entries are dealt over the replicas -- replica r writes the copy r & 1 (this set's / the other set's
+            // critic frame); the heights, the long block, are also halved by r >> 1.  The labels row belongs to replica 0.
+            const bool lw = FUSED ? live_all && ((sub & 1) == 0 || has_pn2) : live;
+            const bool lw01 = FUSED ? lw && sub < 2 : live;
+            float *const pd = (FUSED && (sub & 1)) ? pn2 : pn;
+            auto wp = [&](int idx, float v) { const float c = clampf(v, -co, co); pd[idx] = c; if (!FUSED && has_pn2) pn2[idx] = c; };
+            auto wpv = [&](auto nv_, const int idx0, const float *v) {
+                constexpr int NV = decltype(nv_)::value;
+                float cn[NV];
+#pragma unroll
+                for (int k = 0; k < NV; k++) cn[k] = clampf(v[k], -co, co);
+                stv<NV>(pd + idx0, cn);
+                if (!FUSED && has_pn2) stv<NV>(pn2 + idx0, cn);
+            };
+            if (lw01) {
                 float vkp[JPL], vkd[JPL];
 #pragma unroll
                 for (int j = 0; j < JPL; j++) { vkp[j] = ld_kp[j] - HOT(kp_offset); vkd[j] = ld_kd[j] - HOT(kd_offset); }
-                putpv(NJ, FR + 7 + d0, vkp);
-                putpv(NJ, FR + 7 + A + d0, vkd);
+                wpv(NJ, FR + 7 + d0, vkp);
+                wpv(NJ, FR + 7 + A + d0, vkd);
                 // contact states are those of the physics read-back (stale for a just-reset env, as in the reference)
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
@@ -2245,32 +2291,36 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     if ((M->state_link_mask >> l) & 1u) {
                         const int idx = __popc(M->state_link_mask & ((1u << l) - 1u));
                         const float cs = norm(f_link[k]) > 1.f ? 1.f : 0.f;
-                        putp(FR + 7 + 2 * A + idx, cs);
-                        lab[3 + idx] = cs;
+                        wp(FR + 7 + 2 * A + idx, cs);
+                        if (live) lab[3 + idx] = cs;
                     }
                 }
+            }
+            if (lw) {
                 if (hreg) {
 #pragma unroll
                     for (int i = 0; i < HMAX; i++) {
                         const int k = leg + i * LEGS;
                         float hv = pos.z - hc_heights_offset - hts[i];
                         if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
-                        if (k < P) putp(FR + 7 + 2 * A + K + k, hv);
+                        if (k < P && (!FUSED || (i & 1) == (sub >> 1))) wp(FR + 7 + 2 * A + K + k, hv);
                     }
-                } else {
+                } else if (!FUSED || sub < 2) {
                     for (int k = leg; k < P; k += LEGS) {
                         float hv = pos.z - hc_heights_offset - B.measured_heights[(size_t)e * P + k];
                         if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
-                        putp(FR + 7 + 2 * A + K + k, hv);
+                        wp(FR + 7 + 2 * A + K + k, hv);
                     }
                 }
-                // labels (go2_ee.py:69-75): v_b 3 | contact states K | foot height above the local terrain mean F
-                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmean - hc_foot_height_offset, -1.f, 1.f);
+            }
+            // labels (go2_ee.py:69-75): v_b 3 | contact states K | foot height above the local terrain mean F
+            if (live) lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmean - hc_foot_height_offset, -1.f, 1.f);
+            if (lw01 && leg == 0) {
+                const float vdr[7] = {ld_fric - HOT(friction_offset), ld_mass, ld_com[0], ld_com[1], ld_com[2], ld_push[0], ld_push[1]};
+                wpv(std::integral_constant<int, 7>{}, FR, vdr);
+                if (M->state_link_mask & 1u) { const float cs = norm(f_base) > 1.f ? 1.f : 0.f; wp(FR + 7 + 2 * A, cs); if (lead) lab[3] = cs; }
             }
             if (lead) {
-                const float vdr[7] = {ld_fric - HOT(friction_offset), ld_mass, ld_com[0], ld_com[1], ld_com[2], ld_push[0], ld_push[1]};
-                putpv(std::integral_constant<int, 7>{}, FR, vdr);
-                if (M->state_link_mask & 1u) { const float cs = norm(f_base) > 1.f ? 1.f : 0.f; putp(FR + 7 + 2 * A, cs); lab[3] = cs; }
                 const float vl[3] = {blv.x * hc_obs_scale_lin_vel, blv.y * hc_obs_scale_lin_vel, blv.z * hc_obs_scale_lin_vel};
                 stv<3>(lab, vl);
             }
@@ -2348,8 +2398,14 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
 #pragma unroll
                     for (int k = 0; k < NV; k++) cn[k] = clampf(v[k], -cl, cl);
                     if (to_lab) stv<NV>(labp + idx0, cn);
+                    else if (FUSED) stv<NV>((sub == 0 ? pn : pn2) + idx0, cn);      // replica 0 / 1: this set's / the other set's critic frame
                     else { stv<NV>(pn + idx0, cn); if (has_pn2) stv<NV>(pn2 + idx0, cn); }
                 };
+                // who writes: the labels row replica 0; the critic frame replicas 0 and (second copy) 1; the heights block, the long one, is
+                // halved once more: replica r writes copy r & 1, entries with (i & 1) == r >> 1
+                const bool live = to_lab ? live_all && sub == 0 : (FUSED ? live_all && (sub == 0 || (sub == 1 && has_pn2)) : live_all);
+                const bool lead = live && leg == 0;
+                const bool liveh = (FUSED && !to_lab) ? live_all && ((sub & 1) == 0 || has_pn2) : live;
                 auto Wr = [&](int idx, float v) { WrV(std::integral_constant<int, 1>{}, idx, &v); };
                 constexpr std::integral_constant<int, 7> N7{};
                 constexpr std::integral_constant<int, 9> N9{};
@@ -2388,16 +2444,19 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                         }
                         if (lead && (M->state_link_mask & 1u)) Wr(off, norm(f_base) > 1.f ? 1.f : 0.f);
                     } else if (kind == LG_SEG_HEIGHTS) {
-                        if (live) {
-                            if (hreg) {
+                        if (hreg && liveh) {
+                            float *const hd = to_lab ? labp : ((FUSED && (sub & 1)) ? pn2 : pn);
 #pragma unroll
-                                for (int i = 0; i < HMAX; i++) {
-                                    const int k = leg + i * LEGS;
-                                    float hv = pos.z - hc_heights_offset - hts[i];
-                                    if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
-                                    if (k < P) Wr(off + k, hv);
-                                }
-                            } else {
+                            for (int i = 0; i < HMAX; i++) {
+                                const int k = leg + i * LEGS;
+                                float hv = pos.z - hc_heights_offset - hts[i];
+                                if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
+                                hv = clampf(hv, -cl, cl);
+                                if (k < P && (!FUSED || to_lab || (i & 1) == (sub >> 1))) { hd[off + k] = hv; if (!FUSED && !to_lab && has_pn2) pn2[off + k] = hv; }
+                            }
+                        }
+                        if (!hreg && live) {
+                            {
                                 for (int k = leg; k < P; k += LEGS) {
                                     float hv = pos.z - hc_heights_offset - B.measured_heights[(size_t)e * P + k];
                                     if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;

@@ -1668,8 +1668,10 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         // agent-scope fence here writes back the XCD's L2 from every wave: measured +29 us per launch.
         if (P > 0) __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
         __syncthreads();
-        if (threadIdx.x < 16)
-            env_step_body<LEGS, MPH, true, PROF>(p, sMraw, sHot, sStF, sX, blockIdx.x * 16 + (int)threadIdx.x, (int)threadIdx.x);
+        // the wave's 64 lanes run the leg-per-lane body as FOUR replicas of its 16 leg-lanes (lane = 16 replica + leg-lane): every replica
+        // computes the same values, replica 0 owns the state stores, and the observation section deals its stores over the replicas
+        // (the four destinations of an actor-frame entry, the two of a critic entry; blanking with 64 lanes)
+        env_step_body<LEGS, MPH, true, PROF>(p, sMraw, sHot, sStF, sX, blockIdx.x * 16 + ((int)threadIdx.x & 15), (int)threadIdx.x & 15);
     }
     STAMPB(12288);
 }
