@@ -2389,6 +2389,15 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             // auxiliary output are concatenations of the blocks of LgObsSeg at the offsets the task's programs give
             const int K = __popc(M->state_link_mask);
             const int l0 = foot_link - 3;
+            // block values that do not depend on the program, formed once (each HOT() is an LDS round trip)
+            const float vdr[7] = {ld_fric - HOT(friction_offset), ld_mass, ld_com[0], ld_com[1], ld_com[2], ld_push[0], ld_push[1]};
+            float vkp[JPL], vkd[JPL];
+            {
+                const float kpo = HOT(kp_offset), kdo = HOT(kd_offset);
+#pragma unroll
+                for (int j = 0; j < JPL; j++) { vkp[j] = ld_kp[j] - kpo; vkd[j] = ld_kd[j] - kdo; }
+            }
+            const unsigned slm = M->state_link_mask;
             // `which`: 0 = critic frame (priv_prog), 1 = auxiliary row (labels_prog); the program words come from LDS (PRG_I / PRG_F)
             auto run = [&](const int which, const bool to_lab) {
                 const float cl = PRG_I(which, 1) ? co : 3.0e38f;
@@ -2413,12 +2422,8 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 for (int s_ = 0; s_ < n_segs; s_++) {
                     const int kind = PRG_I(which, 2 + s_), off = PRG_I(which, 10 + s_);
                     const float sc = PRG_F(which, 18 + s_);
-                    const float vdr[7] = {ld_fric - HOT(friction_offset), ld_mass, ld_com[0], ld_com[1], ld_com[2], ld_push[0], ld_push[1]};
                     if (kind == LG_SEG_DR || kind == LG_SEG_KP || kind == LG_SEG_KD) {
                         if (live) {
-                            float vkp[JPL], vkd[JPL];
-#pragma unroll
-                            for (int j = 0; j < JPL; j++) { vkp[j] = ld_kp[j] - HOT(kp_offset); vkd[j] = ld_kd[j] - HOT(kd_offset); }
                             if (kind == LG_SEG_DR) { WrV(NJ, off + 7 + d0, vkp); WrV(NJ, off + 7 + A + d0, vkd); }
                             else {
                                 float vs[JPL];
@@ -2439,10 +2444,10 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
 #pragma unroll
                             for (int k = 0; k < 4; k++) {
                                 const int l = l0 + k;
-                                if ((M->state_link_mask >> l) & 1u) Wr(off + __popc(M->state_link_mask & ((1u << l) - 1u)), norm(f_link[k]) > 1.f ? 1.f : 0.f);
+                                if ((slm >> l) & 1u) Wr(off + __popc(slm & ((1u << l) - 1u)), norm(f_link[k]) > 1.f ? 1.f : 0.f);
                             }
                         }
-                        if (lead && (M->state_link_mask & 1u)) Wr(off, norm(f_base) > 1.f ? 1.f : 0.f);
+                        if (lead && (slm & 1u)) Wr(off, norm(f_base) > 1.f ? 1.f : 0.f);
                     } else if (kind == LG_SEG_HEIGHTS) {
                         if (hreg && liveh) {
                             float *const hd = to_lab ? labp : ((FUSED && (sub & 1)) ? pn2 : pn);

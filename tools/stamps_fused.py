@@ -18,7 +18,7 @@ for i in range(800):
         acc += env._engine.buf["episode_done_sums"].flatten()[:32].cpu(); n += 1
 acc /= n
 order = [(23, "quad: load burst + LDS staging"), (24, "quad: lane constants"), (12, "quad: rest of prologue"), (21, "4 sub-steps (to read-back)"), (22, "read-back + stores"),
-         (5, "mdp: start"), (6, "mdp: callback"), (7, "mdp: termination + rewards"), (9, "mdp: reset blk"), (10, "mdp: obs"), (11, "mdp: state stores")]
+         (5, "mdp: start"), (6, "mdp: callback"), (7, "mdp: termination + rewards"), (9, "mdp: reset blk"), (25, "mdp: obs pointers + blanking"), (26, "mdp: obs noise draws"), (27, "mdp: obs actor frame"), (10, "mdp: obs task blocks"), (11, "mdp: state stores")]
 prev = 0.0
 for k, name in order:
     print(f"{name:30s} +{acc[k]-prev:8.0f} cycles (cum {acc[k]:8.0f})")
