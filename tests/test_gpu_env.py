@@ -75,7 +75,7 @@ def _go2_all_terms_cfg():
     return cfg
 
 
-@pytest.mark.parametrize("task", ["go2", "go2-push", "go2-allterms", "go2-yawcmd", "go2_wtw", "go2_ee"])
+@pytest.mark.parametrize("task", ["go2", "go2-push", "go2-allterms", "go2-yawcmd", "go2_wtw", "go2_ee", "go2_ts", "tron1_pf_ee", "tron1_pf", "tron1_sf"])
 def test_fused_launch_equals_split_launches(task):
     """Same state in, one control step through (a) the fused launch -- the instantiation bench.py times,
     quad_sim_kernel<4, true, POST|RESET> with the MDP phases in its tail -- and (b) SIM, then PRE|POST|RESET in
@@ -83,8 +83,10 @@ def test_fused_launch_equals_split_launches(task):
     identical integers, floats to 1e-5 (the template instantiations may contract FMAs differently; contact dynamics
     would amplify that over many steps, so states are re-synced every step).  Every quadruped task that uses the fused
     tail is covered: go2 (45-wide frame; its fused launch is the FLAT instantiation whose MDP phases run in component
-    layout on all 64 lanes, lg_quad.h), go2_wtw (gait state, 5-frame stacks, PD-gain DR), go2_ee (heightfield sampling handed
-    over through measured_heights, 20 / 5-frame stacks, labels)."""
+    layout on all 64 lanes, lg_quad.h), go2_wtw (the same kind of tail: gait state, 5-frame stacks, PD-gain DR), go2_ee and go2_ts
+    (heightfield sampling handed over through measured_heights, 20 / 5-frame stacks, labels / observation programs; the tail runs as four
+    replicas of its leg-lanes).  For the bipeds path (a) is what their env.step() issues -- component-per-lane physics launch, then the
+    leg-per-lane MDP launch (tron1_sf: four-joint legs in both)."""
     import torch
     from hcr_genesis_lr_cl_amd import abi
     from hcr_genesis_lr_cl_amd.envs import make_env
@@ -119,7 +121,7 @@ def test_fused_launch_equals_split_launches(task):
         for k in e1._engine.buf.keys():
             e2._engine.buf.raw(k).copy_(e1._engine.buf.raw(k))
         e2.common_step_counter = e1.common_step_counter
-        act = torch.randn(N, 12, generator=g, device="cuda") * (1.0 if t % 5 else 4.0)
+        act = torch.randn(N, e1.num_actions, generator=g, device="cuda") * (1.0 if t % 5 else 4.0)
         e1.step(act)
         e2.common_step_counter += 1
         ca = float(e2.cfg.normalization.clip_actions)
