@@ -274,7 +274,7 @@ def launcher_dry_run(args, world, rank):
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
     n_local, widths = 32, [5, 3]
-    gather = StepGather(n_local, widths, world, "cpu", overlap=not args.sync_gather) if world > 1 else None
+    gather = StepGather(n_local, widths, world, "cpu", overlap=not args.sync_gather, batch=args.gather_batch) if world > 1 else None
     obs = [torch.full((n_local, w), float(rank)) for w in widths]
     rew, done = torch.full((n_local,), 0.5 + rank), torch.zeros(n_local, dtype=torch.bool)
     done[rank] = True
@@ -293,10 +293,10 @@ def launcher_dry_run(args, world, rank):
         t = torch.tensor([elapsed], dtype=torch.float64)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-        parts, r, d = gather.split(out)
+        last = (args.steps - 1) % gather.batch               # slot of the last step inside its batch
         for k in range(world):
-            sl = slice(k * n_local, (k + 1) * n_local)
-            ok &= all(bool((p_[sl] == k).all()) for p_ in parts) and bool((r[sl] == 0.5 + k).all()) and int(d[sl].sum()) == 1 and bool(d[k * n_local + k])
+            parts, r, d = gather.split(gather.step_view(out, k, last))
+            ok &= all(bool((p_ == k).all()) for p_ in parts) and bool((r == 0.5 + k).all()) and int(d.sum()) == 1 and bool(d[k])
     if rank == 0:
         print(json.dumps({"metric": "launcher dry run", "value": n_local * world * args.steps / max(elapsed, 1e-9), "unit": "records/s",
                           "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "gather_ok": bool(ok), "data": "synthetic"}), flush=True)
@@ -311,7 +311,10 @@ def main():
     ap.add_argument("--steps", type=int, default=2000)
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
-    ap.add_argument("--no-gather", action="store_true", help="skip the per-step RCCL all-gather at N>1")
+    ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of the step outputs at N>1")
+    ap.add_argument("--gather-batch", type=int, default=8, metavar="K",
+                    help="control steps per all-gather at N>1 (default 8: one ~43 MB message per 8 steps at 8 ranks instead of eight "
+                         "latency-bound 5 MB ones; 1 = one collective per step)")
     ap.add_argument("--sync-gather", action="store_true",
                     help="wait for each step's all-gather before the next step (default: it overlaps the next step, double-buffered)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -372,7 +375,7 @@ def main():
     def obs_outputs(out):      # every observation tensor step() returns: 5-tuple (obs, priv) or 6-tuple (features, labels, critic)
         return [o for o in out[:-3] if o is not None]
     widths = [int(o.shape[1]) for o in obs_outputs(env.step(bank[0]))]
-    gather = StepGather(n_local, widths, world, dev, overlap=not args.sync_gather) if world > 1 and not args.no_gather else None
+    gather = StepGather(n_local, widths, world, dev, overlap=not args.sync_gather, batch=args.gather_batch) if world > 1 and not args.no_gather else None
 
     def one_step(i):
         out = env.step(bank[i % len(bank)])
@@ -429,7 +432,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{WORKLOADS[args.task]}, {n_local} envs per GPU, fused LeggedRobot.step "
                                    f"(4 sub-steps dt=0.005) with synthetic N(0,1) actions",
-                       "envs_total": total_envs, "parallelism": f"env-shard x{world}" + (" [gloo rehearsal, ranks may share a GPU]" if world > 1 and args.backend == "gloo" else "") + ((" + all-gather(obs,rew,done) per step" + ("" if args.sync_gather else ", overlapped with the next step")) if world > 1 and not args.no_gather else "")},
+                       "envs_total": total_envs, "parallelism": f"env-shard x{world}" + (" [gloo rehearsal, ranks may share a GPU]" if world > 1 and args.backend == "gloo" else "") + ((f" + all-gather(obs,rew,done) of every step, {args.gather_batch} steps per collective" + ("" if args.sync_gather else ", overlapped with the following steps")) if world > 1 and not args.no_gather else "")},
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": hbm_traffic(wkey),
                          "kernel": layout, "launch_us": launch_s * 1e6, "samples": kern_n,

@@ -34,6 +34,18 @@ def _worker(rank, world, port, q):
     full = torch.arange(64, dtype=torch.float32)
     assert torch.allclose(outs[2][:, 5], full * 4) and torch.allclose(outs[1][:, 5], full * 3)
     assert torch.allclose(outs[2][:, 0], full + 2)
+    # several steps per collective: 7 steps in batches of 3 (the last one partly filled and flushed by finish()), overlapped
+    g3 = StepGather(n, 5, world, "cpu", overlap=True, batch=3)
+    outs3 = [g3(obs + k, ids * (2 + k), (ids % 3 == 0).float()) for k in range(7)]
+    g3.finish()
+    for k, slot in ((3, 0), (5, 2), (6, 0)):
+        for rk in range(world):
+            o_k, n_k = shard(64, world, rk)
+            rec = g3.step_view(outs3[k], rk, slot)
+            ids_k = torch.arange(o_k, o_k + n_k, dtype=torch.float32)
+            assert torch.allclose(rec[:, 5], ids_k * (2 + k)) and torch.allclose(rec[:, 0], ids_k + k), (k, rk)
+    (p3,), r3, d3 = g3.split(g3.step_view(outs3[5], 1, 2))
+    assert p3.shape == (n, 5) and d3.dtype == torch.bool
     q.put((rank, o.numpy().copy(), r.numpy().copy(), d.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
