@@ -214,6 +214,9 @@ def valu_roofline(workload_key, launch_s):
             "wait_frac": _profile_json("sq_counters.json", workload_key, "wait_share")}
 
 
+_REAL_STDOUT = sys.stdout      # main() swaps in a private copy of fd 1 and points fd 1 at stderr (see there)
+
+
 def spawn_ranks(n):
     """`python bench.py --gpus N` from a plain shell: start N ranks (one per GPU) with torch.distributed.run as a CHILD process
     -- this process has not touched the GPU (torch is not even imported yet) -- and pass its exit code on.  Rank 0 of the
@@ -299,7 +302,7 @@ def launcher_dry_run(args, world, rank):
             ok &= all(bool((p_ == k).all()) for p_ in parts) and bool((r == 0.5 + k).all()) and int(d.sum()) == 1 and bool(d[k])
     if rank == 0:
         print(json.dumps({"metric": "launcher dry run", "value": n_local * world * args.steps / max(elapsed, 1e-9), "unit": "records/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "gather_ok": bool(ok), "data": "synthetic"}), flush=True)
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "gather_ok": bool(ok), "data": "synthetic"}), file=_REAL_STDOUT, flush=True)
     if world > 1:
         dist.destroy_process_group()
     return 0 if ok else 1
@@ -341,6 +344,12 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"bench.py: --gpus {args.gpus} but the launcher started {world} rank(s); pass --gpus {world} or run "
                          f"`python bench.py --gpus {args.gpus}` from a plain shell (it spawns the ranks itself)")
+    # stdout carries ONE JSON line and nothing else: whatever native libraries write to file descriptor 1 while the run lasts (gloo's
+    # connection banner, RCCL / ROCm notices) goes to stderr; the line itself is written to the real stdout at the end
+    global _REAL_STDOUT
+    sys.stdout.flush()
+    _REAL_STDOUT = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
     if args.launcher_dry_run:
         return launcher_dry_run(args, world, rank)
 
@@ -446,7 +455,7 @@ def main():
             out["ppo_rollout"] = ppo_rollout(args.task, n_local, args.ppo_rollout, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline()
-        print(json.dumps(out), flush=True)
+        print(json.dumps(out), file=_REAL_STDOUT, flush=True)
     if dist is not None:
         dist.destroy_process_group()
 
