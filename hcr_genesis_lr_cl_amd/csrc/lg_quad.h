@@ -432,8 +432,10 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     // (env_step_body<.., FUSED>) reads it back after the physics instead of paying the round trips then.  Layout = the
     // stash of env_step_body (NST values x 16 lanes).
     constexpr int NST = LG_R_COUNT + 36;
-    constexpr bool QTAIL = (FLAT || PROF == 2) && MPH == (LG_PHASE_POST | LG_PHASE_RESET);   // MDP phases in component layout on all 64 lanes (below)
+    constexpr bool QTAIL = (FLAT || PROF == 2 || PROF == 3) && MPH == (LG_PHASE_POST | LG_PHASE_RESET);   // MDP phases in component layout on all 64 lanes (below)
     constexpr bool WQ = PROF == 2 && QTAIL;   // ... of the go2_wtw task: gait clock, behaviour targets, 61 x 5 | 99 x 5 observation stacks
+    constexpr bool EQ = PROF == 3 && QTAIL;   // ... of the go2_ee task: heightfield, terrain curriculum, 45 x 20 | (45 + 31 + K + P) x 5 stacks, labels
+    constexpr bool SQ = WQ || EQ;             // stacked observations, PD-gain randomisation, root twist draws
     __shared__ float sStF[(MPH != 0 && !QTAIL) ? NST * 16 : 1];
     float wsv[(MPH != 0 && !QTAIL) ? NST : 1];
     // QTAIL working set, one value per lane: command component c, the two episode sums this lane owns (terms ei and ei + 16 of its
@@ -457,13 +459,19 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     // go2_wtw: gait clock and behaviour targets (per-env scalars replicated, per-foot entries by leg), the latest push, the deferred-
     // blanking flag of the observation stacks
     float w_gt = 0.f, w_phi = 0.f, w_gp = 1.f, w_bh = 0.f, w_fc = 0.f, w_pt = 0.f, w_th = 0.f, w_ec = 0.f, w_push = 0.f;
-    int w_dirty = 0;
+    int w_dirty = 0, w_lvl = 0, w_type = 0;
     if (WQ) {
         const float GAS *ts = KB(const float GAS *, task_state) + (size_t)e * LG_TASK_STATE_WTW;
         w_gt = ts[0]; w_phi = ts[1]; w_gp = ts[2]; w_bh = ts[3]; w_fc = ts[4]; w_pt = ts[5];
         w_th = ts[6 + foot_slot]; w_ec = ts[18 + foot_slot];
+    }
+    if (SQ) {
         w_push = KB(const float GAS *, rand_push_vels)[3 * e + cj];
         if (k_obs_dirty) w_dirty = (int)k_obs_dirty[e];
+    }
+    if (EQ) {   // go2_ee: terrain level / type of the env (curriculum at reset)
+        const int32_t GAS *tl = KB(const int32_t GAS *, terrain_levels), *tt = KB(const int32_t GAS *, terrain_types);
+        if (tl) { w_lvl = tl[e]; w_type = tt[e]; }
     }
     if (MPH != 0 && !QTAIL && threadIdx.x < 16) {
         const LgTaskCfg GAS *T = kT;
@@ -1055,12 +1063,16 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
 
     // ---------------- terrain sampling around the base and the feet (genesis_simulator.py:552-610) ------
     const int P = PLANE ? 0 : HOT(o_n_height_points);
+    constexpr int HQ = 7;                        // samples per lane held in flight (go2: 81 / 16 lanes, tron1: 49 / 8)
+    const int kstride = 4 * LEGS, hk0 = leg * 4 + L.c;   // this lane's terrain samples: k = hk0 + i kstride
+    float hq[HQ];                                // this lane's samples (k = k0 + i kstride), kept for the go2_ee tail
+    float f_hmean = 0.f, f_hmax = 0.f;           // mean / max of the nine heights around this leg's foot
+#pragma unroll
+    for (int i = 0; i < HQ; i++) hq[i] = 0.f;
     if (P > 0) {
         const float yn = rcp(fmaxf(fsqrt(qz * qz + qw * qw), 1e-9f));
         const float yz = qz * yn, yw = qw * yn;
         const float px = bc<0>(pos), py = bc<1>(pos);
-        constexpr int HQ = 7;                    // samples per lane held in flight (go2: 81 / 16 lanes, tron1: 49 / 8)
-        const int kstride = 4 * LEGS, k0 = leg * 4 + L.c;
         if (P <= HQ * kstride) {
             // all of this lane's samples at once: points, then the 3 x HQ height loads, then the minima -- instead of one
             // exposed load round trip per sample
@@ -1068,7 +1080,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const int TRr = HOT(o_terrain_rows), TCc = HOT(o_terrain_cols);
             float vx[HQ], vy[HQ];
 #pragma unroll
-            for (int i = 0; i < HQ; i++) { const int kc = min(k0 + i * kstride, P - 1); vx[i] = B.height_points[2 * kc]; vy[i] = B.height_points[2 * kc + 1]; }
+            for (int i = 0; i < HQ; i++) { const int kc = min(hk0 + i * kstride, P - 1); vx[i] = B.height_points[2 * kc]; vy[i] = B.height_points[2 * kc + 1]; }
             int h1[HQ], h2[HQ], h3[HQ];
 #pragma unroll
             for (int i = 0; i < HQ; i++) {
@@ -1083,11 +1095,12 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             }
 #pragma unroll
             for (int i = 0; i < HQ; i++) {
-                const int k = k0 + i * kstride;
-                if (live && k < P) B.measured_heights[(size_t)e * P + k] = (float)min(min(h1[i], h2[i]), h3[i]) * vs;
+                const int k = hk0 + i * kstride;
+                hq[i] = (float)min(min(h1[i], h2[i]), h3[i]) * vs;
+                if (live && k < P) B.measured_heights[(size_t)e * P + k] = hq[i];
             }
         } else {
-            for (int k = k0; k < P; k += kstride) {
+            for (int k = hk0; k < P; k += kstride) {
                 const float vx = B.height_points[2 * k], vy = B.height_points[2 * k + 1];
                 const float tx = -2.f * yz * vy, ty = 2.f * yz * vx;
                 const float rx = vx + yw * tx - yz * ty, ry = vy + yw * ty + yz * tx;
@@ -1105,6 +1118,12 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             // order of genesis_simulator.py:591-599
             const int hh[9] = {hf[xm * Cc + gy], hf[(gx + 1) * Cc + gy], hf[gx * Cc + ym], hf[gx * Cc + gy + 1], hf[gx * Cc + gy],
                                hf[xm * Cc + ym], hf[(gx + 1) * Cc + gy + 1], hf[xm * Cc + gy + 1], hf[(gx + 1) * Cc + ym]};
+            {
+                float sm = 0.f, mx = -1e30f;
+#pragma unroll
+                for (int k = 0; k < 9; k++) { const float hv = (float)hh[k] * HOT(o_vscale); sm += hv; mx = fmaxf(mx, hv); }
+                f_hmean = sm / 9.f; f_hmax = mx;
+            }
             if (live && L.is0) {
 #pragma unroll
                 for (int k = 0; k < 9; k++) B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k] = (float)hh[k] * HOT(o_vscale);
@@ -1205,22 +1224,41 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         const auto h_behavior_resample_steps = WQ ? HOT(behavior_resample_steps) : 0;
         const auto h_slots_task_cb = WQ ? HOT(slots.task_cb) : 0;
         const auto h_slots_task_reset = WQ ? HOT(slots.task_reset) : 0;
-        const auto h_slots_dr_kp = WQ ? HOT(slots.dr_kp) : 0;
-        const auto h_slots_dr_kd = WQ ? HOT(slots.dr_kd) : 0;
-        const auto h_dr_pd_on = WQ ? HOT(dr_pd_on) : 0;
-        const auto h_dr_kp_lo = WQ ? HOT(dr_kp_lo) : 0.f;
-        const auto h_dr_kp_span = WQ ? HOT(dr_kp_span) : 0.f;
-        const auto h_dr_kd_lo = WQ ? HOT(dr_kd_lo) : 0.f;
-        const auto h_dr_kd_span = WQ ? HOT(dr_kd_span) : 0.f;
-        const auto h_reset_lin_vel_span = WQ ? HOT(reset_lin_vel_span) : 0.f;
-        const auto h_reset_ang_vel_span = WQ ? HOT(reset_ang_vel_span) : 0.f;
-        const auto h_obs_frame = WQ ? HOT(obs_frame) : 0;
-        const auto h_priv_frame = WQ ? HOT(priv_frame) : 0;
-        const auto h_obs_stack = WQ ? HOT(obs_stack) : 1;
-        const auto h_priv_stack = WQ ? HOT(priv_stack) : 1;
-        const auto h_obs_slack = WQ ? HOT(obs_slack) : 0;
-        const auto h_num_obs = WQ ? HOT(num_obs) : 0;
-        const auto h_num_priv_obs = WQ ? HOT(num_priv_obs) : 0;
+        const auto h_slots_dr_kp = SQ ? HOT(slots.dr_kp) : 0;
+        const auto h_slots_dr_kd = SQ ? HOT(slots.dr_kd) : 0;
+        const auto h_dr_pd_on = SQ ? HOT(dr_pd_on) : 0;
+        const auto h_dr_kp_lo = SQ ? HOT(dr_kp_lo) : 0.f;
+        const auto h_dr_kp_span = SQ ? HOT(dr_kp_span) : 0.f;
+        const auto h_dr_kd_lo = SQ ? HOT(dr_kd_lo) : 0.f;
+        const auto h_dr_kd_span = SQ ? HOT(dr_kd_span) : 0.f;
+        const auto h_reset_lin_vel_span = SQ ? HOT(reset_lin_vel_span) : 0.f;
+        const auto h_reset_ang_vel_span = SQ ? HOT(reset_ang_vel_span) : 0.f;
+        const auto h_obs_frame = SQ ? HOT(obs_frame) : 0;
+        const auto h_priv_frame = SQ ? HOT(priv_frame) : 0;
+        const auto h_obs_stack = SQ ? HOT(obs_stack) : 1;
+        const auto h_priv_stack = SQ ? HOT(priv_stack) : 1;
+        const auto h_obs_slack = SQ ? HOT(obs_slack) : 0;
+        const auto h_num_obs = SQ ? HOT(num_obs) : 0;
+        const auto h_num_priv_obs = SQ ? HOT(num_priv_obs) : 0;
+        // go2_ee only
+        const auto h_terrain_curriculum = EQ ? HOT(terrain_curriculum) : 0;
+        const auto h_max_terrain_level = EQ ? HOT(max_terrain_level) : 1;
+        const auto h_terrain_cols_n = EQ ? HOT(terrain_cols_n) : 1;
+        const auto h_terrain_env_length = EQ ? HOT(terrain_env_length) : 0.f;
+        const auto h_episode_length_s = EQ ? HOT(episode_length_s) : 0.f;
+        const auto h_slots_reset_root_xy = EQ ? HOT(slots.reset_root_xy) : 0;
+        const auto h_slots_terrain_level = EQ ? HOT(slots.terrain_level) : 0;
+        const auto h_reset_root_xy_lo = EQ ? HOT(reset_root_xy_lo) : 0.f;
+        const auto h_reset_root_xy_span = EQ ? HOT(reset_root_xy_span) : 0.f;
+        const auto h_custom_origins = EQ ? HOT(custom_origins) : 0;
+        const auto h_heights_offset = EQ ? HOT(heights_offset) : 0.f;
+        const auto h_heights_clip_scale = EQ ? HOT(heights_clip_scale) : 0;
+        const auto h_obs_scale_height = EQ ? HOT(obs_scale_height) : 1.f;
+        const auto h_num_labels = EQ ? HOT(num_labels) : 0;
+        const auto h_foot_clearance_ref = EQ ? HOT(foot_clearance_ref) : 0;
+        const auto h_friction_offset = EQ ? HOT(friction_offset) : 0.f;
+        const auto h_kp_offset = EQ ? HOT(kp_offset) : 0.f;
+        const auto h_kd_offset = EQ ? HOT(kd_offset) : 0.f;
         asm volatile("" ::: "memory");
         const float cdt = h_control_dt;
         const unsigned rmask = (unsigned)p.k.reward_mask;
@@ -1386,7 +1424,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         if (RON(LG_R_FOOT_ACC)) { const float a = (foot_v - last_foot_v) * (1.f / cdt); add(LG_R_FOOT_ACC, legsum<LEGS>(vnorm2(a))); }    // :605-608
         if (RON(LG_R_FOOT_CLEARANCE)) {                                                                                          // :575-588
             const float vxy = sqrtf(fvx * fvx + fvy * fvy);
-            const float d = fpz - 0.f - h_foot_clearance_target - h_foot_height_offset;
+            const float d = fpz - (h_foot_clearance_ref == 1 ? f_hmean : (h_foot_clearance_ref == 2 ? f_hmax : 0.f)) - h_foot_clearance_target - h_foot_height_offset;
             add(LG_R_FOOT_CLEARANCE, __expf(-legsum<LEGS>(vxy * (d * d)) / h_foot_clearance_sigma));
         }
         if (RON(LG_R_FOOT_LANDING_VEL)) {                                                                                        // :590-599
@@ -1449,7 +1487,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             // env-level uniforms (block 0x200 + leg sits in quad `leg`): the element each lane needs is fetched from the quad that
             // holds it: v0 = (cmd u0 u1 u2 | friction), v1 = (CoM xyz | mass), v2 / v3 = root twist (slots of env_step_body's eu[])
             const float v0 = fetch(rc, L.c), v1 = fetch(rc, 4 + L.c);
-            const float v2 = WQ ? fetch(rc, 8 + L.c) : 0.f, v3 = WQ ? fetch(rc, 12 + L.c) : 0.f;   // root twist draws (slots 8-10, 12-14)
+            const float v2 = SQ ? fetch(rc, 8 + L.c) : 0.f, v3 = SQ ? fetch(rc, 12 + L.c) : 0.f;   // root twist draws (slots 8-10, 12-14)
             // go2_wtw: ONE more call for what only a reset of this task draws -- lane 0 / 1: the leg's kp / kd blocks
             // (genesis_simulator.py:735-739), lanes 2 / 3 of quads 0 and 1: the four behaviour parameters' draws, lane 2 of quad 2: the
             // gait draw with the env-independent counter (go2_wtw.py:124-142, 180-218)
@@ -1468,8 +1506,40 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 // parameter c was drawn in lane 2 + (c & 1) of quad c >> 1; the gait draw in lane 2 of quad 2
                 behavior_apply(fetch(ub, (L.c < 2 ? 2 : 4) + L.c), fetch(ub, 10), reset);
             }
+            // go2_ee: ONE more call likewise -- lane 0 / 1: the leg's kp / kd blocks, lanes 2 / 3 of quad 0: the root xy draws
+            // (legged_robot.py:288), lane 2 of quad 1: the terrain-level draw (legged_robot.py:266-268)
+            float u_xy = 0.5f, u_tl = 0.f;
+            if constexpr (EQ) {
+                const int sb = leg == 0 ? h_slots_reset_root_xy + (L.c - 2) : h_slots_terrain_level;
+                const unsigned c3 = L.is0 ? 0x40000000u + (unsigned)(h_slots_dr_kp + d0)
+                                          : (L.is1 ? 0x40000000u + (unsigned)(h_slots_dr_kd + d0) : (unsigned)(sb >> 2));
+                const U4 rB = philox(c3);
+                const float bx = u01(rB.x), by = u01(rB.y), bz = u01(rB.z);
+                nkp = h_dr_kp_span * L.sel(bc<0>(bx), bc<0>(by), bc<0>(bz)) + h_dr_kp_lo;
+                nkd = h_dr_kd_span * L.sel(bc<1>(bx), bc<1>(by), bc<1>(bz)) + h_dr_kd_lo;
+                const float ub = u01(pick(rB, sb & 3));          // valid in lanes 2 / 3
+                u_xy = fetch(ub, 2 + (L.c & 1));                 // x / y draw for components 0 / 1 (quad 0, lanes 2 / 3)
+                u_tl = fetch(ub, 6);                             // quad 1, lane 2
+            }
+            // terrain curriculum (legged_robot.py:254-272 + genesis_simulator.py:140-148; skipped on the construction-time reset, where
+            // the reference returns early because init_done is False)
+            float norg = origin;
+            int nlvl = w_lvl;
+            if (EQ && h_terrain_curriculum && p.counter > 0) {
+                const float dd = pos - origin;
+                const float dx = bc<0>(dd), dy = bc<1>(dd);
+                const float dist = sqrtf(dx * dx + dy * dy);
+                const bool up = dist > h_terrain_env_length / 2.f;
+                const bool down = (dist < sqrtf(cmd0 * cmd0 + cmd1 * cmd1) * h_episode_length_s * 0.5f) && !up;
+                int lvl = w_lvl + (up ? 1 : 0) - (down ? 1 : 0);
+                if (lvl >= h_max_terrain_level) lvl = min((int)floorf(u_tl * (float)h_max_terrain_level), h_max_terrain_level - 1);
+                else lvl = max(lvl, 0);
+                nlvl = lvl;
+                norg = B.terrain_origins[((size_t)lvl * h_terrain_cols_n + w_type) * 3 + cj];
+            }
             const float ncmd = resample(cmdv, bc<0>(v0), bc<1>(v0), bc<2>(v0));
-            const float ipos = L.sel(h_o_base_init_pos_0, h_o_base_init_pos_1, h_o_base_init_pos_2) + origin;
+            float ipos = L.sel(h_o_base_init_pos_0, h_o_base_init_pos_1, h_o_base_init_pos_2) + (EQ ? norg : origin);
+            if (EQ && h_custom_origins && L.c < 2) ipos += h_reset_root_xy_span * u_xy + h_reset_root_xy_lo;      // legged_robot.py:288
             const float iq = L.is3 ? h_base_init_quat_3 : L.sel(h_base_init_quat_0, h_base_init_quat_1, h_base_init_quat_2);
             // go2.py:131-133 draws U(0, 0) (flat_profile: zero spans); go2_wtw: legged_robot.py:289-292
             const float nvw = h_reset_lin_vel_span * v2 + h_reset_lin_vel_lo, nww = h_reset_ang_vel_span * v3 + h_reset_ang_vel_lo;
@@ -1478,7 +1548,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const float ncom = L.sel(h_dr_com_span_0, h_dr_com_span_1, h_dr_com_span_2) * v1 + L.sel(h_dr_com_lo_0, h_dr_com_lo_1, h_dr_com_lo_2);
             if (reset) {
                 if (WQ) { gait_time = 0.f; phi = 0.f; }
-                if (WQ && h_dr_pd_on) { o_kp = nkp; o_kd = nkd; }
+                if (SQ && h_dr_pd_on) { o_kp = nkp; o_kd = nkd; }
                 if (h_dr_friction_on) o_fric = nfric;
                 if (h_dr_mass_on) o_mass = nmass;
                 if (h_dr_com_on) o_com = ncom;
@@ -1496,7 +1566,8 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             if (reset && st) {
                 B.dof_pos[ja] = q; B.dof_vel[ja] = 0.f; B.last_dof_vel[ja] = 0.f;
                 B.actions[ja] = 0.f; B.last_actions[ja] = 0.f; B.llast_actions[ja] = 0.f;
-                if (WQ && h_dr_pd_on) { B.kp_scale[ja] = o_kp; B.kd_scale[ja] = o_kd; }
+                if (SQ && h_dr_pd_on) { B.kp_scale[ja] = o_kp; B.kd_scale[ja] = o_kd; }
+                if (EQ && h_terrain_curriculum && p.counter > 0 && leg == 0) { B.env_origins[3 * e + cj] = norg; if (L.is0) B.terrain_levels[e] = nlvl; }
                 B.last_feet_vel[(e * F + foot_slot) * 3 + cj] = 0.f;
                 if (leg == 0) {
                     B.base_pos[3 * e + cj] = pos; B.base_lin_vel_w[3 * e + cj] = vw; B.base_ang_vel_w[3 * e + cj] = ww;
@@ -1520,7 +1591,90 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             }
         }
         STAMP(9);
-        if constexpr (WQ) {
+        if constexpr (EQ) {
+            // ---- compute_observations + clip, go2_ee.py:10-75: actor frame = go2's 45, stacked 20 deep; critic frame = the frame without
+            //      noise | DR 31 (friction - offset, mass, CoM 3, push 2, kp - offset 12, kd - offset 12) | contact states K | heights P,
+            //      stacked 5 deep; labels = v_b 3 | contact states K | foot height above the local terrain mean F.  Same window / copy /
+            //      blanking bookkeeping as the go2_wtw block below; the env's 16 lanes write consecutive columns, every lane the terrain
+            //      samples it took itself.
+            const float co = h_clip_obs;
+            const bool nz = h_add_noise != 0;
+            const int FR = h_obs_frame, PF = h_priv_frame, ST = h_obs_stack, PST = h_priv_stack, SL = h_obs_slack;
+            const size_t orow = (size_t)(h_num_obs + SL * FR), prow = (size_t)(h_num_priv_obs + SL * PF);
+            const bool two = h_obs_sets > 1;
+            const int cs = two ? p.obs_set : 0, xs = two ? 1 - cs : 0;
+            float *oc = B.obs_buf + ((size_t)cs * N + e) * orow + (size_t)p.obs_win * FR;
+            float *ox = B.obs_buf + ((size_t)xs * N + e) * orow + (size_t)p.obs_win * FR;
+            float *pc = B.priv_obs_buf + ((size_t)cs * N + e) * prow + (size_t)p.obs_win * PF;
+            float *px = B.priv_obs_buf + ((size_t)xs * N + e) * prow + (size_t)p.obs_win * PF;
+            float *lab = B.labels_buf + ((size_t)cs * N + e) * h_num_labels;
+            if (anyl(reset)) {                         // legged_robot_ee.py: the histories of a reset env restart from zeros
+                if (reset && live) {
+                    for (int i = ei; i < (ST - 1) * FR; i += 16) oc[i] = 0.f;
+                    for (int i = ei; i < (PST - 1) * PF; i += 16) pc[i] = 0.f;
+                }
+            }
+            if (two && anyl(!reset && w_dirty != 0)) {
+                if (!reset && w_dirty != 0 && live) {
+                    for (int i = ei; i < (ST - 2) * FR; i += 16) oc[i] = 0.f;
+                    for (int i = ei; i < (PST - 2) * PF; i += 16) pc[i] = 0.f;
+                }
+            }
+            float *on = oc + (ST - 1) * FR, *on2 = ox + (ST - 1) * FR, *pn = pc + (PST - 1) * PF, *pn2 = px + (PST - 1) * PF;
+            const bool w2o = two && ST > 1, w2p = two && PST > 1;
+            float uq = 0.5f, uqd = 0.5f, ug = 0.5f, ua = 0.5f;
+            if (nz) {
+                const float ux = rux, uy = ruy, uz = ruz, uw = ruw;   // lanes 0 / 1 hold blocks 2 leg / 2 leg + 1 (shared call above)
+                uq = L.sel(bc<0>(ux), bc<0>(uy), bc<0>(uz));
+                uqd = L.sel(bc<1>(ux), bc<1>(uy), bc<1>(uz));
+                ug = fetch(uw, 4 * (cj >> 1) + (cj & 1));
+                ua = fetch(uw, 4 * ((3 + cj) >> 1) + ((3 + cj) & 1));
+            }
+            auto W = [&](int idx, float v, float u, float ns) {
+                const float cl = clampf(v, -co, co);
+                const float nv = clampf(nz ? v + (2.f * u - 1.f) * ns : v, -co, co);
+                on[idx] = nv; if (w2o) on2[idx] = nv;
+                pn[idx] = cl; if (w2p) pn2[idx] = cl;
+            };
+            auto WP = [&](int idx, float v) { const float cl = clampf(v, -co, co); pn[idx] = cl; if (w2p) pn2[idx] = cl; };
+            // quad broadcasts outside the divergent branches
+            const float env4 = L.sel4(o_fric - h_friction_offset, o_mass, bc<0>(o_push), bc<1>(o_push));
+            const float pzn = bc<2>(pos);
+            const unsigned smask = M->state_link_mask;
+            const int K = __popc(smask);
+            const float csv = (L.sel4(n2[0], n2[1], n2[2], n2[3]) > 1.f) ? 1.f : 0.f;     // contact state of link l0 + c (physics read-back, stale after a reset as in the reference)
+            const int cl_ = l0 + L.c;
+            const bool chas = ((smask >> cl_) & 1u) != 0;
+            const int cidx = __popc(smask & ((1u << cl_) - 1u));
+            if (st) {
+                W(9 + d0 + cj, (q - q0) * h_obs_scale_dof_pos, uq, m_nq);
+                W(9 + A + d0 + cj, qd * h_obs_scale_dof_vel, uqd, m_nqd);
+                W(9 + 2 * A + d0 + cj, act, 0.5f, 0.f);
+                WP(FR + 7 + d0 + cj, o_kp - h_kp_offset);
+                WP(FR + 7 + A + d0 + cj, o_kd - h_kd_offset);
+                if (leg == 0) {
+                    W(cj, cmdv * (L.is2 ? h_obs_scale_ang_vel : h_obs_scale_lin_vel), 0.5f, 0.f);
+                    W(3 + cj, pg, ug, L.sel(h_noise_lead_0, h_noise_lead_1, h_noise_lead_2));
+                    W(6 + cj, bav * h_obs_scale_ang_vel, ua, L.sel(h_noise_lead_3, h_noise_lead_4, h_noise_lead_5));
+                    lab[cj] = blv * h_obs_scale_lin_vel;
+                }
+                if (leg == 2) WP(FR + 2 + cj, o_com);
+                if (L.is0) lab[3 + K + foot_slot] = clampf(fpz - f_hmean - h_foot_height_offset, -1.f, 1.f);
+            }
+            if (live) {
+                if (leg == 1) WP(FR + (L.c < 2 ? L.c : 3 + L.c), env4);                 // friction, mass | push x, y at FR + 5, 6
+                if (chas) { WP(FR + 7 + 2 * A + cidx, csv); lab[3 + cidx] = csv; }
+                if (leg == 0 && L.is3 && (smask & 1u)) { const float cb = nb2 > 1.f ? 1.f : 0.f; WP(FR + 7 + 2 * A, cb); lab[3] = cb; }
+#pragma unroll
+                for (int i = 0; i < HQ; i++) {
+                    const int k = hk0 + i * kstride;
+                    float hv = pzn - h_heights_offset - hq[i];
+                    if (h_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * h_obs_scale_height;
+                    if (k < P) WP(FR + 7 + 2 * A + K + k, hv);
+                }
+                if (leg == 0 && L.is0 && B.obs_dirty) B.obs_dirty[e] = reset ? 1 : 0;
+            }
+        } else if constexpr (WQ) {
             // ---- compute_observations + clip, go2_wtw.py:53-111: actor frame 61 = go2's 45 | clock sin 4, cos 4 | gait period, base-height,
             //      clearance, pitch targets | theta 4; critic frame 99 = the frame without noise | v_b 3, push 2, mass, friction, CoM 3 |
             //      kp 12 | kd 12 | exp_C_frc 4.  Five-frame stacks as sliding windows over rows with slack, in `obs_sets` copies: the new
