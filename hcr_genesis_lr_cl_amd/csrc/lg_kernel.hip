@@ -2748,21 +2748,27 @@ static int rough_profile(const LgEngine *h) {
     if (t.gait_mode != 0 || t.sit_percent != 0.f || t.behavior_resample_steps != 0 || t.noise_vec[9 + 6 * h->model.n_legs] != 0.f || h->bufs.task_state)
         return 0;
     if (!h->hf || h->opts.terrain_rows <= 0) return 0;     // the profiles hard-wire "there is a heightfield" (lg_quad.h HFC)
-    if (t.obs_layout == LG_OBS_GO2_EE && t.double_shift == 0 && t.cat_enable == 0) {
-        // PROF 3 = the component-layout tail of lg_quad.h for go2_ee: what it hard-wires
-        const LgBuffers &b = h->bufs;
-        const int K = __builtin_popcount(h->model.state_link_mask), P = h->opts.n_height_points, A = h->model.n_bodies - 1;
-        const bool ok = t.obs_slack > 0 && t.obs_frame == 9 + 3 * A && t.priv_frame == 9 + 3 * A + 7 + 2 * A + K + P && t.obs_stack > 1 && t.priv_stack > 1 &&
-                        t.num_labels == 3 + K + h->model.n_legs && t.obs_sets <= 2 && (t.obs_sets < 2 || b.obs_dirty) && !b.rand_in && !b.joint_armature &&
-                        !t.dr_joint_on && flat_noise_ok(h) && h->model.n_legs == 4 && h->model.n_bodies == 13 && P > 0 && P <= 7 * 16 &&
-                        h->opts.feet_terrain_info && b.priv_obs_buf && b.labels_buf && b.rand_push_vels && t.air_time_cmd_dims != 3 &&
+    // PROF 3 / 4 = the component-layout tail of lg_quad.h for the go2_ee family: what it hard-wires
+    const LgBuffers &b = h->bufs;
+    const int K = __builtin_popcount(h->model.state_link_mask), P = h->opts.n_height_points, A = h->model.n_bodies - 1;
+    const bool common = t.double_shift == 0 && t.cat_enable == 0 && t.obs_slack > 0 && t.obs_frame == 9 + 3 * A && t.obs_stack > 1 && t.priv_stack > 1 &&
+                        t.obs_sets <= 2 && (t.obs_sets < 2 || b.obs_dirty) && !b.rand_in && !b.joint_armature && !t.dr_joint_on && flat_noise_ok(h) &&
+                        h->model.n_legs == 4 && h->model.n_bodies == 13 && P > 0 && P <= 7 * 16 && h->opts.feet_terrain_info && b.priv_obs_buf &&
+                        b.rand_push_vels && t.air_time_cmd_dims != 3 && t.num_priv_obs > 0 &&
                         (!t.terrain_curriculum || (b.terrain_levels && b.terrain_types && b.terrain_origins && b.env_origins)) &&
                         ((unsigned)h->hot.reward_mask & ((1u << LG_R_BIPED_PERIODIC_GAIT) | (1u << LG_R_QUAD_PERIODIC_GAIT) | (1u << LG_R_FEET_DISTANCE) |
                                                          (1u << LG_R_BASE_HEIGHT) | (1u << LG_R_TRACKING_BASE_HEIGHT) | (1u << LG_R_TRACKING_FOOT_CLEARANCE) |
                                                          (1u << LG_R_TRACKING_ORIENTATION))) == 0;
-        return ok ? 3 : 0;
+    if (!common) return 0;
+    if (t.obs_layout == LG_OBS_GO2_EE)
+        return (t.priv_frame == 9 + 3 * A + 7 + 2 * A + K + P && t.num_labels == 3 + K + h->model.n_legs && b.labels_buf) ? 3 : 0;
+    if (t.obs_layout == LG_OBS_PROGRAM) {
+        if (t.num_labels > 0 && !b.labels_buf) return 0;
+        for (const LgObsProgram *pr : {&t.priv_prog, &t.labels_prog})
+            for (int i = 0; i < pr->n_segs; i++)
+                if (pr->kind[i] == LG_SEG_DR_JOINT || pr->kind[i] <= LG_SEG_END || pr->kind[i] > LG_SEG_KD) return 0;
+        return 4;
     }
-    if (t.obs_layout == LG_OBS_PROGRAM) return 4;
     return 0;
 }
 

@@ -432,9 +432,10 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     // (env_step_body<.., FUSED>) reads it back after the physics instead of paying the round trips then.  Layout = the
     // stash of env_step_body (NST values x 16 lanes).
     constexpr int NST = LG_R_COUNT + 36;
-    constexpr bool QTAIL = (FLAT || PROF == 2 || PROF == 3) && MPH == (LG_PHASE_POST | LG_PHASE_RESET);   // MDP phases in component layout on all 64 lanes (below)
+    constexpr bool QTAIL = (FLAT || PROF == 2 || PROF == 3 || PROF == 4) && MPH == (LG_PHASE_POST | LG_PHASE_RESET);   // MDP phases in component layout on all 64 lanes (below)
     constexpr bool WQ = PROF == 2 && QTAIL;   // ... of the go2_wtw task: gait clock, behaviour targets, 61 x 5 | 99 x 5 observation stacks
-    constexpr bool EQ = PROF == 3 && QTAIL;   // ... of the go2_ee task: heightfield, terrain curriculum, 45 x 20 | (45 + 31 + K + P) x 5 stacks, labels
+    constexpr bool PQ = PROF == 4 && QTAIL;   // ... of the rough heads with observation programs (go2_ts / go2_cts / go2_dreamwaq): go2_ee's MDP, other packaging
+    constexpr bool EQ = (PROF == 3 || PROF == 4) && QTAIL;   // ... of the go2_ee family: heightfield, terrain curriculum, 45 x 20 | critic x 5 stacks, labels
     constexpr bool SQ = WQ || EQ;             // stacked observations, PD-gain randomisation, root twist draws
     __shared__ float sStF[(MPH != 0 && !QTAIL) ? NST * 16 : 1];
     float wsv[(MPH != 0 && !QTAIL) ? NST : 1];
@@ -1067,6 +1068,9 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     const int kstride = 4 * LEGS, hk0 = leg * 4 + L.c;   // this lane's terrain samples: k = hk0 + i kstride
     float hq[HQ];                                // this lane's samples (k = k0 + i kstride), kept for the go2_ee tail
     float f_hmean = 0.f, f_hmax = 0.f;           // mean / max of the nine heights around this leg's foot
+    float f_h9[9], f_n3[3] = {0.f, 0.f, 0.f};    // ... the nine heights and the terrain normal there (observation programs)
+#pragma unroll
+    for (int k = 0; k < 9; k++) f_h9[k] = 0.f;
 #pragma unroll
     for (int i = 0; i < HQ; i++) hq[i] = 0.f;
     if (P > 0) {
@@ -1121,8 +1125,11 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             {
                 float sm = 0.f, mx = -1e30f;
 #pragma unroll
-                for (int k = 0; k < 9; k++) { const float hv = (float)hh[k] * HOT(o_vscale); sm += hv; mx = fmaxf(mx, hv); }
+                for (int k = 0; k < 9; k++) { const float hv = (float)hh[k] * HOT(o_vscale); sm += hv; mx = fmaxf(mx, hv); f_h9[k] = hv; }
                 f_hmean = sm / 9.f; f_hmax = mx;
+                const float dx_ = (float)(hh[1] - hh[0]) / (HOT(o_hscale) * 2.f), dy_ = (float)(hh[3] - hh[2]) / (HOT(o_hscale) * 2.f);
+                const float nn_ = fsqrt(dx_ * dx_ + dy_ * dy_ + 1.f);
+                f_n3[0] = dx_ / nn_; f_n3[1] = dy_ / nn_; f_n3[2] = -1.f / nn_;      // genesis_simulator.py:601-606 (raw int16 differences, reproduced)
             }
             if (live && L.is0) {
 #pragma unroll
@@ -1630,11 +1637,22 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 ug = fetch(uw, 4 * (cj >> 1) + (cj & 1));
                 ua = fetch(uw, 4 * ((3 + cj) >> 1) + ((3 + cj) & 1));
             }
+            // observation programs (PROF 4): where the noise-free actor frame sits in the critic frame (-1: nowhere), where the "next state"
+            // copy sits in the labels row (-1: none), whether the critic frame is clipped
+            int pfo = 0, nxo = -1;
+            float pclip = co;
+            if constexpr (PQ) {
+                pfo = -1;
+                for (int s_ = 0; s_ < PRG_I(0, 0); s_++) if (PRG_I(0, 2 + s_) == LG_SEG_FRAME) pfo = PRG_I(0, 10 + s_);
+                for (int s_ = 0; s_ < PRG_I(1, 0); s_++) if (PRG_I(1, 2 + s_) == LG_SEG_NEXT_STATE) nxo = PRG_I(1, 10 + s_);
+                pclip = PRG_I(0, 1) ? co : 3.0e38f;
+            }
+            const float ascl = HOT(o_action_scale);
             auto W = [&](int idx, float v, float u, float ns) {
-                const float cl = clampf(v, -co, co);
                 const float nv = clampf(nz ? v + (2.f * u - 1.f) * ns : v, -co, co);
                 on[idx] = nv; if (w2o) on2[idx] = nv;
-                pn[idx] = cl; if (w2p) pn2[idx] = cl;
+                if (pfo >= 0) { const float cl = clampf(v, -pclip, pclip); pn[pfo + idx] = cl; if (w2p) pn2[pfo + idx] = cl; }
+                if (PQ && nxo >= 0) lab[nxo + idx] = idx >= 9 + 2 * A ? v * ascl : v;      // go2_dreamwaq.py:66-74, not clipped
             };
             auto WP = [&](int idx, float v) { const float cl = clampf(v, -co, co); pn[idx] = cl; if (w2p) pn2[idx] = cl; };
             // quad broadcasts outside the divergent branches
@@ -1646,18 +1664,22 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const int cl_ = l0 + L.c;
             const bool chas = ((smask >> cl_) & 1u) != 0;
             const int cidx = __popc(smask & ((1u << cl_) - 1u));
+            // the actor frame (both profiles)
             if (st) {
                 W(9 + d0 + cj, (q - q0) * h_obs_scale_dof_pos, uq, m_nq);
                 W(9 + A + d0 + cj, qd * h_obs_scale_dof_vel, uqd, m_nqd);
                 W(9 + 2 * A + d0 + cj, act, 0.5f, 0.f);
-                WP(FR + 7 + d0 + cj, o_kp - h_kp_offset);
-                WP(FR + 7 + A + d0 + cj, o_kd - h_kd_offset);
                 if (leg == 0) {
                     W(cj, cmdv * (L.is2 ? h_obs_scale_ang_vel : h_obs_scale_lin_vel), 0.5f, 0.f);
                     W(3 + cj, pg, ug, L.sel(h_noise_lead_0, h_noise_lead_1, h_noise_lead_2));
                     W(6 + cj, bav * h_obs_scale_ang_vel, ua, L.sel(h_noise_lead_3, h_noise_lead_4, h_noise_lead_5));
-                    lab[cj] = blv * h_obs_scale_lin_vel;
                 }
+            }
+            if constexpr (!PQ) {
+            if (st) {
+                WP(FR + 7 + d0 + cj, o_kp - h_kp_offset);
+                WP(FR + 7 + A + d0 + cj, o_kd - h_kd_offset);
+                if (leg == 0) lab[cj] = blv * h_obs_scale_lin_vel;
                 if (leg == 2) WP(FR + 2 + cj, o_com);
                 if (L.is0) lab[3 + K + foot_slot] = clampf(fpz - f_hmean - h_foot_height_offset, -1.f, 1.f);
             }
@@ -1672,8 +1694,66 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                     if (h_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * h_obs_scale_height;
                     if (k < P) WP(FR + 7 + 2 * A + K + k, hv);
                 }
-                if (leg == 0 && L.is0 && B.obs_dirty) B.obs_dirty[e] = reset ? 1 : 0;
             }
+            } else {
+                // observation programs (include/lgsim.h LgObsSeg): the critic frame and the auxiliary row are concatenations of blocks; each
+                // block is written by the lanes that hold its values -- joint lanes, component lanes, the lane of a link, the lane that
+                // took a terrain sample
+                const float blvs = blv * h_obs_scale_lin_vel;
+                const float clr = clampf(fpz - f_hmean - h_foot_height_offset, -1.f, 1.f);
+                for (int which = 0; which < 2; which++) {
+                    const bool to_lab = which == 1;
+                    if (to_lab ? h_num_labels <= 0 : h_num_priv_obs <= 0) continue;
+                    const float cl = PRG_I(which, 1) ? co : 3.0e38f;
+                    auto WS = [&](int idx, float v) {
+                        v = clampf(v, -cl, cl);
+                        if (to_lab) lab[idx] = v;
+                        else { pn[idx] = v; if (w2p) pn2[idx] = v; }
+                    };
+                    const int n_segs = PRG_I(which, 0);
+                    for (int s_ = 0; s_ < n_segs; s_++) {
+                        const int kind = PRG_I(which, 2 + s_), off = PRG_I(which, 10 + s_);
+                        const float sc = PRG_F(which, 18 + s_);
+                        if (kind == LG_SEG_DR || kind == LG_SEG_DR_BASE) {
+                            if (st && kind == LG_SEG_DR) { WS(off + 7 + d0 + cj, o_kp - h_kp_offset); WS(off + 7 + A + d0 + cj, o_kd - h_kd_offset); }
+                            if (st && leg == 2) WS(off + 2 + cj, o_com);
+                            if (live && leg == 1) WS(off + (L.c < 2 ? L.c : 3 + L.c), env4);
+                        } else if (kind == LG_SEG_KP || kind == LG_SEG_KD) {
+                            if (st) WS(off + d0 + cj, kind == LG_SEG_KP ? o_kp - h_kp_offset : o_kd - h_kd_offset);
+                        } else if (kind == LG_SEG_BASE_LIN_VEL) {
+                            if (st && leg == 0) WS(off + cj, blvs * sc);
+                        } else if (kind == LG_SEG_CONTACT_STATES) {
+                            if (live && chas) WS(off + cidx, csv);
+                            if (live && leg == 0 && L.is3 && (smask & 1u)) WS(off, nb2 > 1.f ? 1.f : 0.f);
+                        } else if (kind == LG_SEG_HEIGHTS) {
+                            if (live) {
+#pragma unroll
+                                for (int i = 0; i < HQ; i++) {
+                                    const int k = hk0 + i * kstride;
+                                    float hv = pzn - h_heights_offset - hq[i];
+                                    if (h_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * h_obs_scale_height;
+                                    if (k < P) WS(off + k, hv);
+                                }
+                            }
+                        } else if (kind == LG_SEG_FEET_REL_HEIGHTS || kind == LG_SEG_FEET_HEIGHTS) {
+                            if (live) {   // nine per foot: lane c of the leg's quad writes entries c, c + 4 (and 8)
+#pragma unroll
+                                for (int k = 0; k < 9; k++)
+                                    if ((k & 3) == L.c) WS(off + 9 * foot_slot + k, kind == LG_SEG_FEET_HEIGHTS ? f_h9[k] : clampf(fpz - f_h9[k], -1.f, 1.f));
+                            }
+                        } else if (kind == LG_SEG_FEET_NORMALS) {
+                            if (st) WS(off + 3 * foot_slot + cj, L.sel(f_n3[0], f_n3[1], f_n3[2]));
+                        } else if (kind == LG_SEG_FOOT_CLEARANCE) {
+                            if (live && L.is0) WS(off + foot_slot, clr);
+                        } else if (kind == LG_SEG_LAST_ACTIONS) {
+                            if (st) WS(off + d0 + cj, last_act);
+                        } else if (kind == LG_SEG_FEET_AIR_TIME) {
+                            if (live && L.is0) WS(off + foot_slot, air);
+                        }   // LG_SEG_FRAME / LG_SEG_NEXT_STATE: written entry by entry in W(); LG_SEG_DR_JOINT: excluded by the host check
+                    }
+                }
+            }
+            if (live && leg == 0 && L.is0 && B.obs_dirty) B.obs_dirty[e] = reset ? 1 : 0;
         } else if constexpr (WQ) {
             // ---- compute_observations + clip, go2_wtw.py:53-111: actor frame 61 = go2's 45 | clock sin 4, cos 4 | gait period, base-height,
             //      clearance, pitch targets | theta 4; critic frame 99 = the frame without noise | v_b 3, push 2, mass, friction, CoM 3 |

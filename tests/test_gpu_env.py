@@ -75,7 +75,7 @@ def _go2_all_terms_cfg():
     return cfg
 
 
-@pytest.mark.parametrize("task", ["go2", "go2-push", "go2-allterms", "go2-yawcmd", "go2_wtw", "go2_ee", "go2_ts", "tron1_pf_ee", "tron1_pf", "tron1_sf"])
+@pytest.mark.parametrize("task", ["go2", "go2-push", "go2-allterms", "go2-yawcmd", "go2_wtw", "go2_ee", "go2_ts", "go2_cts", "go2_dreamwaq", "tron1_pf_ee", "tron1_pf", "tron1_sf"])
 def test_fused_launch_equals_split_launches(task):
     """Same state in, one control step through (a) the fused launch -- the instantiation bench.py times,
     quad_sim_kernel<4, true, POST|RESET> with the MDP phases in its tail -- and (b) SIM, then PRE|POST|RESET in
@@ -83,9 +83,9 @@ def test_fused_launch_equals_split_launches(task):
     identical integers, floats to 1e-5 (the template instantiations may contract FMAs differently; contact dynamics
     would amplify that over many steps, so states are re-synced every step).  Every quadruped task that uses the fused
     tail is covered: go2 (45-wide frame; its fused launch is the FLAT instantiation whose MDP phases run in component
-    layout on all 64 lanes, lg_quad.h), go2_wtw (the same kind of tail: gait state, 5-frame stacks, PD-gain DR), go2_ee and go2_ts
-    (heightfield sampling handed over through measured_heights, 20 / 5-frame stacks, labels / observation programs; the tail runs as four
-    replicas of its leg-lanes).  For the bipeds path (a) is what their env.step() issues -- component-per-lane physics launch, then the
+    layout on all 64 lanes, lg_quad.h), go2_wtw (the same kind of tail: gait state, 5-frame stacks, PD-gain DR), go2_ee and the heads
+    go2_ts / go2_cts / go2_dreamwaq (the same kind of tail again: terrain curriculum, terrain samples kept in the lanes that took them,
+    20 / 5-frame stacks, labels / observation programs interpreted in component layout).  For the bipeds path (a) is what their env.step() issues -- component-per-lane physics launch, then the
     leg-per-lane MDP launch (tron1_sf: four-joint legs in both)."""
     import torch
     from hcr_genesis_lr_cl_amd import abi
