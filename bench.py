@@ -252,10 +252,27 @@ def cpu_baseline(n_envs=4096, steps=800):
     for _ in range(steps):
         act = rng.normal(size=(n_envs, 12)).astype(np.float32)
         orc.sim_step(desc, opts, st, act, "f32", threads=cores)
-    dt = time.perf_counter() - t0
-    return {"value": n_envs * steps / dt, "unit": "env-steps/s", "cores": cores, "kind": "port",
-            "sample": f"{n_envs} envs x {steps} control steps of go2 flat (physics phase of the C oracle, f32, "
-                      f"OpenMP {cores} threads; the numpy MDP stack is not included)"}
+    t_phys = (time.perf_counter() - t0) / steps
+    # the MDP half of the step (termination, rewards, reset + domain randomisation, commands, observation): the numpy oracle
+    # on states of the same batch size (numpy: one thread)
+    from oracle import mdp_oracle as mo
+    from tests.golden_inputs import random_mdp_inputs
+    task = builders.make_task_cfg(model, cfg)
+    origins = np.zeros((n_envs, 3), np.float32)
+    mdp = mo.MdpOracle(model, cfg, task, n_envs, origins)
+    mdp.episode_length_buf[:] = rng.integers(0, 1001, n_envs)
+    mdp_steps = 12
+    sims = [random_mdp_inputs(rng, model, cfg, n_envs, task.slots.n_slots) for _ in range(4)]
+    mdp.step(*sims[0], 1)                                         # warm-up
+    t0 = time.perf_counter()
+    for i in range(mdp_steps):
+        mdp.step(*sims[i % 4], 2 + i)
+    t_mdp = (time.perf_counter() - t0) / mdp_steps
+    return {"value": n_envs / (t_phys + t_mdp), "unit": "env-steps/s", "cores": cores, "kind": "port",
+            "physics_ms_per_step": t_phys * 1e3, "mdp_ms_per_step": t_mdp * 1e3,
+            "sample": f"{n_envs} envs of go2 flat: {steps} control steps of the C oracle's physics phase (f32, OpenMP {cores} "
+                      f"threads, {t_phys * 1e3:.2f} ms/step) + {mdp_steps} steps of the numpy oracle's MDP phases (one thread, "
+                      f"{t_mdp * 1e3:.2f} ms/step); value = envs / (physics + MDP time per step)"}
 
 
 def build_flags():
