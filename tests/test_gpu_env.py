@@ -284,6 +284,37 @@ def test_ragged_batch_sizes(layout, monkeypatch):
         assert torch.equal(o1, o2) and torch.equal(r1, r2) and torch.equal(d1, d2)
 
 
+@pytest.mark.parametrize("task", ["go2_wtw", "go2_ee", "go2_ts", "go2_dreamwaq", "tron1_pf_ee", "tron1_pf", "tron1_sf"])
+def test_ragged_batch_sizes_task_tails(task):
+    """The same for the task-specific tails (component-layout MDP on all lanes of the wave, observation stores dealt over the
+    lanes of an env, the two-launch bipeds): a 7-env shard of a 10-env job (a wave holds 4 quadruped / 8 biped envs, so the last
+    wave is partly dead in both runs) steps bit for bit like the first 7 envs of the 10-env job -- every returned observation
+    tensor, reward and done flag."""
+    import torch
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    g = torch.Generator(device="cuda"); g.manual_seed(22)
+    runs = []
+    for n in (7, 10):
+        env = make_env(task, n, "cuda:0", global_num_envs=10)[0]
+        env.reset()
+        A = env.num_actions
+        if not runs:
+            bank = [torch.randn(10, A, generator=g, device="cuda") for _ in range(40)]
+        outs = []
+        for a in bank:
+            out = env.step(a[:n].contiguous())
+            obs = [o[:7].clone() for o in out[:-3] if o is not None]
+            outs.append((obs, out[-3][:7].clone(), out[-2][:7].clone()))
+        for k in ("dof_pos", "dof_vel", "base_pos", "base_quat"):
+            assert torch.isfinite(env._engine.buf[k]).all(), (task, n, k)
+        runs.append(outs)
+    for t, ((o1, r1, d1), (o2, r2, d2)) in enumerate(zip(*runs)):
+        assert len(o1) == len(o2)
+        for a, b in zip(o1, o2):
+            assert torch.equal(a, b), (task, t)
+        assert torch.equal(r1, r2) and torch.equal(d1, d2), (task, t)
+
+
 def _obs_tensors(out):
     """(actor obs, critic obs / labels ...) of a step()/reset() result: every tensor-valued observation output."""
     import torch
