@@ -295,6 +295,8 @@ def launcher_dry_run(args, world, rank):
         dist.init_process_group("gloo")
     n_local, widths = 32, [5, 3]
     gather = StepGather(n_local, widths, world, "cpu", overlap=not args.sync_gather, batch=args.gather_batch) if world > 1 else None
+    if gather is not None:
+        gather.prime()
     obs = [torch.full((n_local, w), float(rank)) for w in widths]
     rew, done = torch.full((n_local,), 0.5 + rank), torch.zeros(n_local, dtype=torch.bool)
     done[rank] = True
@@ -402,6 +404,8 @@ def main():
         return [o for o in out[:-3] if o is not None]
     widths = [int(o.shape[1]) for o in obs_outputs(env.step(bank[0]))]
     gather = StepGather(n_local, widths, world, dev, overlap=not args.sync_gather, batch=args.gather_batch) if world > 1 and not args.no_gather else None
+    if gather is not None:
+        gather.prime()         # communicator set-up of the all-gather is initialisation, not a step (W may be smaller than the batch)
 
     def one_step(i):
         out = env.step(bank[i % len(bank)])

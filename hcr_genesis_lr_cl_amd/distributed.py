@@ -91,6 +91,19 @@ class StepGather:
             self._issue(i)
         return self.out
 
+    def prime(self):
+        """One all-gather on each buffer pair, awaited: RCCL sets up the connections of an algorithm at its first use, and the first
+        collective of a run would otherwise land `batch` steps into it (inside a short timed region).  Leaves `t` untouched."""
+        if self.world > 1:
+            for i in range(len(self.recs)):
+                self.recs[i].zero_()
+                self._issue(i)
+                if self.work[i] is not None:
+                    self.work[i].wait()
+                    self.work[i] = None
+            if self.recs[0].is_cuda:
+                torch.cuda.synchronize()
+
     def finish(self):
         """Send a partly filled batch, then wait for every outstanding gather (end of rollout / end of the timed region)."""
         if self.t % self.batch != 0:

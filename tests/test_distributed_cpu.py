@@ -36,6 +36,8 @@ def _worker(rank, world, port, q):
     assert torch.allclose(outs[2][:, 0], full + 2)
     # several steps per collective: 7 steps in batches of 3 (the last one partly filled and flushed by finish()), overlapped
     g3 = StepGather(n, 5, world, "cpu", overlap=True, batch=3)
+    g3.prime()       # communicator warm-up on both buffer pairs: must not disturb the step count or the records that follow
+    assert g3.t == 0
     outs3 = [g3(obs + k, ids * (2 + k), (ids % 3 == 0).float()) for k in range(7)]
     g3.finish()
     for k, slot in ((3, 0), (5, 2), (6, 0)):
