@@ -223,3 +223,134 @@ def test_no_robot_is_thrown_by_the_contact_solver(task):
         worst_h = max(worst_h, float((s.base_pos[:, 2] - s.env_origins[:, 2]).max()))
         worst_f = max(worst_f, float(s.link_contact_forces.norm(dim=-1).max()))
     assert worst_v < 6.0 and worst_h < 3.0 and worst_f < 6000.0, (worst_v, worst_h, worst_f)
+
+
+# ---- first principles on the kernel itself (no oracle in the loop) ------------------------------------------------------------
+def _engine_with(go2, layout, n, **opt_overrides):
+    import copy
+    from hcr_genesis_lr_cl_amd import builders
+    from hcr_genesis_lr_cl_amd.engine import Engine
+    opts = copy.copy(go2["opts"])
+    opts.sim_layout = layout
+    for k, v in opt_overrides.items():
+        setattr(opts, k, v)
+    task = builders.make_task_cfg(go2["model"], go2["cfg"])
+    return Engine(go2["model"], go2["desc"], opts, task, n, "cuda:0")
+
+
+def _read_back(engine, st, names=("base_pos", "base_quat", "base_lin_vel_w", "base_ang_vel_w", "dof_pos", "dof_vel")):
+    got = engine_arrays_like(engine, names)
+    for k in names:
+        st.arr[k][:] = got[k].reshape(st.arr[k].shape)
+
+
+def engine_arrays_like(engine, names):
+    from tests.util import engine_arrays
+    return engine_arrays(engine, list(names))
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_zero_gravity_momentum_is_conserved_by_the_kernel(go2, layout):
+    """Internal (actuator, joint-limit, damping) torques cannot change the total momentum.  64 floating robots in zero gravity,
+    random twists / joint rates / actions, 48 ms of simulated time: the linear and angular momentum (computed from the kernel's state
+    by an independent numpy FK, tests/test_oracle_physics._momentum) drift only by the O(dt) global error of the first-order
+    integrator -- small at dt = 2 ms and at least 2.5x smaller at dt = 0.5 ms (a force that did not belong there would not scale)."""
+    import torch
+    from hcr_genesis_lr_cl_amd import abi
+    from oracle import oracle as orc
+    from hcr_genesis_lr_cl_amd import config as cfgmod
+    from tests.test_oracle_physics import _momentum
+    from tests.util import load_state_into_engine
+    n = 64
+    drift = []
+    for dt, ctrl_steps in ((2e-3, 6), (5e-4, 24)):
+        eng = _engine_with(go2, layout, n, gravity_z=0.0, dt=dt)
+        st = orc.HostState(go2["model"], n, cfgmod.default_dof_pos(go2["cfg"]), 3.0)
+        rng = np.random.default_rng(7)
+        st.arr["base_lin_vel_w"][:] = rng.normal(size=(n, 3))
+        st.arr["base_ang_vel_w"][:] = rng.normal(size=(n, 3))
+        st.arr["dof_vel"][:] = rng.normal(size=(n, 12))
+        st.arr["dof_pos"][:] += rng.uniform(-0.2, 0.2, (n, 12)).astype(np.float32)
+        st.arr["base_pos"][:, :2] = 0
+        load_state_into_engine(eng, st)
+        m0 = [_momentum(go2["model"], st, e) for e in range(n)]
+        act = torch.from_numpy(rng.normal(size=(n, 12)).astype(np.float32)).cuda()
+        for _ in range(ctrl_steps):
+            eng.step(abi.PHASE_SIM, act, 0)
+        _read_back(eng, st)
+        assert np.abs(eng.buf["link_contact_forces"].cpu().numpy()).max() == 0.0
+        dl, da = [], []
+        for e in range(n):
+            l1, a1, _ = _momentum(go2["model"], st, e)
+            l0, a0, _ = m0[e]
+            dl.append(np.linalg.norm(l1 - l0) / max(np.linalg.norm(l0), 1.0))
+            da.append(np.linalg.norm(a1 - a0) / max(np.linalg.norm(a0), 1.0))
+        drift.append((float(np.mean(dl)), float(np.mean(da)), float(np.max(dl)), float(np.max(da))))
+    print("momentum drift (mean lin, mean ang, max lin, max ang) at dt = 2 ms / 0.5 ms:", drift)
+    assert drift[0][2] < 2e-2 and drift[0][3] < 2e-2, drift          # measured: 7e-3 / 5e-3 at worst, means 1.8e-3 / 1.0e-3
+    assert drift[1][0] < drift[0][0] / 2.5 + 2e-6 and drift[1][1] < drift[0][1] / 2.5 + 2e-6, drift   # measured: /4.01 and /4.01
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_mirror_symmetry_of_the_kernel(go2, layout):
+    """Left/right mirrored state + mirrored actions give the mirrored next state (three control steps with contact), in both
+    layouts.  The go2 URDF is not perfectly mirror symmetric (calf collision cylinders 0.012 vs 0.013 m), hence 2e-3."""
+    import torch
+    from hcr_genesis_lr_cl_amd import abi
+    from oracle import oracle as orc
+    from hcr_genesis_lr_cl_amd import config as cfgmod
+    from tests.util import load_state_into_engine
+    n = 32
+    eng = _engine_with(go2, layout, n)
+    st = orc.HostState(go2["model"], n, cfgmod.default_dof_pos(go2["cfg"]), 0.36)
+    rng = np.random.default_rng(3)
+    perm = np.array([3, 4, 5, 0, 1, 2, 9, 10, 11, 6, 7, 8]); sgn = np.array([-1, 1, 1] * 4, np.float32)
+    acts = np.zeros((n, 12), np.float32)
+    for e in range(0, n, 2):
+        q = cfgmod.default_dof_pos(go2["cfg"]) + rng.uniform(-0.2, 0.2, 12).astype(np.float32)
+        qd = rng.normal(size=12).astype(np.float32)
+        a = rng.normal(size=12).astype(np.float32)
+        v, w = rng.normal(size=3) * 0.3, rng.normal(size=3) * 0.3
+        st.arr["dof_pos"][e], st.arr["dof_vel"][e] = q, qd
+        st.arr["dof_pos"][e + 1], st.arr["dof_vel"][e + 1] = q[perm] * sgn, qd[perm] * sgn
+        st.arr["base_lin_vel_w"][e] = v; st.arr["base_lin_vel_w"][e + 1] = v * [1, -1, 1]
+        st.arr["base_ang_vel_w"][e] = w; st.arr["base_ang_vel_w"][e + 1] = w * [-1, 1, -1]
+        acts[e], acts[e + 1] = a, a[perm] * sgn
+    st.arr["base_pos"][:, :2] = 0
+    load_state_into_engine(eng, st)
+    act = torch.from_numpy(acts).cuda()
+    for _ in range(3):
+        eng.step(abi.PHASE_SIM, act, 0)
+    got = engine_arrays_like(eng, ("dof_pos", "base_pos", "base_lin_vel_w"))
+    np.testing.assert_allclose(got["dof_pos"][1::2], got["dof_pos"][0::2][:, perm] * sgn, atol=2e-3)
+    np.testing.assert_allclose(got["base_pos"][1::2] * [1, -1, 1], got["base_pos"][0::2], atol=1e-3)
+    np.testing.assert_allclose(got["base_lin_vel_w"][1::2] * [1, -1, 1], got["base_lin_vel_w"][0::2], atol=2e-2)
+
+
+@pytest.mark.parametrize("layout", LAYOUTS)
+def test_free_fall_closed_form_on_the_kernel(go2, layout):
+    """No contact, kp = kd = 0: the base follows the semi-implicit Euler closed form z_n = z0 - g dt^2 n (n + 1) / 2 and a
+    multibody falling under gravity alone has no relative acceleration (joints and attitude stay put)."""
+    import torch
+    from hcr_genesis_lr_cl_amd import abi
+    from oracle import oracle as orc
+    from hcr_genesis_lr_cl_amd import config as cfgmod
+    from tests.util import load_state_into_engine
+    n = 8
+    eng = _engine_with(go2, layout, n)
+    eng.buf["kp_scale"].zero_(); eng.buf["kd_scale"].zero_()          # PD gains off through their per-env multipliers
+    st = orc.HostState(go2["model"], n, cfgmod.default_dof_pos(go2["cfg"]), 50.0)
+    st.arr["dof_vel"][:] = 0
+    st.arr["kp_scale"][:] = 0; st.arr["kd_scale"][:] = 0
+    load_state_into_engine(eng, st)
+    act = torch.zeros(n, 12, device="cuda")
+    n_ctrl = 10
+    for _ in range(n_ctrl):
+        eng.step(abi.PHASE_SIM, act, 0)
+    got = engine_arrays_like(eng, ("base_pos", "base_lin_vel_w", "dof_vel", "base_ang_vel_w", "base_quat"))
+    k = n_ctrl * 4
+    z = 50.0 - 9.81 * 0.005 ** 2 * k * (k + 1) / 2
+    np.testing.assert_allclose(got["base_pos"][:, 2], z, atol=5e-5)            # f32 at z = 50: 4e-6 per ulp
+    np.testing.assert_allclose(got["base_lin_vel_w"][:, 2], -9.81 * 0.005 * k, atol=2e-5)
+    np.testing.assert_allclose(got["dof_vel"], 0, atol=2e-4)
+    np.testing.assert_allclose(got["base_ang_vel_w"], 0, atol=2e-4)
