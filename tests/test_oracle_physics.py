@@ -63,8 +63,9 @@ def _momentum(model, st, e=0):
     s = {k: v[e].astype(np.float64) for k, v in st.arr.items()}
     R, P = [qmat(s["base_quat"])], [s["base_pos"]]
     W, V = [s["base_ang_vel_w"]], [s["base_lin_vel_w"]]
-    for i in range(1, 13):
-        p = 0 if (i - 1) % 3 == 0 else i - 1
+    nb = int(a["mass"].shape[0])
+    for i in range(1, nb):
+        p = int(a["parent"][i])
         Rpc = a["jrot"][i].reshape(3, 3) @ rod(a["axis"][i], s["dof_pos"][i - 1])
         R.append(R[p] @ Rpc)
         Pi = P[p] + R[p] @ a["jpos"][i]
@@ -72,7 +73,7 @@ def _momentum(model, st, e=0):
         V.append(V[p] + np.cross(W[p], Pi - P[p]))
         W.append(W[p] + R[i] @ a["axis"][i] * s["dof_vel"][i - 1])
     lin, ang, mtot, com = np.zeros(3), np.zeros(3), 0.0, np.zeros(3)
-    for i in range(13):
+    for i in range(nb):
         c = P[i] + R[i] @ a["com"][i]
         vc = V[i] + np.cross(W[i], c - P[i])
         Iw = R[i] @ _sym(a["inertia"][i]) @ R[i].T
