@@ -523,7 +523,7 @@ enum { XA = 0, XLA = 3, XLLA = 6, XQ = 9, XQD = 12, XLQD = 15, XTQ = 18, XFL = 2
 // PROF 2 (host-checked, `wtw_profile`): the go2_wtw task on the plane -- gait clock and 5-frame stacks stay, terrain and the other
 // tasks' packaging drop out.
 // JPL: joints per leg of the serial chains (3: go2, TRON1 point foot; 4: TRON1 sole foot, whose last body is the foot itself).
-template <int LEGS, unsigned PH, bool FUSED, int PROF = 0, int JPL = 3>
+template <int LEGS, unsigned PH, bool FUSED, int PROF = 0, int JPL = 3, bool REPL = false>
 LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF, const float *sX, const int vtid, const int vlane) {
     constexpr bool FLAT = PROF == 1, WTWP = PROF == 2, PLANE = FLAT || WTWP, EEP = PROF == 3, PRGP = PROF == 4, ROUGHQ = EEP || PRGP;
     constexpr bool DO_PRE = (PH & LG_PHASE_PRE) != 0, DO_SIM = (PH & LG_PHASE_SIM) != 0;
@@ -557,7 +557,14 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     int e = tid / LEGS;
     // FUSED: the wave runs four replicas of its 16 leg-lanes (lg_quad.h); replica `sub` > 0 computes the same values and stores only
     // its share of the observation outputs
-    const int sub = FUSED ? ((int)threadIdx.x >> 4) : 0;
+    constexpr bool RP = FUSED || REPL;   // REPL: the same replication in a launch of its own (MDP phases after component-layout physics)
+    const int sub = RP ? ((int)threadIdx.x >> 4) : 0;
+    const int glane = RP ? ((int)threadIdx.x & 15) : vlane;   // lane inside the replica
+    // replicated launches share Philox blocks between the replicas of a leg-lane: `from(w, r)` = word `w` (selected the same way in
+    // every lane) as replica r's lane of this leg holds it
+    auto from = [&](unsigned w, int r) { return (unsigned)__builtin_amdgcn_ds_bpermute(((r << 4) | glane) << 2, (int)w); };
+    auto word = [](const U4 &m, int k) { return k == 0 ? m.x : (k == 1 ? m.y : (k == 2 ? m.z : m.w)); };
+    (void)from; (void)word;
     const bool live_all = e < B.n_envs;
     const bool live = live_all && sub == 0;
     if (!live_all) e = B.n_envs - 1;  // dead lanes shadow the last env (keeps DPP quads uniform), never store
@@ -1829,11 +1836,46 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             constexpr int NB = LEGS == 4 ? 1 : 3;          // blocks per lane: 16 uniforms per quadruped env, 24 per biped env
             float eu[4 * LEGS * NB];
             const bool bundle = !rs.in;
+            // Replicated launch: the Philox blocks a resetting leg-lane needs (env-level bundle, _reset_dofs, kp, kd, root xy, terrain
+            // level, the sit coin: 7-9 calls of ~800 cycles) are evaluated ONE PER REPLICA in two rounds and fetched from the replica
+            // that holds them (same counters, same words: the values are those of the one-by-one calls).
+            const bool spread = RP && !rs.in;
+            U4 R1 = {0u, 0u, 0u, 0u}, R2 = R1;
+            float s_ud[4] = {0.f, 0.f, 0.f, 0.f}, s_up[4] = {0.f, 0.f, 0.f, 0.f}, s_kd[4] = {0.f, 0.f, 0.f, 0.f}, s_xy[2] = {0.f, 0.f}, s_tl = 0.f, s_sit = 0.f;
+            if (spread) {
+                const unsigned c_dof = 0x40000000u + (unsigned)(HOT(slots.reset_dof) + d0), c_kp = 0x40000000u + (unsigned)(HOT(slots.dr_kp) + d0),
+                               c_kd = 0x40000000u + (unsigned)(HOT(slots.dr_kd) + d0), c_bun = 0x80000000u + (unsigned)(0x200 + leg * NB);
+                const int sxy = HOT(slots.reset_root_xy), stl = HOT(slots.terrain_level), ssit = HOT(slots.task_reset);
+                // round 1: biped  r0-r2 bundle blocks, r3 _reset_dofs; quadruped  r0 bundle, r1 _reset_dofs, r2 kp, r3 kd
+                const unsigned c1 = LEGS == 2 ? (sub < 3 ? c_bun + (unsigned)sub : c_dof) : (sub == 0 ? c_bun : (sub == 1 ? c_dof : (sub == 2 ? c_kp : c_kd)));
+                R1 = philox4x32_10(U4{rs.e_lo, rs.e_hi, rs.step, c1}, rs.k0, rs.k1);
+                // round 2: biped  r0 kp, r1 kd, r2 root xy, r3 sit coin (job-wide: env words all ones); quadruped  r0 root xy, r1 terrain level
+                const bool coin = LEGS == 2 && sub == 3;
+                const unsigned c2 = LEGS == 2 ? (sub == 0 ? c_kp : (sub == 1 ? c_kd : (sub == 2 ? (unsigned)(sxy >> 2) : (unsigned)(ssit >> 2))))
+                                              : (sub == 0 ? (unsigned)(sxy >> 2) : (unsigned)(stl >> 2));
+                R2 = philox4x32_10(U4{coin ? 0xFFFFFFFFu : rs.e_lo, coin ? 0xFFFFFFFFu : rs.e_hi, rs.step, c2}, rs.k0, rs.k1);
+                const int rdof = LEGS == 2 ? 3 : 1;
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    s_ud[k] = u01(from(word(R1, k), rdof));
+                    s_up[k] = u01(LEGS == 2 ? from(word(R2, k), 0) : from(word(R1, k), 2));
+                    s_kd[k] = u01(LEGS == 2 ? from(word(R2, k), 1) : from(word(R1, k), 3));
+                }
+                const int rxy = LEGS == 2 ? 2 : 0;
+                s_xy[0] = u01(from(word(R2, sxy & 3), rxy));
+                // the second coordinate sits in the next block when the slot pair straddles one (never with the slot tables in use)
+                s_xy[1] = (sxy & 3) == 3 ? rs.draw(sxy + 1) : u01(from(word(R2, (sxy + 1) & 3), rxy));
+                if (LEGS == 4) s_tl = u01(from(word(R2, stl & 3), 1));
+                else s_sit = u01(from(word(R2, ssit & 3), 3));
+            }
             if (bundle) {
 #pragma unroll
                 for (int b_ = 0; b_ < NB; b_++) {
                     float b[4];
-                    rs.block4(0x200 + leg * NB + b_, b[0], b[1], b[2], b[3]);
+                    if (spread) {
+#pragma unroll
+                        for (int k = 0; k < 4; k++) b[k] = u01(from(word(R1, k), b_));
+                    } else rs.block4(0x200 + leg * NB + b_, b[0], b[1], b[2], b[3]);
 #pragma unroll
                     for (int k = 0; k < 4; k++) {
                         const int x = __float_as_int(b[k]);
@@ -1861,7 +1903,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 const bool up = dist > HOT(terrain_env_length) / 2.f;
                 const bool down = (dist < sqrtf(cmd0 * cmd0 + cmd1 * cmd1) * hc_episode_length_s * 0.5f) && !up;
                 int lvl = B.terrain_levels[e] + (up ? 1 : 0) - (down ? 1 : 0);
-                if (lvl >= HOT(max_terrain_level)) lvl = min((int)floorf(((bundle && EU2) ? eu[EU2 ? 21 : 0] : rs.draw(HOT(slots.terrain_level))) * (float)HOT(max_terrain_level)), HOT(max_terrain_level) - 1);
+                if (lvl >= HOT(max_terrain_level)) lvl = min((int)floorf(((bundle && EU2) ? eu[EU2 ? 21 : 0] : (spread ? s_tl : rs.draw(HOT(slots.terrain_level)))) * (float)HOT(max_terrain_level)), HOT(max_terrain_level) - 1);
                 else lvl = max(lvl, 0);
                 const V3 norg = ld3(B.terrain_origins + ((size_t)lvl * HOT(terrain_cols_n) + B.terrain_types[e]) * 3);
                 if (lead) { B.terrain_levels[e] = lvl; st3(B.env_origins + 3 * e, norg); }
@@ -1874,12 +1916,16 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             if (hc_sit_percent > 0.f) {
                 float us;
                 if (rs.in) us = rs.in[HOT(slots.task_reset)];
+                else if (spread && LEGS == 2) us = s_sit;
                 else { RandSrc g = rs; g.e_lo = 0xFFFFFFFFu; g.e_hi = 0xFFFFFFFFu; us = g.draw(HOT(slots.task_reset)); }
                 sit = us < hc_sit_percent;
             }
             // _reset_dofs (go2.py:17-37): default + U(range) per joint, zero velocity
             float ud[JPL];
-            if constexpr (JPL == 4) rs.draw4(HOT(slots.reset_dof) + d0, ud[0], ud[1], ud[2], ud[3]);
+            if (spread) {
+#pragma unroll
+                for (int j = 0; j < JPL; j++) ud[j] = s_ud[j];
+            } else if constexpr (JPL == 4) rs.draw4(HOT(slots.reset_dof) + d0, ud[0], ud[1], ud[2], ud[3]);
             else rs.draw3(HOT(slots.reset_dof) + d0, ud[0], ud[1], ud[2]);
 #pragma unroll
             for (int j = 0; j < JPL; j++) {
@@ -1892,8 +1938,8 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             // _reset_root_states (go2.py:119-134)
             pos = (sit ? ld3(T->sit_pos) : v3(HOT(o_base_init_pos[0]), HOT(o_base_init_pos[1]), HOT(o_base_init_pos[2]))) + (have_origin ? pos_origin_override : origin_pre);
             if (hc_custom_origins) {
-                pos.x += HOT(reset_root_xy_span) * rs.draw(HOT(slots.reset_root_xy)) + HOT(reset_root_xy_lo);
-                pos.y += HOT(reset_root_xy_span) * rs.draw(HOT(slots.reset_root_xy) + 1) + HOT(reset_root_xy_lo);
+                pos.x += HOT(reset_root_xy_span) * (spread ? s_xy[0] : rs.draw(HOT(slots.reset_root_xy))) + HOT(reset_root_xy_lo);
+                pos.y += HOT(reset_root_xy_span) * (spread ? s_xy[1] : rs.draw(HOT(slots.reset_root_xy) + 1)) + HOT(reset_root_xy_lo);
             }
             qx = sit ? T->sit_quat[0] : HOT(base_init_quat[0]); qy = sit ? T->sit_quat[1] : HOT(base_init_quat[1]);
             qz = sit ? T->sit_quat[2] : HOT(base_init_quat[2]); qw = sit ? T->sit_quat[3] : HOT(base_init_quat[3]);
@@ -1930,20 +1976,25 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     B.actions[e * A + d0 + j] = 0.f; B.last_actions[e * A + d0 + j] = 0.f; B.llast_actions[e * A + d0 + j] = 0.f;
                 }
                 st3(B.last_feet_vel + (e * F + foot_slot) * 3, v3(0, 0, 0));
-                if (HOT(dr_pd_on)) {   // genesis_simulator.py:735-739
-                    float up[JPL], ud2[JPL];
-                    if constexpr (JPL == 4) {
-                        rs.draw4(HOT(slots.dr_kp) + d0, up[0], up[1], up[2], up[3]);
-                        rs.draw4(HOT(slots.dr_kd) + d0, ud2[0], ud2[1], ud2[2], ud2[3]);
-                    } else {
-                        rs.draw3(HOT(slots.dr_kp) + d0, up[0], up[1], up[2]);
-                        rs.draw3(HOT(slots.dr_kd) + d0, ud2[0], ud2[1], ud2[2]);
-                    }
+            }
+            // the redrawn parameters are formed in every replica (each writes its share of the privileged frame from them); replica 0 stores
+            if ((RP || live) && HOT(dr_pd_on)) {   // genesis_simulator.py:735-739
+                float up[JPL], ud2[JPL];
+                if (spread) {
 #pragma unroll
-                    for (int j = 0; j < JPL; j++) {
-                        ld_kp[j] = HOT(dr_kp_span) * up[j] + HOT(dr_kp_lo); B.kp_scale[e * A + d0 + j] = ld_kp[j];
-                        ld_kd[j] = HOT(dr_kd_span) * ud2[j] + HOT(dr_kd_lo); B.kd_scale[e * A + d0 + j] = ld_kd[j];
-                    }
+                    for (int j = 0; j < JPL; j++) { up[j] = s_up[j]; ud2[j] = s_kd[j]; }
+                } else if constexpr (JPL == 4) {
+                    rs.draw4(HOT(slots.dr_kp) + d0, up[0], up[1], up[2], up[3]);
+                    rs.draw4(HOT(slots.dr_kd) + d0, ud2[0], ud2[1], ud2[2], ud2[3]);
+                } else {
+                    rs.draw3(HOT(slots.dr_kp) + d0, up[0], up[1], up[2]);
+                    rs.draw3(HOT(slots.dr_kd) + d0, ud2[0], ud2[1], ud2[2]);
+                }
+#pragma unroll
+                for (int j = 0; j < JPL; j++) {
+                    ld_kp[j] = HOT(dr_kp_span) * up[j] + HOT(dr_kp_lo);
+                    ld_kd[j] = HOT(dr_kd_span) * ud2[j] + HOT(dr_kd_lo);
+                    if (live) { B.kp_scale[e * A + d0 + j] = ld_kp[j]; B.kd_scale[e * A + d0 + j] = ld_kd[j]; }
                 }
             }
             if (lead) {
@@ -1953,24 +2004,29 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 st3(B.base_lin_vel + 3 * e, blv); st3(B.base_ang_vel + 3 * e, bav);
                 st3(B.projected_gravity + 3 * e, pg);
                 st3(B.last_base_lin_vel + 3 * e, v3(0, 0, 0)); st3(B.last_base_ang_vel + 3 * e, v3(0, 0, 0));
+            }
+            if (RP ? leg == 0 : lead) {   // every replica's lead lane forms the values (shared bundle / injected row); replica 0 stores
                 // domain randomisation (genesis_simulator.py:62-77, 665-739)
-                if (HOT(dr_friction_on)) { ld_fric = HOT(dr_friction_span) * (bundle ? eu[3] : rs.draw(HOT(slots.dr_friction))) + HOT(dr_friction_lo); B.friction_values[e] = ld_fric; }
-                if (HOT(dr_mass_on)) { ld_mass = HOT(dr_mass_span) * (bundle ? eu[7] : rs.draw(HOT(slots.dr_mass))) + HOT(dr_mass_lo); B.added_base_mass[e] = ld_mass; }
+                if (HOT(dr_friction_on)) { ld_fric = HOT(dr_friction_span) * (bundle ? eu[3] : rs.draw(HOT(slots.dr_friction))) + HOT(dr_friction_lo); if (lead) B.friction_values[e] = ld_fric; }
+                if (HOT(dr_mass_on)) { ld_mass = HOT(dr_mass_span) * (bundle ? eu[7] : rs.draw(HOT(slots.dr_mass))) + HOT(dr_mass_lo); if (lead) B.added_base_mass[e] = ld_mass; }
                 if (HOT(dr_com_on)) {
                     float uc[3];
                     if (bundle) { uc[0] = eu[4]; uc[1] = eu[5]; uc[2] = eu[6]; }
                     else rs.draw3(HOT(slots.dr_com), uc[0], uc[1], uc[2]);
 #pragma unroll
-                    for (int k = 0; k < 3; k++) { ld_com[k] = HOT(dr_com_span[k]) * uc[k] + HOT(dr_com_lo[k]); B.base_com_bias[3 * e + k] = ld_com[k]; }
+                    for (int k = 0; k < 3; k++) { ld_com[k] = HOT(dr_com_span[k]) * uc[k] + HOT(dr_com_lo[k]); if (lead) B.base_com_bias[3 * e + k] = ld_com[k]; }
                 }
                 if (HOT(dr_joint_on) && B.joint_armature) {
                     float uj[3];
                     if (bundle && EU2) { uj[0] = eu[EU2 ? 16 : 0]; uj[1] = eu[EU2 ? 17 : 0]; uj[2] = eu[EU2 ? 18 : 0]; }
                     else rs.draw3(HOT(slots.dr_joint), uj[0], uj[1], uj[2]);
-                    ld_jnt[0] = HOT(dr_joint_span[0]) * uj[0] + HOT(dr_joint_lo[0]); B.joint_armature[e] = ld_jnt[0];
-                    ld_jnt[1] = HOT(dr_joint_span[1]) * uj[1] + HOT(dr_joint_lo[1]); B.joint_friction[e] = ld_jnt[1];
-                    ld_jnt[2] = HOT(dr_joint_span[2]) * uj[2] + HOT(dr_joint_lo[2]); B.joint_damping[e] = ld_jnt[2];
+                    ld_jnt[0] = HOT(dr_joint_span[0]) * uj[0] + HOT(dr_joint_lo[0]);
+                    ld_jnt[1] = HOT(dr_joint_span[1]) * uj[1] + HOT(dr_joint_lo[1]);
+                    ld_jnt[2] = HOT(dr_joint_span[2]) * uj[2] + HOT(dr_joint_lo[2]);
+                    if (lead) { B.joint_armature[e] = ld_jnt[0]; B.joint_friction[e] = ld_jnt[1]; B.joint_damping[e] = ld_jnt[2]; }
                 }
+            }
+            if (lead) {
                 // extras["episode"] (legged_robot.py:128-132): snapshot this env's sums + the step it reset at; the
                 // host forms the per-step means lazily from these.  (A first version used one float atomic per term
                 // per reset on a shared accumulator: ~10 us per launch of same-line atomic latency.)
@@ -2020,7 +2076,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 while (rm) {
                     const int bit = __builtin_ctzll(rm);
                     rm &= rm - 1;
-                    const int er = (vtid - vlane + bit) / LEGS;
+                    const int er = (vtid - glane + bit) / LEGS;
                     float *orw = oset_c + (size_t)er * orow + (size_t)p.obs_win * FR;
                     for (int i = wl; i < (ST - keep) * FR; i += nl) orw[i] = 0.f;
                     if (pset_c) {
@@ -2070,7 +2126,14 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 // two Philox blocks per lane, all four outputs used: the fourth ones of the env's lanes are the base's
                 // six uniforms (a call is ~800 cycles and a lead-only call stalls the whole wave)
                 float sp0 = 0.5f, sp1 = 0.5f;
-                if constexpr (JPL == 4) {   // all four outputs go to the joints; the base's six uniforms come from two more blocks
+                U4 N1 = {0u, 0u, 0u, 0u};
+                if constexpr (RP) {   // one block per replica: 2 leg | 2 leg + 1 | 2 LEGS | 2 LEGS + 1, fetched where needed
+                    const unsigned idn = sub == 0 ? 2u * leg : (sub == 1 ? 2u * leg + 1u : (sub == 2 ? 2u * LEGS : 2u * LEGS + 1u));
+                    N1 = philox4x32_10(U4{rs.e_lo, rs.e_hi, rs.step, 0x80000000u + idn}, rs.k0, rs.k1);
+#pragma unroll
+                    for (int j = 0; j < JPL; j++) { uq[j] = u01(from(word(N1, j), 0)); uqd[j] = u01(from(word(N1, j), 1)); }
+                    if constexpr (JPL == 3) { sp0 = u01(from(N1.w, 0)); sp1 = u01(from(N1.w, 1)); }
+                } else if constexpr (JPL == 4) {   // all four outputs go to the joints; the base's six uniforms come from two more blocks
                     rs.block4(2 * leg, uq[0], uq[1], uq[2], uq[3]);
                     rs.block4(2 * leg + 1, uqd[0], uqd[1], uqd[2], uqd[3]);
                 } else {
@@ -2086,9 +2149,16 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 if (LEGS == 4) {
                     ub[0] = bcq(sp0, 0); ub[1] = bcq(sp1, 0); ub[2] = bcq(sp0, 1); ub[3] = bcq(sp1, 1); ub[4] = bcq(sp0, 2); ub[5] = bcq(sp1, 2);
                 } else {   // two lanes per env: one more block, same id on both lanes of the pair (only the lead's copy is used)
-                    if constexpr (JPL == 4) { float d0_, d1_; rs.block4(2 * LEGS + 1, sp0, sp1, d0_, d1_); }
-                    ub[0] = sp0; ub[1] = sp1;
-                    rs.block4(2 * LEGS, ub[2], ub[3], ub[4], ub[5]);
+                    if constexpr (RP) {
+                        if constexpr (JPL == 4) { sp0 = u01(from(N1.x, 3)); sp1 = u01(from(N1.y, 3)); }
+                        ub[0] = sp0; ub[1] = sp1;
+#pragma unroll
+                        for (int k = 0; k < 4; k++) ub[2 + k] = u01(from(word(N1, k), 2));
+                    } else {
+                        if constexpr (JPL == 4) { float d0_, d1_; rs.block4(2 * LEGS + 1, sp0, sp1, d0_, d1_); }
+                        ub[0] = sp0; ub[1] = sp1;
+                        rs.block4(2 * LEGS, ub[2], ub[3], ub[4], ub[5]);
+                    }
                 }
             }
         }
@@ -2099,10 +2169,18 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 for (int j = 0; j < JPL; j++) uact[j] = rs.in[ns + 9 + 2 * A + d0 + j];
                 uclk[0] = rs.in[ns + 9 + 3 * A + foot_slot]; uclk[1] = rs.in[ns + 9 + 3 * A + LEGS + foot_slot];
             } else {
-                float dummy;
-                if constexpr (JPL == 4) rs.block4(2 * LEGS + 2 + leg, uact[0], uact[1], uact[2], uact[3]);
-                else rs.block3(2 * LEGS + 2 + leg, uact[0], uact[1], uact[2]);
-                rs.block3(3 * LEGS + 2 + leg, uclk[0], uclk[1], dummy);
+                if constexpr (RP) {   // replica 0: the action block, the others: the clock block
+                    const unsigned idn = sub == 0 ? 2u * LEGS + 2u + leg : 3u * LEGS + 2u + leg;
+                    const U4 N2 = philox4x32_10(U4{rs.e_lo, rs.e_hi, rs.step, 0x80000000u + idn}, rs.k0, rs.k1);
+#pragma unroll
+                    for (int j = 0; j < JPL; j++) uact[j] = u01(from(word(N2, j), 0));
+                    uclk[0] = u01(from(N2.x, 1)); uclk[1] = u01(from(N2.y, 1));
+                } else {
+                    float dummy;
+                    if constexpr (JPL == 4) rs.block4(2 * LEGS + 2 + leg, uact[0], uact[1], uact[2], uact[3]);
+                    else rs.block3(2 * LEGS + 2 + leg, uact[0], uact[1], uact[2]);
+                    rs.block3(3 * LEGS + 2 + leg, uclk[0], uclk[1], dummy);
+                }
             }
         }
         STAMP(26);
@@ -2182,7 +2260,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 nl[k] = clampf(x, -co, co);
             }
             const bool crit = has_pn && pfo >= 0;
-            if constexpr (FUSED) {   // replica 0: this window, 1: the other set's, 2: the critic frame's copy, 3: the other set's critic copy
+            if constexpr (RP) {   // replica 0: this window, 1: the other set's, 2: the critic frame's copy, 3: the other set's critic copy
                 float *const dst = sub == 0 ? on : (sub == 1 ? on2 : (sub == 2 ? pn + pfo : pn2 + pfo));
                 const bool en = sub == 0 || (sub == 1 && has_on2) || (sub == 2 && crit) || (sub == 3 && crit && has_pn2);
                 const bool noisy = sub < 2;
@@ -2266,17 +2344,17 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             float *lab = B.labels_buf + ((size_t)cs * N + e) * hc_num_labels;
             // FUSED: the critic entries are dealt over the replicas -- replica r writes the copy r & 1 (this set's / the other set's
             // critic frame); the heights, the long block, are also halved by r >> 1.  The labels row belongs to replica 0.
-            const bool lw = FUSED ? live_all && ((sub & 1) == 0 || has_pn2) : live;
-            const bool lw01 = FUSED ? lw && sub < 2 : live;
-            float *const pd = (FUSED && (sub & 1)) ? pn2 : pn;
-            auto wp = [&](int idx, float v) { const float c = clampf(v, -co, co); pd[idx] = c; if (!FUSED && has_pn2) pn2[idx] = c; };
+            const bool lw = RP ? live_all && ((sub & 1) == 0 || has_pn2) : live;
+            const bool lw01 = RP ? lw && sub < 2 : live;
+            float *const pd = (RP && (sub & 1)) ? pn2 : pn;
+            auto wp = [&](int idx, float v) { const float c = clampf(v, -co, co); pd[idx] = c; if (!RP && has_pn2) pn2[idx] = c; };
             auto wpv = [&](auto nv_, const int idx0, const float *v) {
                 constexpr int NV = decltype(nv_)::value;
                 float cn[NV];
 #pragma unroll
                 for (int k = 0; k < NV; k++) cn[k] = clampf(v[k], -co, co);
                 stv<NV>(pd + idx0, cn);
-                if (!FUSED && has_pn2) stv<NV>(pn2 + idx0, cn);
+                if (!RP && has_pn2) stv<NV>(pn2 + idx0, cn);
             };
             if (lw01) {
                 float vkp[JPL], vkd[JPL];
@@ -2303,9 +2381,9 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                         const int k = leg + i * LEGS;
                         float hv = pos.z - hc_heights_offset - hts[i];
                         if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
-                        if (k < P && (!FUSED || (i & 1) == (sub >> 1))) wp(FR + 7 + 2 * A + K + k, hv);
+                        if (k < P && (!RP || (i & 1) == (sub >> 1))) wp(FR + 7 + 2 * A + K + k, hv);
                     }
-                } else if (!FUSED || sub < 2) {
+                } else if (!RP || sub < 2) {
                     for (int k = leg; k < P; k += LEGS) {
                         float hv = pos.z - hc_heights_offset - B.measured_heights[(size_t)e * P + k];
                         if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
@@ -2332,55 +2410,79 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             float *lab = B.labels_buf + ((size_t)cs * N + e) * hc_num_labels;
             const float ang = 6.283185307179586f * (phi + theta);
             const int oDR = FR, oG = FR + 7 + 2 * A + 3, oK = oG + F, oH = oK + K, oN = oH + P, oR = oN + 3 * F;
+            // Replicated launch: the critic entries are dealt over the replicas -- replica r writes the copy r & 1 (this set's / the other
+            // set's critic frame); r >> 1 halves the heights and splits the other blocks (0: gains, gait, contact states, DR; 1: normals,
+            // foot clearances).  The actor-frame clock entries, the task state and the labels row belong to replica 0.
+            const bool lwc = RP ? live_all && ((sub & 1) == 0 || has_pn2) : live;
+            const bool gA = !RP || (sub >> 1) == 0, gB = !RP || (sub >> 1) == 1;
+            float *const pd = (RP && (sub & 1)) ? pn2 : pn;
+            auto wpv = [&](auto nv_, const int idx0, const float *v) {
+                constexpr int NV = decltype(nv_)::value;
+                float cn[NV];
+#pragma unroll
+                for (int k = 0; k < NV; k++) cn[k] = clampf(v[k], -co, co);
+                stv<NV>(pd + idx0, cn);
+                if (!RP && has_pn2) stv<NV>(pn2 + idx0, cn);
+            };
+            auto wp = [&](int idx, float v) { wpv(std::integral_constant<int, 1>{}, idx, &v); };
             if (live) {
                 const float sn = sinf(ang), cs = cosf(ang);
                 put(9 + 3 * A + foot_slot, sn, uclk[0], nv_clk[0]);
                 put(9 + 3 * A + F + foot_slot, cs, uclk[1], nv_clk[1]);
                 ts[4 + foot_slot] = theta; ts[6 + foot_slot] = sn; ts[6 + F + foot_slot] = cs; ts[10 + foot_slot] = expC;
-                float vkp[JPL], vkd[JPL];
-#pragma unroll
-                for (int j = 0; j < JPL; j++) { vkp[j] = ld_kp[j] - HOT(kp_offset); vkd[j] = ld_kd[j] - HOT(kd_offset); }
-                putpv(NJ, oDR + 7 + d0, vkp);
-                putpv(NJ, oDR + 7 + A + d0, vkd);
-                putp(oG + foot_slot, expC);
 #pragma unroll
                 for (int k = 0; k < 4; k++) {
                     const int l = l0 + k;
-                    if ((M->state_link_mask >> l) & 1u) {
-                        const int idx = __popc(M->state_link_mask & ((1u << l) - 1u));
-                        const float cst = norm(f_link[k]) > 1.f ? 1.f : 0.f;
-                        putp(oK + idx, cst);
-                        lab[3 + idx] = cst;
-                    }
+                    if ((M->state_link_mask >> l) & 1u) lab[3 + __popc(M->state_link_mask & ((1u << l) - 1u))] = norm(f_link[k]) > 1.f ? 1.f : 0.f;
                 }
+                stv<3>(lab + 3 + K + F + 3 * foot_slot, ld_nv3);
+                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmax - hc_foot_height_offset, -1.f, 1.f);
+            }
+            if (lwc && gA) {
+                float vkp[JPL], vkd[JPL];
+#pragma unroll
+                for (int j = 0; j < JPL; j++) { vkp[j] = ld_kp[j] - HOT(kp_offset); vkd[j] = ld_kd[j] - HOT(kd_offset); }
+                wpv(NJ, oDR + 7 + d0, vkp);
+                wpv(NJ, oDR + 7 + A + d0, vkd);
+                wp(oG + foot_slot, expC);
+#pragma unroll
+                for (int k = 0; k < 4; k++) {
+                    const int l = l0 + k;
+                    if ((M->state_link_mask >> l) & 1u) wp(oK + __popc(M->state_link_mask & ((1u << l) - 1u)), norm(f_link[k]) > 1.f ? 1.f : 0.f);
+                }
+            }
+            if (lwc) {
                 if (hreg) {
 #pragma unroll
                     for (int i = 0; i < HMAX; i++) {
                         const int k = leg + i * LEGS;
                         float hv = pos.z - hc_heights_offset - hts[i];
                         if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
-                        if (k < P) putp(oH + k, hv);
+                        if (k < P && (!RP || (i & 1) == (sub >> 1))) wp(oH + k, hv);
                     }
                 } else {
-                    for (int k = leg; k < P; k += LEGS) {
+                    for (int k = leg + (RP ? (sub >> 1) * LEGS : 0); k < P; k += RP ? 2 * LEGS : LEGS) {
                         float hv = pos.z - hc_heights_offset - B.measured_heights[(size_t)e * P + k];
                         if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
-                        putp(oH + k, hv);
+                        wp(oH + k, hv);
                     }
                 }
-                putpv(N3, oN + 3 * foot_slot, ld_nv3);
-                stv<3>(lab + 3 + K + F + 3 * foot_slot, ld_nv3);
+            }
+            if (lwc && gB) {
+                wpv(N3, oN + 3 * foot_slot, ld_nv3);
                 float vrel[9];
 #pragma unroll
                 for (int k = 0; k < 9; k++) vrel[k] = clampf(foot_p.z - ld_haf[k], -1.f, 1.f);
-                putpv(std::integral_constant<int, 9>{}, oR + 9 * foot_slot, vrel);
-                lab[3 + K + foot_slot] = clampf(foot_p.z - foot_hmax - hc_foot_height_offset, -1.f, 1.f);
+                wpv(std::integral_constant<int, 9>{}, oR + 9 * foot_slot, vrel);
+            }
+            if (lwc && gA && leg == 0) {
+                const float vdr[7] = {ld_fric - HOT(friction_offset), ld_mass, ld_com[0], ld_com[1], ld_com[2], ld_push[0], ld_push[1]};
+                wpv(std::integral_constant<int, 7>{}, oDR, vdr);
+                wpv(N3, oDR + 7 + 2 * A, ld_jnt);
+                if (M->state_link_mask & 1u) wp(oK, norm(f_base) > 1.f ? 1.f : 0.f);
             }
             if (lead) {
-                const float vdr[7] = {ld_fric - HOT(friction_offset), ld_mass, ld_com[0], ld_com[1], ld_com[2], ld_push[0], ld_push[1]};
-                putpv(std::integral_constant<int, 7>{}, oDR, vdr);
-                putpv(N3, oDR + 7 + 2 * A, ld_jnt);
-                if (M->state_link_mask & 1u) { const float cst = norm(f_base) > 1.f ? 1.f : 0.f; putp(oK, cst); lab[3] = cst; }
+                if (M->state_link_mask & 1u) lab[3] = norm(f_base) > 1.f ? 1.f : 0.f;
                 const float vl[3] = {blv.x * hc_obs_scale_lin_vel, blv.y * hc_obs_scale_lin_vel, blv.z * hc_obs_scale_lin_vel};
                 stv<3>(lab, vl);
             }
@@ -2407,14 +2509,14 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
 #pragma unroll
                     for (int k = 0; k < NV; k++) cn[k] = clampf(v[k], -cl, cl);
                     if (to_lab) stv<NV>(labp + idx0, cn);
-                    else if (FUSED) stv<NV>((sub == 0 ? pn : pn2) + idx0, cn);      // replica 0 / 1: this set's / the other set's critic frame
+                    else if (RP) stv<NV>((sub == 0 ? pn : pn2) + idx0, cn);      // replica 0 / 1: this set's / the other set's critic frame
                     else { stv<NV>(pn + idx0, cn); if (has_pn2) stv<NV>(pn2 + idx0, cn); }
                 };
                 // who writes: the labels row replica 0; the critic frame replicas 0 and (second copy) 1; the heights block, the long one, is
                 // halved once more: replica r writes copy r & 1, entries with (i & 1) == r >> 1
-                const bool live = to_lab ? live_all && sub == 0 : (FUSED ? live_all && (sub == 0 || (sub == 1 && has_pn2)) : live_all);
+                const bool live = to_lab ? live_all && sub == 0 : (RP ? live_all && (sub == 0 || (sub == 1 && has_pn2)) : live_all);
                 const bool lead = live && leg == 0;
-                const bool liveh = (FUSED && !to_lab) ? live_all && ((sub & 1) == 0 || has_pn2) : live;
+                const bool liveh = (RP && !to_lab) ? live_all && ((sub & 1) == 0 || has_pn2) : live;
                 auto Wr = [&](int idx, float v) { WrV(std::integral_constant<int, 1>{}, idx, &v); };
                 constexpr std::integral_constant<int, 7> N7{};
                 constexpr std::integral_constant<int, 9> N9{};
@@ -2450,14 +2552,14 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                         if (lead && (slm & 1u)) Wr(off, norm(f_base) > 1.f ? 1.f : 0.f);
                     } else if (kind == LG_SEG_HEIGHTS) {
                         if (hreg && liveh) {
-                            float *const hd = to_lab ? labp : ((FUSED && (sub & 1)) ? pn2 : pn);
+                            float *const hd = to_lab ? labp : ((RP && (sub & 1)) ? pn2 : pn);
 #pragma unroll
                             for (int i = 0; i < HMAX; i++) {
                                 const int k = leg + i * LEGS;
                                 float hv = pos.z - hc_heights_offset - hts[i];
                                 if (hc_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * hc_obs_scale_height;
                                 hv = clampf(hv, -cl, cl);
-                                if (k < P && (!FUSED || to_lab || (i & 1) == (sub >> 1))) { hd[off + k] = hv; if (!FUSED && !to_lab && has_pn2) pn2[off + k] = hv; }
+                                if (k < P && (!RP || to_lab || (i & 1) == (sub >> 1))) { hd[off + k] = hv; if (!RP && !to_lab && has_pn2) pn2[off + k] = hv; }
                             }
                         }
                         if (!hreg && live) {
@@ -2531,11 +2633,16 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     STAMP(11);
 }
 
-template <int LEGS, unsigned PH, int PROF = 0, int JPL = 3>
+// REPL (MDP phases only, small batches): a wave carries 16 leg-lanes in four replicas like the fused tail of quad_sim_kernel -- every
+// replica computes the same values, replica 0 owns the state stores, the observation stores are dealt over the replicas -- so that
+// 4096 biped envs are 512 waves with a quarter of the stores each instead of 128 waves on 1024 SIMDs.
+template <int LEGS, unsigned PH, int PROF = 0, int JPL = 3, bool REPL = false>
 __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_STG * BLOCK];
     __shared__ int sHot[256 + 2 * BLOCK];
-    env_step_body<LEGS, PH, false, PROF, JPL>(p, sMraw, sHot, nullptr, nullptr, blockIdx.x * BLOCK + threadIdx.x, threadIdx.x & 63);
+    static_assert(!REPL || (PH & (LG_PHASE_PRE | LG_PHASE_SIM)) == 0, "replicated launch: MDP phases only");
+    const int vtid = REPL ? (int)(blockIdx.x * 16 + (threadIdx.x & 15)) : (int)(blockIdx.x * BLOCK + threadIdx.x);
+    env_step_body<LEGS, PH, false, PROF, JPL, REPL>(p, sMraw, sHot, nullptr, nullptr, vtid, threadIdx.x & 63);
 }
 
 #include "lg_quad.h"
@@ -2828,6 +2935,12 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
     // auto: component-per-lane while that needs at most two waves per SIMD (1024 SIMDs).  Measured go2, us per step,
     // component vs leg layout: 4096 envs 34.7 / 56.6, 8192: 50.9 / 55.2, 12288: 69.2 / 55.5, 16384: 92 / 60
     // the component-per-lane kernel is specialised for identity joint frames and hip-x / thigh-y / knee-y axes (lg_quad.h)
+    // MDP-only launches of small biped batches run replicated (env_step_kernel<..., REPL>) while four times the waves still fit one per
+    // SIMD.  Measured at 4096 envs, us per step, plain / replicated: tron1_pf_ee 55.8 / 53.7, tron1_sf 52.3 / 50.7, tron1_pf 43.4 / 43.4;
+    // go2_cat (16 k leg-lanes already) 59.4 / 59.6: quadrupeds stay plain.  LG_MDP_REPLICAS=0/1 forces either (read per call: tests flip it).
+    const char *repl_s = getenv("LG_MDP_REPLICAS");
+    const bool repl = repl_s ? atoi(repl_s) != 0 : (LEGS == 2 && (long long)threads * 4 <= 1024LL * BLOCK);
+    const dim3 rgrid((threads + 15) / 16);
     const bool quad_ok = p.jrot_identity && p.k.joint_axis[0] == 0 && p.k.joint_axis[1] == 1 && p.k.joint_axis[2] == 1 && (JPL == 3 || p.k.joint_axis[3] == 1);
     if (h->opts.sim_layout == 2 && !quad_ok) return fail("lg_step: sim_layout 2 needs identity joint frames and x / y / y (/ y) joint axes");
     const int layout = h->opts.sim_layout ? h->opts.sim_layout : ((quad_ok && (long long)threads * 4 <= 2048LL * BLOCK) ? 2 : 1);
@@ -2842,7 +2955,8 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
         else if (rest) LG_LAUNCH_FIRST(pi, (quad_sim_kernel<LEGS, false, 0u, 0, 4>), qgrid);
         else LG_LAUNCH(pi, (quad_sim_kernel<LEGS, false, 0u, 0, 4>), qgrid);
         HIPCHK(hipGetLastError());
-        if (rest == (LG_PHASE_POST | LG_PHASE_RESET)) LG_LAUNCH_LAST(pi, (env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET, 0, 4>), grid);
+        if (rest == (LG_PHASE_POST | LG_PHASE_RESET) && repl) LG_LAUNCH_LAST(pi, (env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET, 0, 4, true>), rgrid);
+        else if (rest == (LG_PHASE_POST | LG_PHASE_RESET)) LG_LAUNCH_LAST(pi, (env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET, 0, 4>), grid);
         else if (rest == LG_PHASE_POST) LG_LAUNCH_LAST(pi, (env_step_kernel<LEGS, LG_PHASE_POST, 0, 4>), grid);
         else if (rest) return fail("lg_step: unsupported phase combination");
         HIPCHK(hipGetLastError());
@@ -2875,7 +2989,8 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
         else LG_LAUNCH(pi, (quad_sim_kernel<LEGS, false, 0u>), qgrid);
         HIPCHK(hipGetLastError());
         if (!fuse && rest) {
-            if (rest == (LG_PHASE_POST | LG_PHASE_RESET)) LG_LAUNCH_LAST(pi, (env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET, 0, JPL>), grid);
+            if (rest == (LG_PHASE_POST | LG_PHASE_RESET) && repl) LG_LAUNCH_LAST(pi, (env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET, 0, JPL, true>), rgrid);
+            else if (rest == (LG_PHASE_POST | LG_PHASE_RESET)) LG_LAUNCH_LAST(pi, (env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET, 0, JPL>), grid);
             else if (rest == LG_PHASE_POST) LG_LAUNCH_LAST(pi, (env_step_kernel<LEGS, LG_PHASE_POST, 0, JPL>), grid);
             else return fail("lg_step: unsupported phase combination");
         }
@@ -2898,7 +3013,9 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
     case LG_PHASE_PRE | LG_PHASE_POST:
         hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_PRE | LG_PHASE_POST, 0, JPL>), grid, block, 0, st, p); break;
     case LG_PHASE_POST | LG_PHASE_RESET:
-        hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET, 0, JPL>), grid, block, 0, st, p); break;
+        if (repl) hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET, 0, JPL, true>), rgrid, block, 0, st, p);
+        else hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST | LG_PHASE_RESET, 0, JPL>), grid, block, 0, st, p);
+        break;
     case LG_PHASE_POST: hipLaunchKernelGGL((env_step_kernel<LEGS, LG_PHASE_POST, 0, JPL>), grid, block, 0, st, p); break;
     default: return fail("lg_step: unsupported phase combination (ALL, SIM, PRE|SIM, PRE|POST|RESET, PRE|SIM|POST, PRE|POST, POST|RESET, POST, RESET)");
     }

@@ -315,6 +315,40 @@ def test_ragged_batch_sizes_task_tails(task):
         assert torch.equal(r1, r2) and torch.equal(d1, d2), (task, t)
 
 
+@pytest.mark.parametrize("task", ["tron1_pf_ee", "tron1_pf", "tron1_sf", "go2_cat"])
+def test_replicated_mdp_launch_is_bit_identical(task, monkeypatch):
+    """MDP phases in a launch of their own (bipeds, go2_cat): plain (one leg per lane) and replicated (16 leg-lanes x 4 replicas per
+    wave, observation stores dealt over the replicas, one Philox block per replica fetched where needed) give the same rollout bit
+    for bit -- every returned tensor and the state behind it, through resets, pushes and window compaction."""
+    import torch
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    monkeypatch.setenv("LG_OBS_SLACK", "16")
+    N = 200
+    runs = []
+    for repl in ("0", "1"):
+        monkeypatch.setenv("LG_MDP_REPLICAS", repl)
+        env, _ = make_env(task, N, "cuda:0")
+        env.reset()
+        g = torch.Generator(device="cuda"); g.manual_seed(8)
+        env.episode_length_buf = torch.randint(940, 1001, (N,), generator=g, device="cuda", dtype=torch.int32)
+        outs = []
+        for t in range(70):
+            out = env.step(torch.randn(N, env.num_actions, generator=g, device="cuda") * 1.5)
+            outs.append([o.clone() for o in out[:-1] if torch.is_tensor(o)])
+        b = env._engine.buf
+        state = {k: b[k].clone() for k in ("dof_pos", "dof_vel", "base_pos", "base_quat", "commands", "episode_sums", "kp_scale", "kd_scale",
+                                          "friction_values", "added_base_mass", "base_com_bias", "feet_air_time", "task_state") if k in b}
+        runs.append((outs, state, sum(int(o[-1].sum()) for o in outs)))
+    (a, sa, ra), (b_, sb, rb) = runs
+    assert ra == rb and ra > N // 4
+    for t, (x, y) in enumerate(zip(a, b_)):
+        assert len(x) == len(y)
+        for u, v in zip(x, y):
+            assert torch.equal(u, v), (task, t)
+    for k in sa:
+        assert torch.equal(sa[k], sb[k]), (task, k)
+
+
 def _obs_tensors(out):
     """(actor obs, critic obs / labels ...) of a step()/reset() result: every tensor-valued observation output."""
     import torch
