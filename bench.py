@@ -317,7 +317,7 @@ def launcher_dry_run(args, world, rank):
         elapsed = float(t.item())
         last = (args.steps - 1) % gather.batch               # slot of the last step inside its batch
         for k in range(world):
-            parts, r, d = gather.split(gather.step_view(out, k, last))
+            parts, r, d = gather.split(gather.step_view(out, k, last, gather.last_fill))
             ok &= all(bool((p_ == k).all()) for p_ in parts) and bool((r == 0.5 + k).all()) and int(d.sum()) == 1 and bool(d[k])
     if rank == 0:
         print(json.dumps({"metric": "launcher dry run", "value": n_local * world * args.steps / max(elapsed, 1e-9), "unit": "records/s",
@@ -334,9 +334,9 @@ def main():
     ap.add_argument("--warmup", type=int, default=100)
     ap.add_argument("--envs-per-gpu", type=int, default=ENVS_PER_GPU)
     ap.add_argument("--no-gather", action="store_true", help="skip the RCCL all-gather of the step outputs at N>1")
-    ap.add_argument("--gather-batch", type=int, default=8, metavar="K",
-                    help="control steps per all-gather at N>1 (default 8: one ~43 MB message per 8 steps at 8 ranks instead of eight "
-                         "latency-bound 5 MB ones; 1 = one collective per step)")
+    ap.add_argument("--gather-batch", type=int, default=4, metavar="K",
+                    help="control steps per all-gather at N>1 (default 4: one ~24 MB message per 4 steps at 8 ranks instead of four "
+                         "latency-bound 6 MB ones, and a short exposed flush at the end of a 20-step run; 1 = one collective per step)")
     ap.add_argument("--sync-gather", action="store_true",
                     help="wait for each step's all-gather before the next step (default: it overlaps the next step, double-buffered)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

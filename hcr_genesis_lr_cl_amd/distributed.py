@@ -50,8 +50,8 @@ class StepGather:
     def __init__(self, n_local, widths, world, device, dtype=torch.float32, overlap=False, batch=1):
         """`batch` = control steps per collective: the records of `batch` consecutive steps travel in ONE all-gather (issued after
         the last of them).  A per-step gather of the go2 record is 0.77 MB per rank -- at 8 ranks 5.4 MB in per rank every 28 us,
-        i.e. ~190 GB/s of ingress in messages small enough to be latency-bound; 8 steps per collective make it one ~43 MB
-        message per 220 us, which RCCL moves near its large-message bandwidth.  The consumer (a learner reading the rollout after
+        i.e. ~190 GB/s of ingress in messages small enough to be latency-bound; 4 steps per collective make it one ~24 MB
+        message per 110 us, which RCCL moves near its large-message bandwidth.  The consumer (a learner reading the rollout after
         its last step) sees the same records either way."""
         self.widths = [int(widths)] if isinstance(widths, int) else [int(w) for w in widths]
         self.num_obs = sum(self.widths)
@@ -63,15 +63,20 @@ class StepGather:
         self.outs = [torch.empty(world * self.batch * n_local, W, device=device, dtype=dtype) if world > 1 else r for r in self.recs]
         self.work = [None] * nb
         self.t = 0
+        self.last_fill = self.batch
         self.rec, self.out = self.recs[0], self.outs[0]
 
-    def _issue(self, i):
+    def _issue(self, i, fill=None):
+        """All-gather of buffer pair i; `fill` < batch sends only the first `fill` steps' records (a partly filled batch)."""
         if self.world > 1:
             import torch.distributed as dist
+            rec, out = self.recs[i], self.outs[i]
+            if fill is not None and fill < self.batch:
+                rec, out = rec[:fill * self.n_local], out[:self.world * fill * self.n_local]
             if self.overlap:
-                self.work[i] = dist.all_gather_into_tensor(self.outs[i], self.recs[i], async_op=True)
+                self.work[i] = dist.all_gather_into_tensor(out, rec, async_op=True)
             else:
-                dist.all_gather_into_tensor(self.outs[i], self.recs[i])
+                dist.all_gather_into_tensor(out, rec)
 
     def __call__(self, obs, rew, done):
         """Pack this step's outputs; every `batch`-th call issues the collective.  Returns the buffer the records of the current
@@ -105,18 +110,24 @@ class StepGather:
                 torch.cuda.synchronize()
 
     def finish(self):
-        """Send a partly filled batch, then wait for every outstanding gather (end of rollout / end of the timed region)."""
+        """Send a partly filled batch (only the steps it holds: `last_fill` of them, laid out as a batch of that size -- pass it to
+        `step_view`), then wait for every outstanding gather (end of rollout / end of the timed region)."""
+        self.last_fill = self.batch
         if self.t % self.batch != 0:
-            self._issue((self.t // self.batch) % len(self.recs))
+            self.last_fill = self.t % self.batch
+            self._issue((self.t // self.batch) % len(self.recs), self.last_fill)
             self.t += self.batch - self.t % self.batch
         for i, w in enumerate(self.work):
             if w is not None:
                 w.wait()
                 self.work[i] = None
 
-    def step_view(self, out, rank, slot):
-        """The (n_local, W) record of `rank` at step `slot` of a gathered batch."""
-        o = out.view(self.world if self.world > 1 else 1, self.batch, self.n_local, self.num_obs + 2)
+    def step_view(self, out, rank, slot, fill=None):
+        """The (n_local, W) record of `rank` at step `slot` of a gathered batch (`fill`: steps in it, for the partly filled batch
+        `finish()` flushed)."""
+        b = self.batch if fill is None else int(fill)
+        w = self.world if self.world > 1 else 1
+        o = out[:w * b * self.n_local].view(w, b, self.n_local, self.num_obs + 2)
         return o[rank, slot]
 
     def split(self, out=None):

@@ -40,10 +40,11 @@ def _worker(rank, world, port, q):
     assert g3.t == 0
     outs3 = [g3(obs + k, ids * (2 + k), (ids % 3 == 0).float()) for k in range(7)]
     g3.finish()
+    assert g3.last_fill == 1          # 7 steps in batches of 3: the flushed batch holds one step and travels at that size
     for k, slot in ((3, 0), (5, 2), (6, 0)):
         for rk in range(world):
             o_k, n_k = shard(64, world, rk)
-            rec = g3.step_view(outs3[k], rk, slot)
+            rec = g3.step_view(outs3[k], rk, slot, g3.last_fill if k == 6 else None)
             ids_k = torch.arange(o_k, o_k + n_k, dtype=torch.float32)
             assert torch.allclose(rec[:, 5], ids_k * (2 + k)) and torch.allclose(rec[:, 0], ids_k + k), (k, rk)
     (p3,), r3, d3 = g3.split(g3.step_view(outs3[5], 1, 2))
