@@ -2633,6 +2633,14 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     STAMP(11);
 }
 
+// XCD-aware workgroup index: blocks b, b + 8, b + 16 ... are dealt to the same XCD (its own 4 MB L2), so THEY get consecutive env groups.
+// With the plain index a wave's 16-byte piece of a (term, N) row or its 48 bytes of an (N, 3) array shares its 128-byte line with waves on
+// the seven other XCDs: every L2 fetched (and wrote back) the whole line.  Bijective for any grid size.
+LG_DEV int lg_wg() {
+    const int b = (int)blockIdx.x, G = (int)gridDim.x, q = G >> 3, r = G & 7, x = b & 7;
+    return x * q + (x < r ? x : r) + (b >> 3);
+}
+
 // REPL (MDP phases only, small batches): a wave carries 16 leg-lanes in four replicas like the fused tail of quad_sim_kernel -- every
 // replica computes the same values, replica 0 owns the state stores, the observation stores are dealt over the replicas -- so that
 // 4096 biped envs are 512 waves with a quarter of the stores each instead of 128 waves on 1024 SIMDs.
@@ -2641,7 +2649,7 @@ __global__ __launch_bounds__(BLOCK) void env_step_kernel(KParams p) {
     __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_STG * BLOCK];
     __shared__ int sHot[256 + 2 * BLOCK];
     static_assert(!REPL || (PH & (LG_PHASE_PRE | LG_PHASE_SIM)) == 0, "replicated launch: MDP phases only");
-    const int vtid = REPL ? (int)(blockIdx.x * 16 + (threadIdx.x & 15)) : (int)(blockIdx.x * BLOCK + threadIdx.x);
+    const int vtid = REPL ? (int)(lg_wg() * 16 + (threadIdx.x & 15)) : (int)(lg_wg() * BLOCK + threadIdx.x);
     env_step_body<LEGS, PH, false, PROF, JPL, REPL>(p, sMraw, sHot, nullptr, nullptr, vtid, threadIdx.x & 63);
 }
 

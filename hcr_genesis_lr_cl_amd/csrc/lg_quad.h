@@ -345,7 +345,8 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     unsigned long long _stamp0 = 0; (void)_stamp0;
     STAMP(0);
     STAMPB(4096);
-    const int tid = blockIdx.x * BLOCK + threadIdx.x;
+    const int wg = lg_wg();   // XCD-aware (lg_kernel.hip)
+    const int tid = wg * BLOCK + threadIdx.x;
     Lane L;
     L.c = tid & 3; L.is0 = L.c == 0; L.is1 = L.c == 1; L.is2 = L.c == 2; L.is3 = L.c == 3;
     L.d0 = L.is0 ? 1.f : 0.f; L.d1 = L.is1 ? 1.f : 0.f; L.d2 = L.is2 ? 1.f : 0.f;
@@ -476,7 +477,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     }
     if (MPH != 0 && !QTAIL && threadIdx.x < 16) {
         const LgTaskCfg GAS *T = kT;
-        const int lt = blockIdx.x * 16 + (int)threadIdx.x, legL = lt % LEGS, dL = 3 * legL;
+        const int lt = wg * 16 + (int)threadIdx.x, legL = lt % LEGS, dL = 3 * legL;
         const int eL = min(lt / LEGS, N - 1);
         const int flL = legL == 0 ? KINT(k.m_foot_link[0]) : (legL == 1 ? KINT(k.m_foot_link[1]) : (legL == 2 ? KINT(k.m_foot_link[2]) : KINT(k.m_foot_link[3])));
         int fsL = 0;
@@ -509,7 +510,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         sHot[threadIdx.x + 256 + BLOCK] = prw;
         if (!QTAIL && threadIdx.x < 16) {
             const unsigned rm = p.k.reward_mask;
-            const bool leadL = (blockIdx.x * 16 + threadIdx.x) % LEGS == 0;
+            const bool leadL = (wg * 16 + threadIdx.x) % LEGS == 0;
 #pragma unroll
             for (int k = 0; k < LG_R_COUNT; k++) sStF[k * 16 + threadIdx.x] = (leadL && ((rm >> k) & 1u)) ? wsv[k] : 0.f;
 #pragma unroll
@@ -1905,7 +1906,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         // the wave's 64 lanes run the leg-per-lane body as FOUR replicas of its 16 leg-lanes (lane = 16 replica + leg-lane): every replica
         // computes the same values, replica 0 owns the state stores, and the observation section deals its stores over the replicas
         // (the four destinations of an actor-frame entry, the two of a critic entry; blanking with 64 lanes)
-        env_step_body<LEGS, MPH, true, PROF>(p, sMraw, sHot, sStF, sX, blockIdx.x * 16 + ((int)threadIdx.x & 15), (int)threadIdx.x & 15);
+        env_step_body<LEGS, MPH, true, PROF>(p, sMraw, sHot, sStF, sX, wg * 16 + ((int)threadIdx.x & 15), (int)threadIdx.x & 15);
     }
     STAMPB(12288);
 }
