@@ -165,9 +165,19 @@ LG_DEV QM inv_sym(const Lane &L, const QM &m) {
     QM r = {x0 * inv, x1 * inv, x2 * inv};
     return r;
 }
+// LG_PK_F32 (off; kept for the record): the elementwise spatial-vector / 6x6 arithmetic and the rank-1 downdate written as
+// packed FP32 (<2 x float>: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32).  Measured slower -- the pairs cost v_mov_b32 to form and 64-bit
+// tuples to allocate -- and the iterative-ilp build of it crashes clang's register allocator.
+#ifdef LG_PK_F32
+typedef float f2 __attribute__((ext_vector_type(2)));
+LG_DEV QV6 operator+(const QV6 &a, const QV6 &b) { const f2 r = f2{a.a, a.l} + f2{b.a, b.l}; QV6 o = {r.x, r.y}; return o; }
+LG_DEV QV6 operator-(const QV6 &a, const QV6 &b) { const f2 r = f2{a.a, a.l} - f2{b.a, b.l}; QV6 o = {r.x, r.y}; return o; }
+LG_DEV QV6 operator*(const QV6 &a, float s) { const f2 r = f2{a.a, a.l} * f2{s, s}; QV6 o = {r.x, r.y}; return o; }
+#else
 LG_DEV QV6 operator+(const QV6 &a, const QV6 &b) { QV6 r = {a.a + b.a, a.l + b.l}; return r; }
 LG_DEV QV6 operator-(const QV6 &a, const QV6 &b) { QV6 r = {a.a - b.a, a.l - b.l}; return r; }
 LG_DEV QV6 operator*(const QV6 &a, float s) { QV6 r = {a.a * s, a.l * s}; return r; }
+#endif
 LG_DEV float dot6(const QV6 &a, const QV6 &b) { return sum3(a.a * b.a + a.l * b.l); }
 LG_DEV QV6 muli6(const QI6 &I, const QV6 &v) {
 #ifndef LG_NO_DPP_ASM
@@ -183,6 +193,25 @@ LG_DEV QV6 muli6(const QI6 &I, const QV6 &v) {
     return r;
 #endif
 }
+#ifdef LG_PK_F32
+LG_DEV QI6 operator+(const QI6 &a, const QI6 &b) {
+    QI6 r;
+#define LG_PKADD(X, Y) { const f2 t = f2{a.X, a.Y} + f2{b.X, b.Y}; r.X = t.x; r.Y = t.y; }
+    LG_PKADD(A.c0, Bt.c0) LG_PKADD(A.c1, Bt.c1) LG_PKADD(A.c2, Bt.c2) LG_PKADD(B.c0, C.c0) LG_PKADD(B.c1, C.c1) LG_PKADD(B.c2, C.c2)
+#undef LG_PKADD
+    return r;
+}
+// I - U U^T dinv: rows of (A | B) and (B^T | C) share the broadcast operand -> six v_pk_fma_f32
+LG_DEV QI6 rank1_down(const QI6 &I, const QV6 &U, float dinv) {
+    const f2 u = f2{U.a, U.l} * f2{-dinv, -dinv};
+    const float a0 = bc<0>(U.a), a1 = bc<1>(U.a), a2 = bc<2>(U.a), l0 = bc<0>(U.l), l1 = bc<1>(U.l), l2 = bc<2>(U.l);
+    QI6 r;
+#define LG_PKFMA(X, Y, S) { const f2 t = __builtin_elementwise_fma(u, f2{S, S}, f2{I.X, I.Y}); r.X = t.x; r.Y = t.y; }
+    LG_PKFMA(A.c0, Bt.c0, a0) LG_PKFMA(A.c1, Bt.c1, a1) LG_PKFMA(A.c2, Bt.c2, a2) LG_PKFMA(B.c0, C.c0, l0) LG_PKFMA(B.c1, C.c1, l1) LG_PKFMA(B.c2, C.c2, l2)
+#undef LG_PKFMA
+    return r;
+}
+#else
 LG_DEV QI6 operator+(const QI6 &a, const QI6 &b) { QI6 r = {a.A + b.A, a.B + b.B, a.Bt + b.Bt, a.C + b.C}; return r; }
 // I - U U^T dinv
 LG_DEV QI6 rank1_down(const QI6 &I, const QV6 &U, float dinv) {
@@ -195,6 +224,7 @@ LG_DEV QI6 rank1_down(const QI6 &I, const QV6 &U, float dinv) {
     r.C.c0 = I.C.c0 - ul * l0; r.C.c1 = I.C.c1 - ul * l1; r.C.c2 = I.C.c2 - ul * l2;
     return r;
 }
+#endif
 // inverse of an SPD 6x6 by Schur complement on the C block
 LG_DEV QI6 inv6(const Lane &L, const QI6 &N) {
     const QM Ci = inv_sym(L, N.C);
@@ -303,7 +333,11 @@ template <int NJ> LG_DEV QV6 resp_down(const Lane &L, const QJoint (&J)[NJ], con
 // scalars live in lane 3 of the quad, the chain arrays have four entries, the foot body's sole corners take the calf's second sphere
 // slot with the sole law of lg_kernel.hip's sphere_contact.
 template <int LEGS, bool DO_PRE, unsigned MPH, int PROF = 0, int JPL = 3>
+#ifdef LG_PK_F32   // one wave per SIMD by design: let the allocator use the accumulation registers instead of spilling the 64-bit tuples
+__global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1))) void quad_sim_kernel(KParams p) {
+#else
 __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
+#endif
     using namespace q4;
     static_assert(JPL == 3 || (JPL == 4 && LEGS == 2 && MPH == 0 && PROF == 0), "four-joint legs: biped physics only");
     constexpr bool FLAT = PROF == 1, PLANE = PROF == 1 || PROF == 2;   // host-checked task profiles (lg_kernel.hip flat_profile / wtw_profile)
