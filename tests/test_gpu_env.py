@@ -349,6 +349,46 @@ def test_replicated_mdp_launch_is_bit_identical(task, monkeypatch):
         assert torch.equal(sa[k], sb[k]), (task, k)
 
 
+def test_step_gather_packs_strided_windows_and_bool_done_on_device():
+    """distributed.StepGather on the device with what a history task really returns: observation tensors that are strided row
+    windows (go2_wtw: 305 of a wider row), a float reward and a BOOL done -- packed by one torch.cat into the float record, several
+    steps per batch, read back through step_view / split (world 1: the packing, batching and partial flush without a collective;
+    the collective itself is covered on gloo in tests/test_distributed_cpu.py and by the 2-rank rehearsal of bench.py)."""
+    import torch
+    from hcr_genesis_lr_cl_amd.distributed import StepGather
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    N = 64
+    env, _ = make_env("go2_wtw", N, "cuda:0")
+    env.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(2)
+    env.episode_length_buf = torch.randint(990, 1001, (N,), generator=g, device="cuda", dtype=torch.int32)      # some time-outs
+    out = env.step(torch.randn(N, 12, generator=g, device="cuda"))
+    obs_list = [o for o in out[:-3] if o is not None]
+    assert any(o.stride(0) != o.shape[1] for o in obs_list) and out[-2].dtype == torch.bool
+    sg = StepGather(N, [int(o.shape[1]) for o in obs_list], 1, "cuda:0", overlap=True, batch=3)
+    sg.prime()
+    def check(buf, kept, fill=None):
+        for slot, (obs_k, rew_k, done_k) in enumerate(kept):
+            parts, r, d = sg.split(sg.step_view(buf, 0, slot, fill))
+            for a, b in zip(parts, obs_k):
+                assert torch.equal(a, b), slot
+            assert torch.equal(r, rew_k) and d.dtype == torch.bool and torch.equal(d, done_k), slot
+
+    kept, n_done = [], 0
+    for t in range(5):      # 5 steps in batches of 3 (one buffer pair at world 1: a batch is read before the next one overwrites it)
+        out = env.step(torch.randn(N, 12, generator=g, device="cuda") * 2.0)
+        obs_list = [o for o in out[:-3] if o is not None]
+        buf = sg(obs_list, out[-3], out[-2])
+        kept.append(([o.clone() for o in obs_list], out[-3].clone(), out[-2].clone()))
+        n_done += int(out[-2].sum())
+        if t == 2:
+            check(buf, kept)
+            kept = []
+    sg.finish()             # the second batch is flushed partly filled
+    assert sg.last_fill == 2 and n_done > 0
+    check(buf, kept, sg.last_fill)
+
+
 def _obs_tensors(out):
     """(actor obs, critic obs / labels ...) of a step()/reset() result: every tensor-valued observation output."""
     import torch
