@@ -23,6 +23,7 @@ TASK_STATE_WTW = 22
 TASK_STATE_BIPED = 12
 
 PHASE_PRE, PHASE_SIM, PHASE_POST, PHASE_RESET, PHASE_ALL = 1, 2, 4, 8, 15
+FAIL_NONFINITE = 1 << 20      # LG_FAIL_NONFINITE
 
 # alphabetical evaluation order of the reference (helpers.py:10-25); index = enum LgReward
 REWARD_NAMES = [
@@ -164,7 +165,7 @@ _BUF_FIELDS = [
         "reset_buf", "time_out_buf",
         "rew_buf", "obs_buf", "priv_obs_buf", "labels_buf", "obs_dirty",
         "episode_sums", "episode_done_sums", "episode_done_step", "cstr_prob", "cstr_sums", "cstr_done_sums",
-        "command_ranges", "task_state", "rand_in")],
+        "command_ranges", "task_state", "rand_in", "nonfinite_count")],
 ]
 
 

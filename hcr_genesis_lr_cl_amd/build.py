@@ -1,31 +1,106 @@
-"""Builds csrc/liblgsim.so with hipcc for gfx950 (in-tree, so it travels to the GPU box)."""
+"""Builds csrc/liblgsim.so with hipcc for gfx950 (in-tree, so it travels to the GPU box).
+
+The library is 18 translation units: lg_host.hip (C ABI), lg_rollout.hip and lg_inst.hip compiled once per kernel-instantiation group
+(-DLG_GROUP=0..15).  They are compiled in parallel into csrc/obj/ and linked; an object is reused while the sources it depends on and
+the flags are unchanged (content hash), so an edit of lg_quad.h rebuilds the eight component-per-lane groups only."""
+import hashlib
+import json
 import os
 import subprocess
+import sys
+from concurrent.futures import ThreadPoolExecutor
 
 HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC = os.path.join(HERE, "csrc")
-SRC = ["lg_kernel.hip", "lg_rollout.hip"]
+INC = os.path.join(HERE, "..", "include")
+OBJ = os.path.join(CSRC, "obj")
 OUT = os.path.join(CSRC, "liblgsim.so")
+N_GROUPS = 16
+QUAD_GROUPS = range(0, 8)          # lg_inst.hip: groups that include lg_quad.h
+COMMON = ["lg_shared.h", "lg_math.h", os.path.join(INC, "lgsim.h")]
 # -fno-slp-vectorize: packing scalars into v_pk_* costs more v_mov / AGPR shuffles than it saves here.
 # iterative-ilp scheduling: the kernels run one wave per SIMD, so occupancy is irrelevant and the scheduler should fill DPP /
 # VALU->SGPR hazard slots with independent work (measured -3 % on the physics launch, neutral elsewhere).
 EXTRA_FLAGS = os.environ.get("LG_HIPCC_FLAGS", "-fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp").split()
+SIDECAR = os.path.join(CSRC, "liblgsim.build.json")
+FALLBACK_FLAGS = [["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"], ["-fno-slp-vectorize"]]
+
+
+def units():
+    """(object name, source, extra defines, dependencies) of every translation unit."""
+    u = [("lg_host", "lg_host.hip", [], COMMON), ("lg_rollout", "lg_rollout.hip", [], [os.path.join(INC, "lgrollout.h")])]
+    for g in range(N_GROUPS):
+        deps = COMMON + ["lg_kernel.h"] + (["lg_quad.h"] if g in QUAD_GROUPS else [])
+        u.append((f"lg_inst_{g}", "lg_inst.hip", [f"-DLG_GROUP={g}"], deps))
+    return u
+
+
+def _path(f):
+    return f if os.path.isabs(f) else os.path.join(CSRC, f)
+
+
+def source_hash():
+    """Hash of every source the library is built from (csrc/*.hip, csrc/*.h, include/*.h): stamps profiles and the build sidecar."""
+    h = hashlib.sha256()
+    files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
+    files += sorted(os.path.join(INC, f) for f in os.listdir(INC) if f.endswith(".h"))
+    for f in files:
+        h.update(os.path.basename(f).encode())
+        with open(f, "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()[:16]
+
+
+def _unit_key(src, defs, deps, flags):
+    h = hashlib.sha256(" ".join(flags + defs).encode())
+    for f in [src] + list(deps):
+        with open(_path(f), "rb") as fh:
+            h.update(fh.read())
+    return h.hexdigest()
 
 
 def needs_build():
     if not os.path.exists(OUT):
         return True
-    deps = [os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h"))]
-    deps.append(os.path.join(HERE, "..", "include", "lgsim.h"))
-    deps.append(os.path.join(HERE, "..", "include", "lgrollout.h"))
-    return any(os.path.getmtime(d) > os.path.getmtime(OUT) for d in deps)
+    try:
+        with open(SIDECAR) as f:
+            return json.load(f).get("source_hash") != source_hash()
+    except (OSError, ValueError):
+        return True
 
 
-SIDECAR = os.path.join(CSRC, "liblgsim.build.json")
-FALLBACK_FLAGS = [["-fno-slp-vectorize", "-mllvm", "-amdgpu-sched-strategy=max-ilp"], ["-fno-slp-vectorize"]]
+def _compile_all(hipcc, flags, force, jobs, verbose):
+    """Compile every stale unit (in parallel); returns (object paths, first error text or '')."""
+    os.makedirs(OBJ, exist_ok=True)
+    todo, objs = [], []
+    for name, src, defs, deps in units():
+        obj, keyf = os.path.join(OBJ, name + ".o"), os.path.join(OBJ, name + ".key")
+        key = _unit_key(src, defs, deps, flags)
+        objs.append(obj)
+        old = open(keyf).read() if os.path.exists(keyf) and os.path.exists(obj) else ""
+        if force or old != key:
+            todo.append((name, [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", *flags, *defs, "-c", _path(src), "-o", obj], keyf, key))
+
+    def run(t):
+        name, cmd, keyf, key = t
+        if os.path.exists(keyf):
+            os.remove(keyf)
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode == 0:
+            with open(keyf, "w") as f:
+                f.write(key)
+        if verbose:
+            print(f"build.py: {name}: rc {r.returncode}", file=sys.stderr)
+        return name, r
+    err = ""
+    with ThreadPoolExecutor(max_workers=jobs) as ex:
+        for name, r in ex.map(run, todo):
+            if r.returncode != 0 and not err:
+                err = f"[{name}] " + r.stderr
+    return objs, err
 
 
-def build(force=False, verbose=False, allow_fallback=None):
+def build(force=False, verbose=False, allow_fallback=None, jobs=None):
     """Compile csrc/liblgsim.so.  The flags actually used are written next to it (liblgsim.build.json) and echoed by bench.py
     in its JSON line, so the scheduling strategy of a measured binary is on record.
 
@@ -35,37 +110,40 @@ def build(force=False, verbose=False, allow_fallback=None):
     on the bench) and records `"fallback": true` plus the compiler's error in the sidecar."""
     if not force and not needs_build():
         return OUT
-    import json
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if allow_fallback is None:
         allow_fallback = os.environ.get("LG_ALLOW_FLAG_FALLBACK", "0") == "1"
+    if jobs is None:
+        jobs = int(os.environ.get("LG_BUILD_JOBS", str(min(8, os.cpu_count() or 1))))
     attempts = [EXTRA_FLAGS]
     if allow_fallback and "LG_HIPCC_FLAGS" not in os.environ:
         attempts += FALLBACK_FLAGS
-    first_err, r = "", None
+    first_err, done = "", False
     for flags in attempts:
-        cmd = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-shared", "-std=c++17", *flags,
-               "-o", OUT] + [os.path.join(CSRC, s) for s in SRC]
-        r = subprocess.run(cmd, capture_output=True, text=True)
-        if r.returncode == 0:
+        objs, err = _compile_all(hipcc, flags, force, jobs, verbose)
+        if not err:
+            r = subprocess.run([hipcc, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", OUT, *objs], capture_output=True, text=True)
+            err = r.stderr if r.returncode != 0 else ""
+        if not err:
             fell = flags is not attempts[0]
             if fell:
-                import sys
                 print("build.py: primary flags failed, compiled with FALLBACK flags " + " ".join(flags), file=sys.stderr)
             ver = subprocess.run([hipcc, "--version"], capture_output=True, text=True).stdout.splitlines()
             with open(SIDECAR, "w") as f:
                 json.dump({"flags": ["--offload-arch=gfx950", "-O3", *flags], "fallback": fell,
                            "primary_flags": EXTRA_FLAGS, "primary_error": first_err[-1500:] if fell else "",
-                           "hipcc": next((l for l in ver if "HIP version" in l), ver[0] if ver else "")}, f, indent=1)
+                           "hipcc": next((l for l in ver if "HIP version" in l), ver[0] if ver else ""),
+                           "source_hash": source_hash(), "translation_units": len(objs)}, f, indent=1)
+            done = True
             break
-        first_err = first_err or r.stderr
-    if r.returncode != 0:
+        first_err = first_err or err
+    if not done:
         raise RuntimeError("hipcc failed" + ("" if allow_fallback else " (no flag fallback: set LG_ALLOW_FLAG_FALLBACK=1 to retry with the "
                            "max-ilp / default scheduler)") + ":\n" + first_err[-4000:])
-    if verbose:
-        print(r.stderr)
     return OUT
 
 
 if __name__ == "__main__":
-    print(build(force=True, verbose=True))
+    import time
+    t0 = time.time()
+    print(build(force="--force" in sys.argv, verbose=True), f"{time.time() - t0:.0f} s")

@@ -1,0 +1,69 @@
+// lg_inst.hip -- the kernel instantiations of the library, compiled once per GROUP (hipcc -DLG_GROUP=g ... -c, the groups in parallel;
+// hcr_genesis_lr_cl_amd/build.py).  One translation unit holding all of them took over three minutes to build; a group is a
+// handful of kernels that share template parameters.  Groups 0-7 hold the component-per-lane kernels (lg_quad.h), groups 8-15 the
+// leg-per-lane ones (lg_kernel.h) and do not include lg_quad.h, so an edit there leaves their objects valid.
+//
+// The host side (lg_host.hip) calls the launchers declared in lg_shared.h; every instantiation it names must appear in exactly
+// one group below (a missing one is a link error, not a run-time surprise).
+#ifndef LG_GROUP
+#error "compile with -DLG_GROUP=<0..15> (hcr_genesis_lr_cl_amd/build.py)"
+#endif
+#include "lg_kernel.h"
+#if LG_GROUP < 8
+#include "lg_quad.h"
+
+template <int LEGS, bool PRE, unsigned MPH, int PROF, int JPL>
+void lg_launch_quad(dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const KParams &p) {
+    if (e0 || e1) hipExtLaunchKernelGGL((quad_sim_kernel<LEGS, PRE, MPH, PROF, JPL>), grid, dim3(BLOCK), 0, st, e0, e1, 0, p);
+    else hipLaunchKernelGGL((quad_sim_kernel<LEGS, PRE, MPH, PROF, JPL>), grid, dim3(BLOCK), 0, st, p);
+}
+#define QUAD(...) template void lg_launch_quad<__VA_ARGS__>(dim3, hipStream_t, hipEvent_t, hipEvent_t, const KParams &);
+#else
+template <int LEGS, unsigned PH, int PROF, int JPL, bool REPL>
+void lg_launch_env(dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const KParams &p) {
+    if (e0 || e1) hipExtLaunchKernelGGL((env_step_kernel<LEGS, PH, PROF, JPL, REPL>), grid, dim3(BLOCK), 0, st, e0, e1, 0, p);
+    else hipLaunchKernelGGL((env_step_kernel<LEGS, PH, PROF, JPL, REPL>), grid, dim3(BLOCK), 0, st, p);
+}
+#define ENV(...) template void lg_launch_env<__VA_ARGS__>(dim3, hipStream_t, hipEvent_t, hipEvent_t, const KParams &);
+// the phase combinations lg_step accepts besides ALL (15) and POST | RESET (12), for one robot shape
+#define ENV_PHASES(LEGS, JPL) ENV(LEGS, 2u, 0, JPL, false) ENV(LEGS, 3u, 0, JPL, false) ENV(LEGS, 4u, 0, JPL, false) ENV(LEGS, 5u, 0, JPL, false) \
+                              ENV(LEGS, 7u, 0, JPL, false) ENV(LEGS, 8u, 0, JPL, false)
+#endif
+
+// ---- component per lane: quad_sim_kernel<LEGS, PRE, MDP phases in the tail, PROF, JPL> ----
+#if LG_GROUP == 0      // go2 on the plane, whole step in one launch (the headline kernel); PRE | SIM | POST of the generic tail
+QUAD(4, true, 12u, 1, 3) QUAD(4, true, 4u, 0, 3)
+#elif LG_GROUP == 1    // go2_wtw, whole step
+QUAD(4, true, 12u, 2, 3)
+#elif LG_GROUP == 2    // go2_ee, whole step
+QUAD(4, true, 12u, 3, 3)
+#elif LG_GROUP == 3    // go2_ts / go2_cts / go2_dreamwaq (observation programs), whole step
+QUAD(4, true, 12u, 4, 3)
+#elif LG_GROUP == 4    // any other quadruped task, whole step (leg-per-lane MDP body in the tail)
+QUAD(4, true, 12u, 0, 3)
+#elif LG_GROUP == 5    // quadruped physics only (go2_cat, split launches of the tests)
+QUAD(4, true, 0u, 0, 3) QUAD(4, true, 0u, 3, 3) QUAD(4, false, 0u, 0, 3) QUAD(4, false, 0u, 3, 3)
+#elif LG_GROUP == 6    // biped physics (three joints per leg)
+QUAD(2, true, 0u, 0, 3) QUAD(2, true, 0u, 3, 3) QUAD(2, false, 0u, 0, 3) QUAD(2, false, 0u, 3, 3)
+#elif LG_GROUP == 7    // biped physics (four joints per leg: TRON1 sole foot)
+QUAD(2, true, 0u, 0, 4) QUAD(2, false, 0u, 0, 4)
+// ---- leg per lane: env_step_kernel<LEGS, PHASES, PROF, JPL, REPL> ----
+#elif LG_GROUP == 8    // whole step, quadruped (large batches)
+ENV(4, 15u, 0, 3, false) ENV(4, 15u, 1, 3, false)
+#elif LG_GROUP == 9    // whole step, biped
+ENV(2, 15u, 0, 3, false) ENV(2, 15u, 1, 3, false) ENV(2, 15u, 0, 4, false)
+#elif LG_GROUP == 10   // MDP phases behind a physics launch, quadruped
+ENV(4, 12u, 0, 3, false) ENV(4, 12u, 0, 3, true) ENV(4, 13u, 0, 3, false)
+#elif LG_GROUP == 11   // ... biped
+ENV(2, 12u, 0, 3, false) ENV(2, 12u, 0, 3, true) ENV(2, 13u, 0, 3, false)
+#elif LG_GROUP == 12   // ... sole-foot biped
+ENV(2, 12u, 0, 4, false) ENV(2, 12u, 0, 4, true) ENV(2, 13u, 0, 4, false)
+#elif LG_GROUP == 13   // single phases and their other combinations (golden replays, glue tests), quadruped
+ENV_PHASES(4, 3)
+#elif LG_GROUP == 14   // ... biped
+ENV_PHASES(2, 3)
+#elif LG_GROUP == 15   // ... sole-foot biped
+ENV_PHASES(2, 4)
+#else
+#error "LG_GROUP out of range"
+#endif

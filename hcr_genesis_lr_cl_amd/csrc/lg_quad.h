@@ -1,4 +1,4 @@
-// lg_quad.h -- physics phase with ONE VECTOR COMPONENT PER LANE (included by lg_kernel.hip).
+// lg_quad.h -- physics phase with ONE VECTOR COMPONENT PER LANE (included by lg_kernel.h).
 //
 // Why a second layout: the headline workload is 4096 envs per GPU.  With one leg per lane that is 256 waves on
 // a chip with 1024 SIMDs -- three SIMDs of every CU idle while the fourth walks a ~20 k-instruction serial
@@ -21,7 +21,7 @@
 // four-joint legs (JPL = 4) the fourth joint's scalars; reductions are only formed in lanes 0-2, so what lane 3 needs from one
 // is fetched from lane 0.
 //
-// Algorithm = lg_kernel.hip's SIM phase statement for statement (same world-aligned ABA about the base origin,
+// Algorithm = lg_kernel.h's SIM phase statement for statement (same world-aligned ABA about the base origin,
 // same contact / limit laws); tests/test_gpu_physics.py checks both layouts against the same f64 CPU restatement.
 #pragma once
 
@@ -306,7 +306,7 @@ template <bool HF = false> LG_DEV void terrain(const Terr &T, float x, float y, 
     nx = -hx * inv; ny = -hy * inv; nz = inv;
 }
 
-// response sweeps (see resp_up / resp_down in lg_kernel.hip); du replicated, tl / dqdd in joint lanes
+// response sweeps (see resp_up / resp_down in lg_kernel.h); du replicated, tl / dqdd in joint lanes
 template <int NJ> LG_DEV QV6 resp_up(const QJoint (&J)[NJ], const QV6 &fspat, float tl, float (&du)[NJ]) {
     QV6 dp = {-fspat.a, -fspat.l};
 #pragma unroll
@@ -331,7 +331,7 @@ template <int NJ> LG_DEV QV6 resp_down(const Lane &L, const QJoint (&J)[NJ], con
 // ramp-up, tables already in LDS.  The hand-off goes through the state arrays themselves (written above, L2-hot).
 // JPL = 4 (TRON1 sole foot: two legs of four joints, physics only -- its MDP phases are the leg-per-lane launch): the fourth joint's
 // scalars live in lane 3 of the quad, the chain arrays have four entries, the foot body's sole corners take the calf's second sphere
-// slot with the sole law of lg_kernel.hip's sphere_contact.
+// slot with the sole law of lg_kernel.h's sphere_contact.
 template <int LEGS, bool DO_PRE, unsigned MPH, int PROF = 0, int JPL = 3>
 #ifdef LG_PK_F32   // one wave per SIMD by design: let the allocator use the accumulation registers instead of spilling the 64-bit tuples
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1))) void quad_sim_kernel(KParams p) {
@@ -340,7 +340,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
 #endif
     using namespace q4;
     static_assert(JPL == 3 || (JPL == 4 && LEGS == 2 && MPH == 0 && PROF == 0), "four-joint legs: biped physics only");
-    constexpr bool FLAT = PROF == 1, PLANE = PROF == 1 || PROF == 2;   // host-checked task profiles (lg_kernel.hip flat_profile / wtw_profile)
+    constexpr bool FLAT = PROF == 1, PLANE = PROF == 1 || PROF == 2;   // host-checked task profiles (lg_kernel.h flat_profile / wtw_profile)
     constexpr int A = JPL * LEGS;
     // The kernel argument block (KParams, ~800 B of pointers) through ONE vector load: lane i holds bytes [16 i, 16 i + 16).
     // Fetched with scalar loads it arrives as a dozen dependent dwordx16 chunks (SGPR pressure), each a device-memory round
@@ -379,7 +379,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     unsigned long long _stamp0 = 0; (void)_stamp0;
     STAMP(0);
     STAMPB(4096);
-    const int wg = lg_wg();   // XCD-aware (lg_kernel.hip)
+    const int wg = lg_wg();   // XCD-aware (lg_kernel.h)
     const int tid = wg * BLOCK + threadIdx.x;
     Lane L;
     L.c = tid & 3; L.is0 = L.c == 0; L.is1 = L.c == 1; L.is2 = L.c == 2; L.is3 = L.c == 3;
@@ -458,7 +458,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     const float origin = k_env_origins ? k_env_origins[3 * e + cj] : 0.f;
     int crv = 0;
     if (MPH != 0) crv = reinterpret_cast<const int GAS *>(k_command_ranges)[min((int)threadIdx.x, LG_CMD_RANGE_FLOATS - 1)];
-    int prw = 0;   // observation programs for the MDP tail (lg_kernel.hip PRG_I / PRG_F)
+    int prw = 0;   // observation programs for the MDP tail (lg_kernel.h PRG_I / PRG_F)
     if ((MPH & LG_PHASE_RESET) != 0 && (PROF == 4 || (PROF == 0 && KINT(k.obs_layout) == LG_OBS_PROGRAM))) {
         const int tl = (int)threadIdx.x;
         prw = reinterpret_cast<const int GAS *>(tl < 26 ? &kT->priv_prog : &kT->labels_prog)[tl < 26 ? tl : min(tl - 26, 25)];
@@ -578,7 +578,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     Terr TR;
     TR.rows = PLANE ? 0 : HOT(o_terrain_rows); TR.cols = HOT(o_terrain_cols); TR.border = HOT(o_border); TR.ihs = 1.f / HOT(o_hscale);
     TR.vscale = HOT(o_vscale); TR.hf = p.hf;
-    constexpr bool HFC = PROF == 3 || PROF == 4;   // rough task profiles: a heightfield is bound (lg_kernel.hip rough_profile)
+    constexpr bool HFC = PROF == 3 || PROF == 4;   // rough task profiles: a heightfield is bound (lg_kernel.h rough_profile)
     const bool hfmode = HFC ? true : (!PLANE && TR.rows > 0);
     const float mass0 = M->mass[0] + dr_mass;
     const float com0 = M->com[0][cj] + dr_com;
@@ -714,7 +714,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                            bc<0>(V.a), bc<1>(V.a), bc<2>(V.a), bc<0>(V.l), bc<1>(V.l), bc<2>(V.l)};
                 return g;
             };
-            // `sole` (four-joint legs, slot 3): the sole law of lg_kernel.hip's sphere_contact -- inverse mass = sph_w + twice the
+            // `sole` (four-joint legs, slot 3): the sole law of lg_kernel.h's sphere_contact -- inverse mass = sph_w + twice the
             // ankle joint's own compliance at the contact point, approach velocity relative to the sole centre's (vref)
             struct Sole { float sax, say, saz, slx, sly, slz, dinv, vref; };
             auto force = [&](int k, Hit t, const BodyS &g, float (&m)[3], float (&f)[3], const Sole *sole = nullptr) {
@@ -963,7 +963,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                     const float A00 = bc<0>(Ac.c0), A01 = bc<0>(Ac.c1), A02 = bc<0>(Ac.c2);   // DPP stays outside the branch
                     const float ft2 = f1 * f1 + f2 * f2, iftn = rsqrtf(ft2), ftn = ft2 * iftn;
                     const float e1 = f1 * iftn, e2 = f2 * iftn;
-                    // friction coupling limited to 3/4 of A_nn (frictional jamming; see lg_kernel.hip / oracle/lg_oracle.c)
+                    // friction coupling limited to 3/4 of A_nn (frictional jamming; see lg_kernel.h / oracle/lg_oracle.c)
                     const float aeff = fmaxf(A00 + mu * (A01 * e1 + A02 * e2), 0.25f * A00);
                     const float fn = rn * rcp(1.f + kappa * aeff);
                     if (ftn > mu * f0) { ok = ok && fn > 0.f; f0 = fn; f1 = mu * fn * e1; f2 = mu * fn * e2; }
@@ -1028,6 +1028,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         if (__builtin_amdgcn_ballot_w64(stj && fabsf(qd) > 4.0f) != 0ull && threadIdx.x == 0) B.command_ranges[LG_CR_ANY_FAST + (int)(p.counter & 1)] = 1.0f;
     }
     // ---------------- read-back (genesis_simulator.py:35-60) ---------------------------------------
+    int guard_bad = 0;
     {   // non-finite guard: re-seat the robot
         const float chk = quat + (L.is3 ? (JPL == 4 ? q + qd : 0.f) : pos + vw + ww + q + qd);
         const int bad = env_or<LEGS>(isfinite(chk) ? 0 : 1);
@@ -1036,7 +1037,13 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             pos = reseat; vw = 0.f; ww = 0.f; quat = L.is3 ? 1.f : 0.f;
             q = q0; qd = 0.f; torque = 0.f;
             f_link[0] = f_link[1] = f_link[2] = f_link[3] = 0.f; f_base = 0.f;
+            // never silent: counted, and the env terminates at this step's check_termination (fail_buf over the threshold)
+            if (lead && L.is0) {
+                if (B.nonfinite_count) atomicAdd(B.nonfinite_count, 1);
+                if (MPH == 0 && B.fail_buf) B.fail_buf[e] = LG_FAIL_NONFINITE;   // the MDP launch that follows reads it
+            }
         }
+        guard_bad = bad;
         // out-of-terrain teleport (genesis_simulator.py:612-628)
         const float px = bc<0>(pos), py = bc<1>(pos);
         if (px >= HOT(o_bound_x[1]) || px <= HOT(o_bound_x[0]) || py >= HOT(o_bound_y[1]) || py <= HOT(o_bound_y[0])) pos = reseat;
@@ -1409,6 +1416,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         fail = __builtin_amdgcn_update_dpp(0, fail, 0x128, 0xF, 0xF, true) | fail;
         fail |= ((tmask & 1u) && nb2 > 100.0f) ? 1 : 0;
         fail |= pgz > h_max_projected_gravity ? 1 : 0;
+        if (guard_bad) failb = LG_FAIL_NONFINITE;   // a re-seated env ends its episode here (lgsim.h)
         failb += fail;
         const bool time_out = (float)ep_len > h_max_episode_length;
         const bool reset = ((float)failb > h_fail_threshold) || time_out;
@@ -1644,7 +1652,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const int FR = h_obs_frame, PF = h_priv_frame, ST = h_obs_stack, PST = h_priv_stack, SL = h_obs_slack;
             const size_t orow = (size_t)(h_num_obs + SL * FR), prow = (size_t)(h_num_priv_obs + SL * PF);
             const bool two = h_obs_sets > 1;
-            const int cs = two ? p.obs_set : 0, xs = two ? 1 - cs : 0;
+            const int cs = two ? p.obs_set : 0, xs = (two && cs < 2) ? 1 - cs : cs;   // the other copy (two sets); with more sets nothing is stacked and xs is unused
             float *oc = B.obs_buf + ((size_t)cs * N + e) * orow + (size_t)p.obs_win * FR;
             float *ox = B.obs_buf + ((size_t)xs * N + e) * orow + (size_t)p.obs_win * FR;
             float *pc = B.priv_obs_buf + ((size_t)cs * N + e) * prow + (size_t)p.obs_win * PF;
@@ -1801,7 +1809,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const int FR = h_obs_frame, PF = h_priv_frame, ST = h_obs_stack, PST = h_priv_stack, SL = h_obs_slack;
             const size_t orow = (size_t)(h_num_obs + SL * FR), prow = (size_t)(h_num_priv_obs + SL * PF);
             const bool two = h_obs_sets > 1;
-            const int cs = two ? p.obs_set : 0, xs = two ? 1 - cs : 0;
+            const int cs = two ? p.obs_set : 0, xs = (two && cs < 2) ? 1 - cs : cs;   // the other copy (two sets); with more sets nothing is stacked and xs is unused
             float *oc = B.obs_buf + ((size_t)cs * N + e) * orow + (size_t)p.obs_win * FR;
             float *ox = B.obs_buf + ((size_t)xs * N + e) * orow + (size_t)p.obs_win * FR;
             float *pc = B.priv_obs_buf + ((size_t)cs * N + e) * prow + (size_t)p.obs_win * PF;
@@ -1919,7 +1927,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     }
     // ---------------- MDP phases in the same launch (every other task): leg-per-lane body on the first 16 lanes -----
     if (MPH != 0 && !QTAIL) {
-        // hand the results to the MDP phases through LDS (layout: lg_kernel.hip, XA .. XFB): leg-lane l of the tail is quad l
+        // hand the results to the MDP phases through LDS (layout: lg_kernel.h, XA .. XFB): leg-lane l of the tail is quad l
         // of this wave; a quad lane writes its own component.  Nothing the tail reads then comes from the arrays stored
         // above, so those stores drain in the background instead of being waited for.
         __shared__ float sX[NX * 16];
@@ -1931,6 +1939,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             XW(XFP, foot_p); XW(XFV, foot_v); XW(XLFV, last_foot_v);
             XW(XPOS, pos); XW(XVW, vw); XW(XWW, ww); XW(XBLV, blv); XW(XBAV, bav); XW(XPG, pg); XW(XEUL, eul); XW(XFB, f_base);
             sX[(XQUAT + L.c) * 16 + qi] = quat;
+            if (L.is0) sX[XBAD * 16 + qi] = guard_bad ? 1.f : 0.f;
         }
         // terrain samples (heightfield only) still travel through measured_heights / height_around_feet: a workgroup-scope
         // fence (the workgroup is this wave; the CU's L1 is coherent with its own stores) makes them visible.  An

@@ -10,7 +10,7 @@
 #include "../../include/lgrollout.h"
 
 extern "C" const char *lg_last_error(void);
-int lg_fail_msg(const std::string &m);   // lg_kernel.hip: sets the thread-local message, returns 1
+int lg_fail_msg(const std::string &m);   // lg_host.hip: sets the thread-local message, returns 1
 
 struct RecordArgs {
     int n; const float *rew; const uint8_t *reset, *time_outs; const float *values; float gamma; float *rewards; uint8_t *dones;

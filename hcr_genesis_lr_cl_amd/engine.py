@@ -130,6 +130,7 @@ class Engine:
         self.buf["episode_done_sums"] = torch.zeros((abi.R_COUNT, self.n), device=self.device)
         self.buf["episode_done_step"] = torch.full((self.n,), -1, dtype=torch.int32, device=self.device)
         self.buf["command_ranges"] = torch.zeros(abi.CMD_RANGE_FLOATS, device=self.device)
+        self.buf["nonfinite_count"] = torch.zeros(1, dtype=torch.int32, device=self.device)   # LgBuffers.nonfinite_count
         if int(task.cat_enable):
             self.buf["cstr_prob"] = torch.zeros(self.n, device=self.device)
             self.buf["cstr_sums"] = torch.zeros((abi.NUM_CSTR, self.n), device=self.device)
@@ -237,6 +238,11 @@ class Engine:
         abi.check(self.lib.lg_obs_set_select(self.handle, int(s_)), self.lib)
         abi.check(self.lib.lg_obs_window_select(self.handle, int(w)), self.lib)
         self._refresh_obs_slot()
+
+    def nonfinite_count(self):
+        """Envs re-seated by the non-finite guard of the physics phase so far (include/lgsim.h LgBuffers.nonfinite_count): 0 in a healthy
+        run.  Synchronises."""
+        return int(self.buf["nonfinite_count"].item())
 
     def profile(self, stride):
         """Time the physics kernel of every `stride`-th step with HIP events (0 = off)."""

@@ -419,7 +419,7 @@ def compile_urdf(path, dof_names, links_to_keep, foot_name, base_link_name=None,
             # the foot is the chain's last body itself (sole foot): its first sphere is the sole centre (_sole_spheres)
             if not cand:
                 raise ValueError(f"foot body {link_names[li]} has no collision geometry")
-            # sole corners: the kernel adds the ankle joint's own compliance at the contact point (lg_kernel.hip sphere_contact);
+            # sole corners: the kernel adds the ankle joint's own compliance at the contact point (lg_kernel.h sphere_contact);
             # what is stored here covers every other way the corner can give: shank + foot as a point mass
             for i in cand[1:]:
                 sph_w[i] = 1.0 / (mass[b] + mass[b - 1])

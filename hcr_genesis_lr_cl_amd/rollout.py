@@ -2,7 +2,8 @@
 
 Mirrors the reference's rsl_rl/storage/rollout_storage.py: same constructor, same tensors under the same names and shapes
 ((T, N, width) float32; dones (T, N, 1) uint8), `add_transitions`, `clear`, `compute_returns`, `get_statistics`,
-`mini_batch_generator` -- so rsl_rl's PPO takes it in place of its own.  What changes is how the rows are filled:
+`mini_batch_generator` -- so rsl_rl's PPO with a feed-forward ActorCritic takes it in place of its own (recurrent policies are refused:
+hidden states are not stored).  What changes is how the rows are filled:
 
   * `record(t-less API: add_step)`: reward (with the time-out bootstrap of rsl_rl/algorithms/ppo.py:106-113), done flag and any
     observation rows in ONE launch (`lg_rollout_record`) instead of nine `copy_` launches (rollout_storage.py:92-100);
@@ -130,6 +131,10 @@ class RolloutStorage:
         t = self.step
         if t >= self.num_transitions_per_env:
             raise AssertionError("Rollout buffer overflow")
+        hs = getattr(transition, "hidden_states", None)
+        if hs is not None and tuple(hs) != (None, None):
+            raise NotImplementedError("hidden states (recurrent ActorCritic, rollout_storage.py:101-122) are not stored here: "
+                                      "use rsl_rl's own RolloutStorage for recurrent policies")
         self.actions[t].copy_(transition.actions)
         self.values[t].copy_(transition.values)
         self.actions_log_prob[t].copy_(transition.actions_log_prob.view(-1, 1))
@@ -152,25 +157,28 @@ class RolloutStorage:
                                           self.dones.data_ptr(), lv.data_ptr(), float(gamma), float(lam), self.returns.data_ptr(),
                                           self.advantages.data_ptr(), self._scratch.data_ptr(), stream), self.lib)
 
-    def get_statistics(self):              # rollout_storage.py:140-146
-        done = self.dones
-        done[-1] = 1
-        flat_dones = done.permute(1, 0, 2).reshape(-1, 1)
-        done_indices = torch.cat((flat_dones.new_tensor([-1], dtype=torch.int64), flat_dones.nonzero(as_tuple=False)[:, 0]))
-        trajectory_lengths = (done_indices[1:] - done_indices[:-1])
-        return trajectory_lengths.float().mean(), self.rewards.mean()
+    def get_statistics(self):
+        """(mean trajectory length, mean reward) of the stored rollout -- what rollout_storage.py:140-146 reports: a trajectory ends at
+        a done flag or at the last stored step.  Leaves `dones` untouched."""
+        ends = self.dones.squeeze(-1).t().bool().clone()        # (N, T), env-major like the reference's flattening
+        ends[:, -1] = True
+        idx = torch.nonzero(ends.reshape(-1)).squeeze(1)
+        lengths = torch.diff(idx, prepend=idx.new_full((1,), -1))
+        return lengths.float().mean(), self.rewards.mean()
 
-    def mini_batch_generator(self, num_mini_batches, num_epochs=8):     # rollout_storage.py:148-186
-        batch_size = self.num_envs * self.num_transitions_per_env
-        mini_batch_size = batch_size // num_mini_batches
-        indices = torch.randperm(num_mini_batches * mini_batch_size, requires_grad=False, device=self.device)
-        observations = self.observations.flatten(0, 1)
-        critic_observations = self.privileged_observations.flatten(0, 1) if self.privileged_observations is not None else observations
-        actions, values, returns = self.actions.flatten(0, 1), self.values.flatten(0, 1), self.returns.flatten(0, 1)
-        old_actions_log_prob, advantages = self.actions_log_prob.flatten(0, 1), self.advantages.flatten(0, 1)
-        old_mu, old_sigma = self.mu.flatten(0, 1), self.sigma.flatten(0, 1)
-        for epoch in range(num_epochs):
-            for i in range(num_mini_batches):
-                b = indices[i * mini_batch_size:(i + 1) * mini_batch_size]
-                yield observations[b], critic_observations[b], actions[b], values[b], advantages[b], returns[b], \
-                    old_actions_log_prob[b], old_mu[b], old_sigma[b], (None, None), None
+    def mini_batch_generator(self, num_mini_batches, num_epochs=8):
+        """Mini-batches in the tuple order rsl_rl's PPO.update unpacks (rollout_storage.py:148-186): obs, critic obs, actions, target
+        values, advantages, returns, old log-prob, old mean, old std, hidden states (None, None), masks None.  One random permutation of
+        the T x N samples per call, cut into `num_mini_batches` equal index blocks and replayed every epoch."""
+        flat = {k: getattr(self, k).flatten(0, 1) for k in
+                ("observations", "actions", "values", "advantages", "returns", "actions_log_prob", "mu", "sigma")}
+        flat["critic"] = self.privileged_observations.flatten(0, 1) if self.privileged_observations is not None else flat["observations"]
+        order = ("observations", "critic", "actions", "values", "advantages", "returns", "actions_log_prob", "mu", "sigma")
+        per = (self.num_envs * self.num_transitions_per_env) // num_mini_batches
+        blocks = torch.randperm(num_mini_batches * per, device=self.device).view(num_mini_batches, per)
+        for _ in range(num_epochs):
+            for b in blocks:
+                yield (*(flat[k][b] for k in order), (None, None), None)
+
+    def reccurent_mini_batch_generator(self, num_mini_batches, num_epochs=8):
+        raise NotImplementedError("recurrent policies are outside the hot path (SURVEY 8): use rsl_rl's own RolloutStorage for them")

@@ -316,7 +316,12 @@ typedef struct LgBuffers {
     float *command_ranges;            /* (LG_CMD_RANGE_FLOATS): vx lo/hi, vy lo/hi, yaw lo/hi, heading lo/hi */
     float *task_state;                /* task specific per-env block (gait phase ...), may be NULL */
     const float *rand_in;             /* (N, slots.n_slots) injected uniforms, NULL => Philox */
+    int32_t *nonfinite_count;         /* (1) may be NULL: envs whose state came out of the physics non-finite (NaN / Inf) since the caller
+                                         last cleared it.  Such an env is re-seated at its origin AND its fail_buf is raised to
+                                         LG_FAIL_NONFINITE, so that check_termination ends the episode in the same step (reset_buf = 1,
+                                         not a time-out): the guard is never silent */
 } LgBuffers;
+#define LG_FAIL_NONFINITE (1 << 20)   /* fail_buf value of an env re-seated by the non-finite guard (far above any fail threshold) */
 
 /* phases of one LeggedRobot.step (legged_robot.py:37-76) a launch may cover */
 #define LG_PHASE_PRE 1    /* _pre_sim_step: clip + action history (legged_robot.py:230-239) */

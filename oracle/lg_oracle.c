@@ -671,6 +671,12 @@ static void env_step(const LgModelDesc *m, const LgSimOptions *o, const int16_t 
             quat[0] = quat[1] = quat[2] = 0; quat[3] = 1;
             for (int k = 0; k < nd; k++) { q[k] = o->default_dof_pos[k]; qd[k] = 0; torque_raw[k] = 0; }
             memset(link_f, 0, sizeof(link_f));
+            /* never silent (lgsim.h LgBuffers.nonfinite_count): counted, and the episode ends at this step's check_termination */
+            if (B->nonfinite_count) {
+#pragma omp atomic
+                (*B->nonfinite_count)++;
+            }
+            if (B->fail_buf) B->fail_buf[e] = LG_FAIL_NONFINITE;
         }
     }
     if (pos[0] >= o->bound_x[1] || pos[0] <= o->bound_x[0] || pos[1] >= o->bound_y[1] || pos[1] <= o->bound_y[0])
