@@ -84,7 +84,7 @@ class LgSimOptions(C.Structure):
         ("kp", f32 * MAX_DOF), ("kd", f32 * MAX_DOF), ("default_dof_pos", f32 * MAX_DOF),
         ("base_init_pos", f32 * 3), ("bound_x", f32 * 2), ("bound_y", f32 * 2),
         ("terrain_rows", i32), ("terrain_cols", i32), ("hscale", f32), ("vscale", f32), ("border", f32),
-        ("n_height_points", i32), ("feet_terrain_info", i32), ("sim_layout", i32),
+        ("n_height_points", i32), ("feet_terrain_info", i32), ("sim_layout", i32), ("contact_w_every", i32),
     ]
 
 
@@ -250,6 +250,8 @@ def load_lib():
     lib.lg_profile_read.argtypes = [H, C.POINTER(C.c_float), C.POINTER(i32)]
     lib.lg_philox.argtypes = [C.POINTER(u32 * 4), C.POINTER(u32 * 2), C.POINTER(u32 * 4)]
     lib.lg_philox.restype = C.c_int
+    lib.lg_stream_copy.argtypes = [C.c_void_p, C.c_void_p, i64, i32, C.c_void_p, C.POINTER(C.c_float)]
+    lib.lg_stream_copy.restype = C.c_int
     lib.lg_rollout_record.argtypes = [i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, f32, C.c_void_p, C.c_void_p,
                                       C.POINTER(LgRowCopy), i32, C.c_void_p]
     lib.lg_rollout_gae.argtypes = [i32, i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, f32, f32, C.c_void_p, C.c_void_p,
@@ -265,7 +267,7 @@ def load_lib():
 
 
 EXPORTS = ["lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step",
-           "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_obs_set_select", "lg_obs_window_select", "lg_profile", "lg_profile_read", "lg_philox", "lg_last_error",
+           "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_obs_set_select", "lg_obs_window_select", "lg_profile", "lg_profile_read", "lg_philox", "lg_stream_copy", "lg_last_error",
            "lg_abi_version"]
 ROLLOUT_EXPORTS = ["lg_rollout_record", "lg_rollout_gae"]          # include/lgrollout.h
 ROLLOUT_MAX_COPIES = 8

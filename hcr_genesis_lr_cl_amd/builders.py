@@ -31,6 +31,7 @@ def make_sim_options(model, cfg, terrain=None):
     o.terrain_friction = cfg.terrain.static_friction  # genesis_simulator.py:276
     o.limit_k, o.limit_b = cfg.hip.joint_limit_stiffness, cfg.hip.joint_limit_damping
     o.contact_iters = cfg.hip.contact_iters
+    o.contact_w_every = int(os.environ.get("LG_W_EVERY", getattr(cfg.hip, "contact_w_every", 1)))   # env override: developer timing only
     o.sim_layout = int(os.environ.get("LG_SIM_LAYOUT", getattr(cfg.hip, "sim_layout", 0)))   # env override: developer timing only
     o.contact_margin, o.limit_margin = cfg.hip.contact_margin, cfg.hip.limit_margin
     o.max_base_lin_vel, o.max_base_ang_vel = cfg.hip.max_base_lin_vel, cfg.hip.max_base_ang_vel

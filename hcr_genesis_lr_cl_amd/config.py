@@ -108,7 +108,7 @@ class LeggedRobotCfg(Section):
     # engine constants of this backend (no counterpart in the reference: Genesis' soft-constraint
     # parameters are internal to genesis-world).  See DESIGN.md "Contact model".
     hip = section(contact_stiffness=4.0e4, contact_damping=4.0e2, joint_limit_stiffness=5.0e3,
-                  joint_limit_damping=5.0e1, contact_iters=2, sim_layout=0, obs_history_slack=64, obs_sets=2, contact_margin=0.02, limit_margin=0.2,
+                  joint_limit_damping=5.0e1, contact_iters=2, contact_w_every=1, sim_layout=0, obs_history_slack=64, obs_sets=2, contact_margin=0.02, limit_margin=0.2,
                   max_base_lin_vel=50.0, max_base_ang_vel=40.0, joint_vel_clamp=2.0, seed=1)
 
 

@@ -426,6 +426,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
     constexpr bool STASH = DO_MDP && DO_SIM;
     constexpr int NST = LG_R_COUNT + 7 * JPL + 15;
     __shared__ float sSt[STASH ? NST : 1][BLOCK];
+    __shared__ float sW[DO_SIM ? 9 * BLOCK : 1];   // dt * W of each lane's foot between refreshes (LgSimOptions.contact_w_every > 1)
     if (STASH) {
         const int t = threadIdx.x;
 #pragma unroll
@@ -552,6 +553,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         STAMP(3);
         const bool jrot_identity = p.jrot_identity != 0;
 
+        float nf_poison = 0.f;   // becomes NaN when an acceleration or a joint rate of any sub-step was not finite (read-back guard)
         for (int sub = 0; sub < HOT(o_decimation); sub++) {
             const M3 Rb = quat_to_mat(qx, qy, qz, qw);
             // ---- forward kinematics + velocities of the chain (root -> leaf) -----------------
@@ -739,6 +741,8 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
             V3 fc = v3(0, 0, 0);          // foot force in the contact frame (n, t1, t2)
             V3 cn = v3(0, 0, 1), ct1 = v3(1, 0, 0), ct2 = v3(0, 1, 0), cp = v3(0, 0, 0), vfree = v3(0, 0, 0);
             M3 Ac = {0, 0, 0, 0, 0, 0, 0, 0, 0};   // dt * W in the contact frame
+            const int w_every = HOT(o_contact_w_every);
+            const bool w_refresh = w_every <= 1 || (sub % w_every) == 0;   // uniform: W of every foot is recomputed on these sub-steps
             float depth = -1.f;
             bool fact = false;
             {
@@ -758,7 +762,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 if (q[j] < lo + HOT(o_limit_margin)) { lim_s[j] = 1.f; lim_e[j] = lo - q[j]; lact = true; }
                 else if (q[j] > hi - HOT(o_limit_margin)) { lim_s[j] = -1.f; lim_e[j] = q[j] - hi; lact = true; }
             }
-            const int any = quad_or<LEGS>((fact || lact) ? 1 : 0);
+            const int any = quad_or<LEGS>((fact || lact) ? 1 : 0) | (w_refresh && w_every > 1 ? 1 : 0);
             float dqdd[JPL] = {0.f, 0.f, 0.f};
             V6 da0 = {v3(0, 0, 0), v3(0, 0, 0)};
             if (any) {  // uniform across the quad: DPP inside is safe
@@ -773,6 +777,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     const V3 axs[3] = {cn, ct1, ct2};
                     V3 col[3];
                     const float zero3[JPL] = {0.f, 0.f, 0.f};
+                    if (w_refresh) {
 #pragma unroll
                     for (int k = 0; k < 3; k++) {
                         float du[JPL], dq[JPL];
@@ -786,6 +791,16 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                     Ac.xx = dt * col[0].x; Ac.xy = dt * col[1].x; Ac.xz = dt * col[2].x;
                     Ac.yx = dt * col[0].y; Ac.yy = dt * col[1].y; Ac.yz = dt * col[2].y;
                     Ac.zx = dt * col[0].z; Ac.zy = dt * col[1].z; Ac.zz = dt * col[2].z;
+                    if (w_every > 1) {   // kept for the sub-steps in between (LDS: this kernel has no registers to spare)
+                        float *w = sW + threadIdx.x;
+                        w[0] = Ac.xx; w[BLOCK] = Ac.xy; w[2 * BLOCK] = Ac.xz; w[3 * BLOCK] = Ac.yx; w[4 * BLOCK] = Ac.yy; w[5 * BLOCK] = Ac.yz;
+                        w[6 * BLOCK] = Ac.zx; w[7 * BLOCK] = Ac.zy; w[8 * BLOCK] = Ac.zz;
+                    }
+                    } else {
+                        const float *w = sW + threadIdx.x;
+                        Ac.xx = w[0]; Ac.xy = w[BLOCK]; Ac.xz = w[2 * BLOCK]; Ac.yx = w[3 * BLOCK]; Ac.yy = w[4 * BLOCK]; Ac.yz = w[5 * BLOCK];
+                        Ac.zx = w[6 * BLOCK]; Ac.zy = w[7 * BLOCK]; Ac.zz = w[8 * BLOCK];
+                    }
                     const V3 vpt = K[JPL - 1].V.l + cross(K[JPL - 1].V.a, cp);
                     const V3 apt = a_calf.l + cross(a_calf.a, cp) + cross(K[JPL - 1].V.a, vpt);
                     const V3 vf = vpt + apt * dt;
@@ -846,11 +861,15 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 const V3 alpha = a0.a + da0.a;
                 const V3 alin = a0.l + da0.l + cross(ww, vw);   // spatial -> classical at O
                 const float mv = HOT(o_max_base_lin_vel), mw = HOT(o_max_base_ang_vel);
+                // poison for the non-finite guard: the clamps below turn NaN into a limit value (fminf / fmaxf drop it), so what goes into
+                // them is watched -- 0 * x is NaN for x = NaN or Inf, 0 otherwise
+                nf_poison = fmaf(alin.x + alin.y + alin.z + alpha.x + alpha.y + alpha.z, 0.f, nf_poison);
                 vw = v3(clampf(vw.x + dt * alin.x, -mv, mv), clampf(vw.y + dt * alin.y, -mv, mv), clampf(vw.z + dt * alin.z, -mv, mv));
                 ww = v3(clampf(ww.x + dt * alpha.x, -mw, mw), clampf(ww.y + dt * alpha.y, -mw, mw), clampf(ww.z + dt * alpha.z, -mw, mw));
 #pragma unroll
                 for (int j = 0; j < JPL; j++) {
                     const float vl = Lvlim[j];
+                    nf_poison = fmaf(qd[j] + qdd[j] + dqdd[j], 0.f, nf_poison);
                     qd[j] = clampf(qd[j] + dt * (qdd[j] + dqdd[j]), -vl, vl);
                     q[j] += dt * qd[j];
                 }
@@ -881,7 +900,7 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
         }
         // ---- read-back (genesis_simulator.py:35-60) ----------------------------------------------
         {   // non-finite guard: re-seat the robot (see oracle for the rationale)
-            float chk = pos.x + pos.y + pos.z + qx + qy + qz + qw + vw.x + vw.y + vw.z + ww.x + ww.y + ww.z;
+            float chk = pos.x + pos.y + pos.z + qx + qy + qz + qw + vw.x + vw.y + vw.z + ww.x + ww.y + ww.z + nf_poison;
 #pragma unroll
             for (int j = 0; j < JPL; j++) chk += q[j] + qd[j];
             const int bad = quad_or<LEGS>(isfinite(chk) ? 0 : 1);
@@ -897,6 +916,12 @@ LG_DEV void env_step_body(const KParams &p, uint4 *sMraw, int *sHot, float *sStF
                 if (lead && B.nonfinite_count) atomicAdd(B.nonfinite_count, 1);
                 guard_bad = true;
                 if (!DO_POST && lead && B.fail_buf) B.fail_buf[e] = LG_FAIL_NONFINITE;
+                // the start-of-step snapshots may be what was not finite: this step's rate terms (dof_acc, foot_acc) read zeros instead
+                last_foot_v = v3(0, 0, 0);
+                if (live) st3(B.last_feet_vel + (e * F + foot_slot) * 3, v3(0, 0, 0));
+#pragma unroll
+                for (int j = 0; j < JPL; j++) { last_qd[j] = 0.f; if (live) B.last_dof_vel[e * A + d0 + j] = 0.f; }
+                if (lead) { st3(B.last_base_lin_vel + 3 * e, v3(0, 0, 0)); st3(B.last_base_ang_vel + 3 * e, v3(0, 0, 0)); }
             }
         }
         // out-of-terrain teleport (genesis_simulator.py:612-628)

@@ -561,7 +561,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         B.last_actions[ja] = last_act;
         B.actions[ja] = act;
     }
-    const float last_foot_v = snap_fv, qd_start = qd;   // kept for the MDP tail (dof_acc, foot_acc)
+    float last_foot_v = snap_fv, qd_start = qd;   // kept for the MDP tail (dof_acc, foot_acc)
     if (stj) B.last_dof_vel[ja] = qd;   // "last" snapshots (genesis_simulator.py:21-24)
     if (st) {
         B.last_feet_vel[(e * F + foot_slot) * 3 + cj] = snap_fv;
@@ -649,10 +649,12 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     float f_link[4] = {0.f, 0.f, 0.f, 0.f};   // net contact force on hip, thigh, calf, foot links (component)
     float f_base = 0.f;
 
-    const int decim = HOT(o_decimation), iters = HOT(o_contact_iters);
+    const int decim = HOT(o_decimation), iters = HOT(o_contact_iters), w_every = HOT(o_contact_w_every);
+    QM Ac_keep = {0.f, 0.f, 0.f};             // dt * W of this leg's foot as of its latest refresh (LgSimOptions.contact_w_every)
     const float mv = HOT(o_max_base_lin_vel), mw = HOT(o_max_base_ang_vel);
 
     STAMP(12);
+    float nf_poison = 0.f;   // becomes NaN when an acceleration or a joint rate of any sub-step was not finite (read-back guard)
     for (int sub = 0; sub < decim; sub++) {
         const QM Rb = quat_rows(L, quat);
         QKin K[JPL];
@@ -910,15 +912,15 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         }
         float dqdd = 0.f;
         QV6 da0 = {0.f, 0.f};
-        if (__builtin_amdgcn_ballot_w64(fact || lim_s != 0.f) != 0ull) {
+        const bool w_refresh = w_every <= 1 || (sub % w_every) == 0;   // wave-uniform: W of every foot is recomputed on these sub-steps
+        if (w_refresh || __builtin_amdgcn_ballot_w64(fact || lim_s != 0.f) != 0ull) {
             // contact-frame projector: row r of E = axis r (n, t1, t2)
             QM E;
             E.c0 = L.sel(bc<0>(cn), bc<0>(ct1), bc<0>(ct2));
             E.c1 = L.sel(bc<1>(cn), bc<1>(ct1), bc<1>(ct2));
             E.c2 = L.sel(bc<2>(cn), bc<2>(ct1), bc<2>(ct2));
             const QM ET = {cn, ct1, ct2};
-            QM Ac;      // dt * W, contact frame, rows
-            {
+            if (w_refresh) {      // dt * W, contact frame, rows
                 float du[JPL], dq;
                 const float axs[3] = {cn, ct1, ct2};
                 float col[3];
@@ -931,8 +933,9 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                     const float ra = ac.l + cross(ac.a, cp);
                     col[k] = dt * mulv(E, ra);
                 }
-                Ac.c0 = col[0]; Ac.c1 = col[1]; Ac.c2 = col[2];
+                Ac_keep.c0 = col[0]; Ac_keep.c1 = col[1]; Ac_keep.c2 = col[2];
             }
+            const QM Ac = Ac_keep;
             float vfree;
             {
                 const float vpt = K[JPL - 1].V.l + cross(K[JPL - 1].V.a, cp);
@@ -999,6 +1002,9 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         {
             const float alpha = a0.a + da0.a;
             const float alin = a0.l + da0.l + cross(ww, vw);     // spatial -> classical at O
+            // poison for the non-finite guard: the clamps below turn NaN into a limit value (fminf / fmaxf drop it), so what goes into
+            // them is watched -- 0 * x is NaN for x = NaN or Inf, 0 otherwise
+            nf_poison = fmaf(L.is3 ? (JPL == 4 ? qd + qdd + dqdd : 0.f) : alin + alpha + (qd + qdd + dqdd), 0.f, nf_poison);   // lane 3: no vector component
             vw = clampf(vw + dt * alin, -mv, mv);
             ww = clampf(ww + dt * alpha, -mw, mw);
             qd = clampf(qd + dt * (qdd + dqdd), -Lvlim, Lvlim);
@@ -1030,7 +1036,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     // ---------------- read-back (genesis_simulator.py:35-60) ---------------------------------------
     int guard_bad = 0;
     {   // non-finite guard: re-seat the robot
-        const float chk = quat + (L.is3 ? (JPL == 4 ? q + qd : 0.f) : pos + vw + ww + q + qd);
+        const float chk = quat + (L.is3 ? (JPL == 4 ? q + qd : 0.f) : pos + vw + ww + q + qd) + nf_poison;
         const int bad = env_or<LEGS>(isfinite(chk) ? 0 : 1);
         const float reseat = HOT(o_base_init_pos[0]) * L.d0 + HOT(o_base_init_pos[1]) * L.d1 + HOT(o_base_init_pos[2]) * L.d2 + origin;
         if (bad) {
@@ -1038,6 +1044,13 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             q = q0; qd = 0.f; torque = 0.f;
             f_link[0] = f_link[1] = f_link[2] = f_link[3] = 0.f; f_base = 0.f;
             // never silent: counted, and the env terminates at this step's check_termination (fail_buf over the threshold)
+            // the start-of-step snapshots may be what was not finite: this step's rate terms (dof_acc, foot_acc) read zeros instead
+            last_foot_v = 0.f; qd_start = 0.f;
+            if (stj) B.last_dof_vel[ja] = 0.f;
+            if (st) {
+                B.last_feet_vel[(e * F + foot_slot) * 3 + cj] = 0.f;
+                if (leg == 0) { B.last_base_lin_vel[3 * e + cj] = 0.f; B.last_base_ang_vel[3 * e + cj] = 0.f; }
+            }
             if (lead && L.is0) {
                 if (B.nonfinite_count) atomicAdd(B.nonfinite_count, 1);
                 if (MPH == 0 && B.fail_buf) B.fail_buf[e] = LG_FAIL_NONFINITE;   // the MDP launch that follows reads it

@@ -120,6 +120,7 @@ struct LgHot {
     float o_limit_k;
     float o_limit_b;
     int32_t o_contact_iters;
+    int32_t o_contact_w_every;
     float o_contact_margin;
     float o_limit_margin;
     float o_max_base_lin_vel;
@@ -240,6 +241,7 @@ static void fill_hot(LgHot &H, const LgTaskCfg &t, const LgSimOptions &o, const 
     H.o_limit_k = o.limit_k;
     H.o_limit_b = o.limit_b;
     H.o_contact_iters = o.contact_iters;
+    H.o_contact_w_every = o.contact_w_every > 1 ? o.contact_w_every : 1;
     H.o_contact_margin = o.contact_margin;
     H.o_limit_margin = o.limit_margin;
     H.o_max_base_lin_vel = o.max_base_lin_vel;

@@ -103,6 +103,10 @@ typedef struct LgSimOptions {
     int32_t n_height_points;   /* 0 = measure_heights off */
     int32_t feet_terrain_info; /* cfg.terrain.obtain_terrain_info_around_feet */
     int32_t sim_layout;        /* physics kernel layout: 0 auto (by batch size), 1 one leg per lane, 2 one vector component per lane */
+    int32_t contact_w_every;   /* the feet's 3x3 operational-space inverse inertias W (three unit-force response sweeps per foot) are
+                                * recomputed on sub-steps 0, k, 2k ... of a control step (every foot, in contact or not) and reused as they
+                                * are in between; <= 1: every sub-step.  W only preconditions the block-Jacobi sweeps -- their fixed point
+                                * (the contact law on the EXACT response of the robot) does not depend on it */
 } LgSimOptions;
 
 /* ---- reward term ids, in the alphabetical order the reference evaluates them
@@ -372,6 +376,11 @@ int lg_obs_set_select(LgHandle h, int32_t set);
 int lg_obs_window_select(LgHandle h, int32_t first_frame);
 int lg_profile(LgHandle h, int32_t stride);
 int lg_profile_read(LgHandle h, float *mean_us, int32_t *samples);
+/* Measurement: the achievable HBM stream rate of THIS device, the denominator bench.py quotes next to the nominal peak (SURVEY 8d:
+ * "peak figures must be replaced by a measured stream-copy bandwidth on the box").  Copies `bytes` (a multiple of 16) from src to dst
+ * `iters` times with a float4 grid-stride kernel on `stream`, timed with HIP events after one untimed pass; *gbs = (read + write)
+ * bytes per second / 1e9.  src / dst: device pointers, 16-byte aligned, not overlapping. */
+int lg_stream_copy(const void *src, void *dst, int64_t bytes, int32_t iters, void *stream, float *gbs);
 /* Diagnostic: one Philox4x32-10 block computed on the device by the kernel's own generator (known-answer tests). */
 int lg_philox(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 const char *lg_last_error(void);

@@ -412,6 +412,8 @@ static void env_step(const LgModelDesc *m, const LgSimOptions *o, const int16_t 
     const real dt = o->dt, kc = o->contact_k, bc = o->contact_b, kappa = kc * dt + bc;
     real torque_raw[ND];
     real link_f[LG_MAX_LINKS][3];
+    real Wc[LG_MAX_LEGS][9];
+    memset(Wc, 0, sizeof(Wc));
 
     for (int sub = 0; sub < o->decimation; sub++) {
         kinematics(&w, pos, quat, vw, ww, q, qd);
@@ -512,8 +514,11 @@ static void env_step(const LgModelDesc *m, const LgSimOptions *o, const int16_t 
          * by an exact joint-space response pass for the current set of foot forces. */
         int active[LG_MAX_LEGS] = {0, 0, 0, 0};
         real cpw[LG_MAX_LEGS][3], cpl[LG_MAX_LEGS][3], nrm[LG_MAX_LEGS][3], t1[LG_MAX_LEGS][3], t2[LG_MAX_LEGS][3];
-        real dep[LG_MAX_LEGS], vfree[LG_MAX_LEGS][3], Wc[LG_MAX_LEGS][9], fc[LG_MAX_LEGS][3];
+        real dep[LG_MAX_LEGS], vfree[LG_MAX_LEGS][3], fc[LG_MAX_LEGS][3];
         int any = 0;
+        /* W (Wc, kept across sub-steps) is refreshed on sub-steps 0, k, 2k ... for EVERY foot (LgSimOptions.contact_w_every) */
+        const int w_every = o->contact_w_every > 1 ? o->contact_w_every : 1;
+        const int w_refresh = (sub % w_every) == 0;
         for (int l = 0; l < F; l++) {
             int s = m->foot_sphere[l], i = m->sph_body[s];
             real rl[3] = {m->sph_pos[s][0], m->sph_pos[s][1], m->sph_pos[s][2]}, rw[3], c[3], h;
@@ -522,8 +527,9 @@ static void env_step(const LgModelDesc *m, const LgSimOptions *o, const int16_t 
             terrain_at(o, hf, c[0], c[1], &h, nrm[l]);
             dep[l] = m->sph_r[s] - (c[2] - h) * nrm[l][2];
             fc[l][0] = fc[l][1] = fc[l][2] = 0;
-            if (dep[l] <= -o->contact_margin) continue;
-            active[l] = 1; any = 1;
+            const int act_l = dep[l] > -o->contact_margin;
+            if (!act_l && !w_refresh) continue;
+            if (act_l) { active[l] = 1; any = 1; }
             /* contact point = sphere surface point along -n; body-frame offset */
             real rel[3];
             for (int k = 0; k < 3; k++) { cpw[l][k] = c[k] - m->sph_r[s] * nrm[l][k]; rel[k] = cpw[l][k] - w.Pw[i][k]; }
@@ -533,7 +539,7 @@ static void env_step(const LgModelDesc *m, const LgSimOptions *o, const int16_t 
             point_accel(&w, i, cpl[l], a[i], 1, af);
             tangent_basis(nrm[l], t1[l], t2[l]);
             const real *ax3[3] = {nrm[l], t1[l], t2[l]};
-            for (int col = 0; col < 3; col++) {
+            for (int col = 0; w_refresh && col < 3; col++) {
                 real fe[NB][6], ad[NB][6], qd2[ND], resp[3];
                 memset(fe, 0, sizeof(fe));
                 add_world_force(&w, i, cpw[l], ax3[col], fe);

@@ -202,6 +202,64 @@ def test_other_sweep_counts_match_oracle(go2, layout, iters):
     assert np.all(err <= 0.3 + 0.01 * np.abs(st.arr["link_contact_forces"].reshape(256, -1))), err.max()
 
 
+@pytest.mark.parametrize("layout", LAYOUTS)
+@pytest.mark.parametrize("every", [2, 4])
+def test_reused_contact_w_matches_oracle(go2, layout, every):
+    """LgSimOptions.contact_w_every: the feet's operational-space matrices are recomputed on sub-steps 0, k, 2k ... only (every foot,
+    in contact or not) and reused in between -- both kernels follow the CPU restatement's statement of that rule, two control steps."""
+    import copy, torch
+    from hcr_genesis_lr_cl_amd import abi, builders
+    from hcr_genesis_lr_cl_amd.engine import Engine
+    from oracle import oracle as orc
+    from tests.util import random_sim_state, load_state_into_engine, engine_arrays
+    opts = copy.copy(go2["opts"])
+    opts.sim_layout, opts.contact_w_every = layout, every
+    eng = Engine(go2["model"], go2["desc"], opts, builders.make_task_cfg(go2["model"], go2["cfg"]), 256, "cuda:0")
+    st, actions = random_sim_state(go2["model"], go2["cfg"], 256, 17)
+    load_state_into_engine(eng, st)
+    ref1 = st.copy()
+    for _ in range(2):
+        eng.step(abi.PHASE_SIM, torch.from_numpy(actions).cuda(), 0)
+        orc.sim_step(go2["desc"], opts, st, actions, "f64", threads=8)
+    got = engine_arrays(eng, ["dof_pos", "dof_vel", "base_pos", "base_quat", "link_contact_forces"])
+    bad = 0
+    for k in ("dof_pos", "dof_vel", "base_pos", "base_quat"):
+        ref = st.arr[k].reshape(256, -1)
+        bad = max(bad, int((np.abs(got[k] - ref) > 2 * TOL[k] + 1e-4 * np.abs(ref)).any(axis=1).sum()))
+    assert bad <= 2, bad      # two steps through stiff contact: an env on a branch edge of the contact law may differ
+    # and the option does something: the default rule gives a (slightly) different trajectory
+    o1 = copy.copy(opts); o1.contact_w_every = 1
+    for _ in range(2):
+        orc.sim_step(go2["desc"], o1, ref1, actions, "f64", threads=8)
+    assert np.abs(ref1.arr["dof_vel"] - st.arr["dof_vel"]).max() > 1e-4
+
+
+def test_nonfinite_state_is_counted_and_ends_the_episode():
+    """the non-finite guard re-seats the robot, and it is never silent -- LgBuffers.nonfinite_count goes up and the env
+    terminates in the same step (reset_buf = 1, not a time-out), in the fused launch and in the split launches."""
+    import torch
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    for task in ("go2", "tron1_pf_ee", "go2_cat"):
+        env, cfg = make_env(task, 64)
+        env.reset()
+        g = torch.Generator(device="cuda"); g.manual_seed(3)
+        for _ in range(3):
+            env.step(torch.randn(64, env.num_actions, generator=g, device="cuda"))
+        eng = env._engine
+        assert eng.nonfinite_count() == 0
+        eng.buf["dof_vel"][5, 1] = float("nan")
+        eng.buf["base_pos"][9, 2] = float("inf")
+        out = env.step(torch.randn(64, env.num_actions, generator=g, device="cuda"))
+        done, extras = out[-2], out[-1]
+        assert eng.nonfinite_count() == 2, task
+        assert bool(done[5]) and bool(done[9]) and not bool(extras["time_outs"][5]) and not bool(extras["time_outs"][9]), task
+        for k in ("dof_pos", "dof_vel", "base_pos", "base_quat", "obs_buf", "rew_buf"):
+            assert bool(torch.isfinite(eng.buf[k]).all()), (task, k)
+        assert int(eng.buf["fail_buf"][5]) == 0 and int(eng.buf["episode_length_buf"][5]) == 0     # the reset went through
+        env.step(torch.randn(64, env.num_actions, generator=g, device="cuda"))
+        assert eng.nonfinite_count() == 2, task
+
+
 @pytest.mark.parametrize("task", ["go2_ee", "tron1_pf_ee", "tron1_sf"])
 def test_no_robot_is_thrown_by_the_contact_solver(task):
     """Regression (round 2): with friction ratios up to 1.7 the sliding branch of the foot contact could jam -- friction coupling

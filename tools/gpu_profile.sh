@@ -6,7 +6,8 @@ set -e -o pipefail
 R=${GRAFT_REPO_ROOT:-$(pwd)}
 cd "$R"
 export TMPDIR=/tmp
-TAG=${1:-r02}
+TAG=${1:-r03}
+export LG_PROFILE_TAG=$TAG
 shift || true
 TASKS=${@:-go2 go2_wtw go2_ee tron1_pf_ee}
 mkdir -p gpurun_out profiles

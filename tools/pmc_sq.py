@@ -5,7 +5,7 @@ import csv, json, os, sys
 from collections import defaultdict
 
 sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-from step_kernels import STEP_KERNELS, key_of
+from step_kernels import STEP_KERNELS, key_of, profile_stamp
 path, task, out = sys.argv[1:4]
 key, subs = key_of(task), STEP_KERNELS[task]
 vals = defaultdict(lambda: defaultdict(list))
@@ -39,6 +39,7 @@ try:
     data = json.load(open(jp))
 except (OSError, ValueError):
     data = {}
+entry.update(profile_stamp())
 data[key] = entry
 json.dump(data, open(jp, "w"), indent=1)
 print("\n".join(lines))

@@ -25,7 +25,7 @@ def per_kernel(path, name):
 
 def main():
     sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
-    from step_kernels import STEP_KERNELS, key_of
+    from step_kernels import STEP_KERNELS, key_of, profile_stamp
     fetch_csv, write_csv, task = sys.argv[1:4]
     key, subs = key_of(task), STEP_KERNELS[task]
     fv, wv = per_kernel(fetch_csv, "FETCH_SIZE"), per_kernel(write_csv, "WRITE_SIZE")
@@ -54,7 +54,7 @@ def main():
         data = {}
     data[key] = {"kernels": used, "bytes_per_launch": rd_b + wr_b, "read_bytes": rd_b, "write_bytes": wr_b,
                  "raw_bytes_per_step": (rd + wr) * 1024.0, "fetch_size_raw_kb": rd, "write_size_raw_kb": wr, "control_steps": steps,
-                 "note": "per control step; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); WRITE_SIZE as reported"}
+                 "note": "per control step; FETCH_SIZE doubled (gfx950 counts 128-B requests as 64 B); WRITE_SIZE as reported", **profile_stamp()}
     json.dump(data, open(out_path, "w"), indent=1)
     print(json.dumps(data[key]))
 

@@ -14,3 +14,15 @@ STEP_KERNELS = {
 
 def key_of(task, n=4096):
     return f"{'go2_flat' if task == 'go2' else task}_{n}"
+
+
+def profile_stamp():
+    """What the counters were taken on: the profile tag of the pass (LG_PROFILE_TAG, set by tools/gpu_profile.sh) and the source hash of
+    the library that ran (csrc/liblgsim.build.json).  bench.py marks a figure stale when the library it loads has another hash."""
+    import json, os
+    root = os.path.join(os.path.dirname(os.path.abspath(__file__)), "..")
+    try:
+        h = json.load(open(os.path.join(root, "hcr_genesis_lr_cl_amd", "csrc", "liblgsim.build.json"))).get("source_hash")
+    except (OSError, ValueError):
+        h = None
+    return {"tag": os.environ.get("LG_PROFILE_TAG"), "source_hash": h}
