@@ -243,6 +243,27 @@ static int rough_profile(const LgEngine *h) {
     return 0;
 }
 
+// tron1_pf_ee (PROF 6 = the component-layout tail of lg_quad.h for the three-joint biped): what it hard-wires
+static bool biped_profile(const LgEngine *h) {
+    const LgTaskCfg &t = h->task;
+    const LgBuffers &b = h->bufs;
+    if (h->model.n_legs != 2 || h->model.n_bodies != 7 || !h->hf || h->opts.terrain_rows <= 0) return false;
+    const int K = __builtin_popcount(h->model.state_link_mask), P = h->opts.n_height_points, A = 6, F = 2;
+    return t.obs_layout == LG_OBS_TRON1_EE && t.gait_mode == 2 && t.double_shift == 1 && t.cat_enable == 0 && t.behavior_resample_steps == 0 &&
+           t.obs_slack > 0 && t.obs_stack > 1 && t.priv_stack > 1 && t.obs_sets <= 2 && (t.obs_sets < 2 || b.obs_dirty) && !b.rand_in &&
+           t.obs_frame == 9 + 3 * A + 2 * F && t.priv_frame == t.obs_frame + 7 + 2 * A + 3 + F + K + P + 3 * F + 9 * F && t.num_labels == 3 + K + F + 3 * F &&
+           P > 0 && P <= 7 * 8 && h->opts.feet_terrain_info && b.priv_obs_buf && b.labels_buf && b.task_state && b.rand_push_vels &&
+           t.task_state_width == LG_TASK_STATE_BIPED && b.link_contact_states &&
+           (!t.terrain_curriculum || (b.terrain_levels && b.terrain_types && b.terrain_origins && b.env_origins)) &&
+           (!t.dr_joint_on || (b.joint_armature && b.joint_friction && b.joint_damping)) &&
+           (t.slots.reset_root_xy & 3) != 3 &&       // the two root xy draws share a Philox block
+           // 32-bit byte offsets into the observation allocations (lg_quad.h)
+           (double)b.n_envs * (t.priv_stack + t.obs_slack) * t.priv_frame * 4.0 < 4.0e9 && (double)b.n_envs * (t.obs_stack + t.obs_slack) * t.obs_frame * 4.0 < 4.0e9 &&
+           // commands carry no observation noise (tron1_pf_ee.py:322-342)
+           t.noise_vec[0] == 0.f && t.noise_vec[1] == 0.f && t.noise_vec[2] == 0.f &&
+           ((unsigned)h->hot.reward_mask & ((1u << LG_R_QUAD_PERIODIC_GAIT) | (1u << LG_R_TRACKING_FOOT_CLEARANCE) | (1u << LG_R_TRACKING_ORIENTATION))) == 0;
+}
+
 template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, const float *actions, int64_t counter, hipStream_t st) {
     KParams p;
     p.M = h->d_model; p.O = h->d_opts; p.T = h->d_task; p.H = h->d_hot; p.hf = h->hf; p.B = h->bufs; p.actions = actions; p.counter = counter;
@@ -345,6 +366,15 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
             else if (fuse && rest == PR && rough_profile(h) == 4) LG_LAUNCH(pi, (lg_launch_quad<4, true, PR, 4, 3>), qgrid);
             else if (fuse && rest == PR) LG_LAUNCH(pi, (lg_launch_quad<4, true, PR, 0, 3>), qgrid);
             else if (fuse && rest == LG_PHASE_POST) LG_LAUNCH(pi, (lg_launch_quad<4, true, LG_PHASE_POST, 0, 3>), qgrid);
+        } else {
+            // biped (TRON1 point foot): the whole step in one launch too -- the leg-per-lane MDP body in the tail, four replicas of the
+            // wave's 16 leg-lanes (8 envs) -- unless the job-wide CaT flag has to pass between the phases.  LG_BIPED_FUSE=0: two launches
+            const char *bf = getenv("LG_BIPED_FUSE");
+            fuse = pre && rest == PR && !h->task.cat_enable && (bf ? atoi(bf) != 0 : true);
+            const char *bt = getenv("LG_BIPED_TAIL");    // 0: the leg-per-lane MDP body in the tail even where the component-layout tail applies
+            if (fuse && hfb && biped_profile(h) && !(bt && atoi(bt) == 0)) LG_LAUNCH(pi, (lg_launch_quad<2, true, PR, 6, 3>), qgrid);
+            else if (fuse && hfb) LG_LAUNCH(pi, (lg_launch_quad<2, true, PR, 5, 3>), qgrid);
+            else if (fuse) LG_LAUNCH(pi, (lg_launch_quad<2, true, PR, 0, 3>), qgrid);
         }
         // physics-only launches: PROF 3 here only says "a heightfield is bound" (lg_quad.h HFC: no branch in front of the terrain loads)
         if (fuse) {}

@@ -1,15 +1,15 @@
 // lg_inst.hip -- the kernel instantiations of the library, compiled once per GROUP (hipcc -DLG_GROUP=g ... -c, the groups in parallel;
 // hcr_genesis_lr_cl_amd/build.py).  One translation unit holding all of them took over three minutes to build; a group is a
-// handful of kernels that share template parameters.  Groups 0-7 hold the component-per-lane kernels (lg_quad.h), groups 8-15 the
+// handful of kernels that share template parameters.  Groups 0-8 hold the component-per-lane kernels (lg_quad.h), groups 9-16 the
 // leg-per-lane ones (lg_kernel.h) and do not include lg_quad.h, so an edit there leaves their objects valid.
 //
 // The host side (lg_host.hip) calls the launchers declared in lg_shared.h; every instantiation it names must appear in exactly
 // one group below (a missing one is a link error, not a run-time surprise).
 #ifndef LG_GROUP
-#error "compile with -DLG_GROUP=<0..15> (hcr_genesis_lr_cl_amd/build.py)"
+#error "compile with -DLG_GROUP=<0..16> (hcr_genesis_lr_cl_amd/build.py)"
 #endif
 #include "lg_kernel.h"
-#if LG_GROUP < 8
+#if LG_GROUP < 9
 #include "lg_quad.h"
 
 template <int LEGS, bool PRE, unsigned MPH, int PROF, int JPL>
@@ -47,22 +47,24 @@ QUAD(4, true, 0u, 0, 3) QUAD(4, true, 0u, 3, 3) QUAD(4, false, 0u, 0, 3) QUAD(4,
 QUAD(2, true, 0u, 0, 3) QUAD(2, true, 0u, 3, 3) QUAD(2, false, 0u, 0, 3) QUAD(2, false, 0u, 3, 3)
 #elif LG_GROUP == 7    // biped physics (four joints per leg: TRON1 sole foot)
 QUAD(2, true, 0u, 0, 4) QUAD(2, false, 0u, 0, 4)
+#elif LG_GROUP == 8    // biped, whole step in one launch (TRON1 point foot): leg-per-lane MDP body in the tail (0, 5: heightfield bound); tron1_pf_ee's component-layout tail (6)
+QUAD(2, true, 12u, 0, 3) QUAD(2, true, 12u, 5, 3) QUAD(2, true, 12u, 6, 3)
 // ---- leg per lane: env_step_kernel<LEGS, PHASES, PROF, JPL, REPL> ----
-#elif LG_GROUP == 8    // whole step, quadruped (large batches)
+#elif LG_GROUP == 9    // whole step, quadruped (large batches)
 ENV(4, 15u, 0, 3, false) ENV(4, 15u, 1, 3, false)
-#elif LG_GROUP == 9    // whole step, biped
+#elif LG_GROUP == 10    // whole step, biped
 ENV(2, 15u, 0, 3, false) ENV(2, 15u, 1, 3, false) ENV(2, 15u, 0, 4, false)
-#elif LG_GROUP == 10   // MDP phases behind a physics launch, quadruped
+#elif LG_GROUP == 11   // MDP phases behind a physics launch, quadruped
 ENV(4, 12u, 0, 3, false) ENV(4, 12u, 0, 3, true) ENV(4, 13u, 0, 3, false)
-#elif LG_GROUP == 11   // ... biped
+#elif LG_GROUP == 12   // ... biped
 ENV(2, 12u, 0, 3, false) ENV(2, 12u, 0, 3, true) ENV(2, 13u, 0, 3, false)
-#elif LG_GROUP == 12   // ... sole-foot biped
+#elif LG_GROUP == 13   // ... sole-foot biped
 ENV(2, 12u, 0, 4, false) ENV(2, 12u, 0, 4, true) ENV(2, 13u, 0, 4, false)
-#elif LG_GROUP == 13   // single phases and their other combinations (golden replays, glue tests), quadruped
+#elif LG_GROUP == 14   // single phases and their other combinations (golden replays, glue tests), quadruped
 ENV_PHASES(4, 3)
-#elif LG_GROUP == 14   // ... biped
+#elif LG_GROUP == 15   // ... biped
 ENV_PHASES(2, 3)
-#elif LG_GROUP == 15   // ... sole-foot biped
+#elif LG_GROUP == 16   // ... sole-foot biped
 ENV_PHASES(2, 4)
 #else
 #error "LG_GROUP out of range"

@@ -78,6 +78,10 @@ struct Lane {
     LG_DEV float sel4(float a0, float a1, float a2, float a3) const { return is0 ? a0 : (is1 ? a1 : (is2 ? a2 : a3)); }
 };
 
+// NOTE on cross-lane reads (DPP broadcasts, ds_bpermute) and `?:`: the arms of a conditional expression are evaluated under the
+// condition, and these intrinsics are not speculated -- `L.is0 ? bc<3>(a) : bc<3>(b)` becomes a divergent branch whose first arm runs
+// with only the is0 lanes in EXEC, so the read from lane 3 returns 0 (bound_ctrl).  Cross-lane values are therefore always formed in
+// their own statements (or as arguments of L.sel / L.sel4, which are evaluated before the call) and selected afterwards.
 LG_DEV float dot3(float a, float b) { return sum3(a * b); }
 LG_DEV float cross(float a, float b) { return rot1(a * rot1(b) - rot1(a) * b); }
 // The quad broadcast of an operand rides ON the multiply-add (v_mul_f32_dpp / v_fmac_f32_dpp with quad_perm:[k,k,k,k] on src0).
@@ -323,6 +327,32 @@ template <int NJ> LG_DEV QV6 resp_down(const Lane &L, const QJoint (&J)[NJ], con
     return a;
 }
 
+// Blank the observation histories of the envs flagged in `rm` (a ballot: one lane per env) with ALL 64 lanes of the wave: a reset env
+// restarts its stacks from zeros (legged_robot_ee.py / go2_wtw.py:174-178) -- 1.5 k floats for the 10-frame stacks of tron1_pf_ee.  Left
+// to the env's own 8 or 16 lanes that is 100-190 stores per lane in a wave that has a reset in it, and a launch ends with its slowest wave.
+// `e`: this lane's env; obs / priv: start of this launch's window in row 0 of the set being written; n_o / n_p: floats to zero per row.
+// n floats from p (4-byte aligned) to zero with the wave's 64 lanes: the unaligned head (< 4 floats), 16-byte stores, the tail.  `p` and `n`
+// are wave-uniform, so every lane takes the same path.
+LG_DEV void zero_run(float *p, int n, int wl) {
+    const int head = min(n, (int)((16u - ((unsigned)(uintptr_t)p & 15u)) & 15u) >> 2);
+    if (wl < head) p[wl] = 0.f;
+    float4 *q4p = reinterpret_cast<float4 *>(p + head);
+    const int n4 = (n - head) >> 2;
+    for (int i = wl; i < n4; i += 64) q4p[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int done = head + 4 * n4;
+    if (wl < n - done) p[done + wl] = 0.f;
+}
+LG_DEV void blank_histories(unsigned long long rm, int e, float *obs, size_t orow, int n_o, float *priv, size_t prow, int n_p) {
+    const int wl = (int)threadIdx.x & 63;
+    while (rm) {
+        const int bit = __builtin_ctzll(rm);
+        rm &= rm - 1;
+        const int er = __builtin_amdgcn_readlane(e, bit);
+        zero_run(obs + (size_t)er * orow, n_o, wl);
+        zero_run(priv + (size_t)er * prow, n_p, wl);
+    }
+}
+
 }  // namespace q4
 
 // ---------------------------------------------------------------------------------------------
@@ -459,7 +489,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     int crv = 0;
     if (MPH != 0) crv = reinterpret_cast<const int GAS *>(k_command_ranges)[min((int)threadIdx.x, LG_CMD_RANGE_FLOATS - 1)];
     int prw = 0;   // observation programs for the MDP tail (lg_kernel.h PRG_I / PRG_F)
-    if ((MPH & LG_PHASE_RESET) != 0 && (PROF == 4 || (PROF == 0 && KINT(k.obs_layout) == LG_OBS_PROGRAM))) {
+    if ((MPH & LG_PHASE_RESET) != 0 && (PROF == 4 || ((PROF == 0 || PROF == 5) && KINT(k.obs_layout) == LG_OBS_PROGRAM))) {
         const int tl = (int)threadIdx.x;
         prw = reinterpret_cast<const int GAS *>(tl < 26 ? &kT->priv_prog : &kT->labels_prog)[tl < 26 ? tl : min(tl - 26, 25)];
     }
@@ -472,22 +502,39 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     constexpr bool PQ = PROF == 4 && QTAIL;   // ... of the rough heads with observation programs (go2_ts / go2_cts / go2_dreamwaq): go2_ee's MDP, other packaging
     constexpr bool EQ = (PROF == 3 || PROF == 4) && QTAIL;   // ... of the go2_ee family: heightfield, terrain curriculum, 45 x 20 | critic x 5 stacks, labels
     constexpr bool SQ = WQ || EQ;             // stacked observations, PD-gain randomisation, root twist draws
-    __shared__ float sStF[(MPH != 0 && !QTAIL) ? NST * 16 : 1];
-    float wsv[(MPH != 0 && !QTAIL) ? NST : 1];
+    // PROF 6 (host-checked, lg_host.hip biped_profile): the tron1_pf_ee task -- point-foot biped on a heightfield -- with its MDP phases in
+    // component layout on the env's EIGHT lanes (two quads), the second block below
+    constexpr bool BQ = PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET);
+    static_assert(PROF != 6 || (LEGS == 2 && JPL == 3), "PROF 6 is the three-joint biped's tail");
+    constexpr bool CTAIL = QTAIL || BQ;       // some component-layout tail: no leg-per-lane stash, no LDS hand-off
+    __shared__ float sStF[(MPH != 0 && !CTAIL) ? NST * 16 : 1];
+    float wsv[(MPH != 0 && !CTAIL) ? NST : 1];
     // QTAIL working set, one value per lane: command component c, the two episode sums this lane owns (terms ei and ei + 16 of its
     // env, ei = 4 leg + c), this lane's joint constants; per-env / per-leg scalars replicated
     static_assert(LG_R_COUNT <= 32, "two episode sums per lane");
     const int ei = (leg << 2) | L.c;
     float m_cmd = 0.f, m_air = 0.f, m_es0 = 0.f, m_es1 = 0.f, m_slo = 0.f, m_shi = 0.f, m_rlo = 0.f, m_rsp = 0.f, m_nq = 0.f, m_nqd = 0.f;
     int m_ep = 0, m_fail = 0, m_lc = 0;
-    if (QTAIL) {
+    // biped tail: four episode sums per lane (terms el + 8 k of its env, el = 4 leg + c), the action / clock noise scales of tron1_pf_ee's
+    // frame, the sit pose and the gait offsets a reset needs
+    float b_es[4] = {0.f, 0.f, 0.f, 0.f}, b_nact = 0.f, b_nclk0 = 0.f, b_nclk1 = 0.f, b_sitq = 0.f, b_sitp = 0.f, b_sitr = 0.f, b_th0 = 0.f, b_th1 = 0.f;
+    if (BQ) {
+        static_assert(LG_R_COUNT <= 32, "four episode sums per lane");
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (ei + 8 * k < LG_R_COUNT) b_es[k] = k_episode_sums[(size_t)(ei + 8 * k) * N + e];
+        b_nact = kT->noise_vec[9 + 2 * A + d0 + cj];
+        b_nclk0 = kT->noise_vec[9 + 3 * A + foot_slot]; b_nclk1 = kT->noise_vec[9 + 3 * A + LEGS + foot_slot];
+        b_sitq = kT->sit_dof_pos[d0 + cj]; b_sitp = kT->sit_pos[cj]; b_sitr = kT->sit_quat[L.c];
+        b_th0 = kT->theta_table[0][0]; b_th1 = kT->theta_table[0][1];
+    }
+    if (CTAIL) {
         m_cmd = k_commands[4 * e + L.c];
         m_ep = k_episode_length_buf[e];
         m_fail = (int)k_fail_buf[e];
         m_air = k_feet_air_time[e * F + foot_slot];
         m_lc = (int)k_last_contacts[e * F + foot_slot];
-        m_es0 = k_episode_sums[(size_t)ei * N + e];
-        if (ei + 16 < LG_R_COUNT) m_es1 = k_episode_sums[(size_t)(ei + 16) * N + e];
+        if (QTAIL) m_es0 = k_episode_sums[(size_t)ei * N + e];
+        if (QTAIL && ei + 16 < LG_R_COUNT) m_es1 = k_episode_sums[(size_t)(ei + 16) * N + e];
         m_slo = kT->soft_dof_lo[d0 + cj]; m_shi = kT->soft_dof_hi[d0 + cj];
         m_rlo = kT->reset_dof_lo[d0 + cj]; m_rsp = kT->reset_dof_span[d0 + cj];
         m_nq = kT->noise_vec[9 + d0 + cj]; m_nqd = kT->noise_vec[9 + A + d0 + cj];
@@ -501,15 +548,19 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         w_gt = ts[0]; w_phi = ts[1]; w_gp = ts[2]; w_bh = ts[3]; w_fc = ts[4]; w_pt = ts[5];
         w_th = ts[6 + foot_slot]; w_ec = ts[18 + foot_slot];
     }
-    if (SQ) {
+    if (BQ) {   // tron1_pf_ee: gait clock (LG_TASK_STATE_BIPED, tron1_pf_ee.py:167-184)
+        const float GAS *ts = KB(const float GAS *, task_state) + (size_t)e * LG_TASK_STATE_BIPED;
+        w_gt = ts[0]; w_phi = ts[1]; w_th = ts[4 + foot_slot]; w_ec = ts[10 + foot_slot];
+    }
+    if (SQ || BQ) {
         w_push = KB(const float GAS *, rand_push_vels)[3 * e + cj];
         if (k_obs_dirty) w_dirty = (int)k_obs_dirty[e];
     }
-    if (EQ) {   // go2_ee: terrain level / type of the env (curriculum at reset)
+    if (EQ || BQ) {   // go2_ee, tron1_pf_ee: terrain level / type of the env (curriculum at reset)
         const int32_t GAS *tl = KB(const int32_t GAS *, terrain_levels), *tt = KB(const int32_t GAS *, terrain_types);
         if (tl) { w_lvl = tl[e]; w_type = tt[e]; }
     }
-    if (MPH != 0 && !QTAIL && threadIdx.x < 16) {
+    if (MPH != 0 && !CTAIL && threadIdx.x < 16) {
         const LgTaskCfg GAS *T = kT;
         const int lt = wg * 16 + (int)threadIdx.x, legL = lt % LEGS, dL = 3 * legL;
         const int eL = min(lt / LEGS, N - 1);
@@ -542,7 +593,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     if (MPH != 0) {
         sHot[threadIdx.x + 256] = crv;
         sHot[threadIdx.x + 256 + BLOCK] = prw;
-        if (!QTAIL && threadIdx.x < 16) {
+        if (!CTAIL && threadIdx.x < 16) {
             const unsigned rm = p.k.reward_mask;
             const bool leadL = (wg * 16 + threadIdx.x) % LEGS == 0;
 #pragma unroll
@@ -578,7 +629,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     Terr TR;
     TR.rows = PLANE ? 0 : HOT(o_terrain_rows); TR.cols = HOT(o_terrain_cols); TR.border = HOT(o_border); TR.ihs = 1.f / HOT(o_hscale);
     TR.vscale = HOT(o_vscale); TR.hf = p.hf;
-    constexpr bool HFC = PROF == 3 || PROF == 4;   // rough task profiles: a heightfield is bound (lg_kernel.h rough_profile)
+    constexpr bool HFC = PROF == 3 || PROF == 4 || PROF == 5 || PROF == 6;   // a heightfield is bound (host-checked: the rough task profiles of lg_host.hip; 5 = that and nothing else, generic tail)
     const bool hfmode = HFC ? true : (!PLANE && TR.rows > 0);
     const float mass0 = M->mass[0] + dr_mass;
     const float com0 = M->com[0][cj] + dr_com;
@@ -1672,16 +1723,12 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             float *px = B.priv_obs_buf + ((size_t)xs * N + e) * prow + (size_t)p.obs_win * PF;
             float *lab = B.labels_buf + ((size_t)cs * N + e) * h_num_labels;
             if (anyl(reset)) {                         // legged_robot_ee.py: the histories of a reset env restart from zeros
-                if (reset && live) {
-                    for (int i = ei; i < (ST - 1) * FR; i += 16) oc[i] = 0.f;
-                    for (int i = ei; i < (PST - 1) * PF; i += 16) pc[i] = 0.f;
-                }
+                blank_histories(__builtin_amdgcn_ballot_w64(reset && live && ei == 0), e, B.obs_buf + (size_t)cs * N * orow + (size_t)p.obs_win * FR, orow, (ST - 1) * FR,
+                                B.priv_obs_buf + (size_t)cs * N * prow + (size_t)p.obs_win * PF, prow, (PST - 1) * PF);
             }
             if (two && anyl(!reset && w_dirty != 0)) {
-                if (!reset && w_dirty != 0 && live) {
-                    for (int i = ei; i < (ST - 2) * FR; i += 16) oc[i] = 0.f;
-                    for (int i = ei; i < (PST - 2) * PF; i += 16) pc[i] = 0.f;
-                }
+                blank_histories(__builtin_amdgcn_ballot_w64(!reset && w_dirty != 0 && live && ei == 0), e, B.obs_buf + (size_t)cs * N * orow + (size_t)p.obs_win * FR, orow,
+                                (ST - 2) * FR, B.priv_obs_buf + (size_t)cs * N * prow + (size_t)p.obs_win * PF, prow, (PST - 2) * PF);
             }
             float *on = oc + (ST - 1) * FR, *on2 = ox + (ST - 1) * FR, *pn = pc + (PST - 1) * PF, *pn2 = px + (PST - 1) * PF;
             const bool w2o = two && ST > 1, w2p = two && PST > 1;
@@ -1828,16 +1875,12 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             float *pc = B.priv_obs_buf + ((size_t)cs * N + e) * prow + (size_t)p.obs_win * PF;
             float *px = B.priv_obs_buf + ((size_t)xs * N + e) * prow + (size_t)p.obs_win * PF;
             if (anyl(reset)) {                         // go2_wtw.py:174-178
-                if (reset && live) {
-                    for (int i = ei; i < (ST - 1) * FR; i += 16) oc[i] = 0.f;
-                    for (int i = ei; i < (PST - 1) * PF; i += 16) pc[i] = 0.f;
-                }
+                blank_histories(__builtin_amdgcn_ballot_w64(reset && live && ei == 0), e, B.obs_buf + (size_t)cs * N * orow + (size_t)p.obs_win * FR, orow, (ST - 1) * FR,
+                                B.priv_obs_buf + (size_t)cs * N * prow + (size_t)p.obs_win * PF, prow, (PST - 1) * PF);
             }
             if (two && anyl(!reset && w_dirty != 0)) {
-                if (!reset && w_dirty != 0 && live) {
-                    for (int i = ei; i < (ST - 2) * FR; i += 16) oc[i] = 0.f;
-                    for (int i = ei; i < (PST - 2) * PF; i += 16) pc[i] = 0.f;
-                }
+                blank_histories(__builtin_amdgcn_ballot_w64(!reset && w_dirty != 0 && live && ei == 0), e, B.obs_buf + (size_t)cs * N * orow + (size_t)p.obs_win * FR, orow,
+                                (ST - 2) * FR, B.priv_obs_buf + (size_t)cs * N * prow + (size_t)p.obs_win * PF, prow, (PST - 2) * PF);
             }
             float *on = oc + (ST - 1) * FR, *on2 = ox + (ST - 1) * FR, *pn = pc + (PST - 1) * PF, *pn2 = px + (PST - 1) * PF;
             const bool w2o = two && ST > 1, w2p = two && PST > 1;
@@ -1938,8 +1981,555 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         }
         STAMP(11);
     }
+    // ---------------- MDP phases in the same launch, tron1_pf_ee profile: component layout on the env's eight lanes ---------------------
+    // Same statements as env_step_body's POST / RESET phases for LG_OBS_TRON1_EE (legged_robot.py:55-168, 300-348; tron1_pf_ee.py:12-141,
+    // 193-256, 347-463), computed on the registers the physics left behind like the quadruped tails above: per-joint values in joint lanes,
+    // vectors one component per lane, per-env scalars replicated over the env's 8 lanes (lane el = 4 leg + c owns episode sums el + 8 k).
+    // The random stream is env_step_body's (same counters, same words), three Philox calls per lane at most:
+    //   A (every step)  lane c of leg l: observation-noise block 2 l | 2 l + 1 | 2 LEGS + 2 + l (actions) | 3 LEGS + 2 + l (clock)
+    //   B (every step)  lane 0: noise block 2 LEGS (base); lanes 1-6: the env-level reset bundle 0x200 + 0 .. 5; lane 7: the job-wide sit coin
+    //   C (a reset in the wave)  lane c of leg l: `_reset_dofs` | kp | kd blocks of the leg; lane 3 of leg 0: the root xy block
+    if constexpr (BQ) {
+        STAMP(5);
+        const auto h_about_landing_threshold = HOT(about_landing_threshold);
+        const auto h_add_noise = HOT(add_noise);
+        const auto h_air_time_cmd_dims = HOT(air_time_cmd_dims);
+        const auto h_b_swing = HOT(b_swing);
+        const auto h_base_height_sigma = HOT(base_height_sigma);
+        const auto h_base_height_target = HOT(base_height_target);
+        const auto h_base_init_quat_0 = HOT(base_init_quat[0]);
+        const auto h_base_init_quat_1 = HOT(base_init_quat[1]);
+        const auto h_base_init_quat_2 = HOT(base_init_quat[2]);
+        const auto h_base_init_quat_3 = HOT(base_init_quat[3]);
+        const auto h_clip_obs = HOT(clip_obs);
+        const auto h_control_dt = HOT(control_dt);
+        const auto h_custom_origins = HOT(custom_origins);
+        const auto h_dr_com_lo_0 = HOT(dr_com_lo[0]);
+        const auto h_dr_com_lo_1 = HOT(dr_com_lo[1]);
+        const auto h_dr_com_lo_2 = HOT(dr_com_lo[2]);
+        const auto h_dr_com_on = HOT(dr_com_on);
+        const auto h_dr_com_span_0 = HOT(dr_com_span[0]);
+        const auto h_dr_com_span_1 = HOT(dr_com_span[1]);
+        const auto h_dr_com_span_2 = HOT(dr_com_span[2]);
+        const auto h_dr_friction_lo = HOT(dr_friction_lo);
+        const auto h_dr_friction_on = HOT(dr_friction_on);
+        const auto h_dr_friction_span = HOT(dr_friction_span);
+        const auto h_dr_joint_lo_0 = HOT(dr_joint_lo[0]);
+        const auto h_dr_joint_lo_1 = HOT(dr_joint_lo[1]);
+        const auto h_dr_joint_lo_2 = HOT(dr_joint_lo[2]);
+        const auto h_dr_joint_on = HOT(dr_joint_on);
+        const auto h_dr_joint_span_0 = HOT(dr_joint_span[0]);
+        const auto h_dr_joint_span_1 = HOT(dr_joint_span[1]);
+        const auto h_dr_joint_span_2 = HOT(dr_joint_span[2]);
+        const auto h_dr_kd_lo = HOT(dr_kd_lo);
+        const auto h_dr_kd_span = HOT(dr_kd_span);
+        const auto h_dr_kp_lo = HOT(dr_kp_lo);
+        const auto h_dr_kp_span = HOT(dr_kp_span);
+        const auto h_dr_mass_lo = HOT(dr_mass_lo);
+        const auto h_dr_mass_on = HOT(dr_mass_on);
+        const auto h_dr_mass_span = HOT(dr_mass_span);
+        const auto h_dr_pd_on = HOT(dr_pd_on);
+        const auto h_env_id_offset = HOT(env_id_offset);
+        const auto h_episode_length_s = HOT(episode_length_s);
+        const auto h_fail_threshold = HOT(fail_threshold);
+        const auto h_feet_air_time_threshold = HOT(feet_air_time_threshold);
+        const auto h_foot_clearance_ref = HOT(foot_clearance_ref);
+        const auto h_foot_clearance_sigma = HOT(foot_clearance_sigma);
+        const auto h_foot_clearance_target = HOT(foot_clearance_target);
+        const auto h_foot_distance_threshold = HOT(foot_distance_threshold);
+        const auto h_foot_height_offset = HOT(foot_height_offset);
+        const auto h_friction_offset = HOT(friction_offset);
+        const auto h_gait_period_fixed = HOT(gait_period_fixed);
+        const auto h_heading_command = HOT(heading_command);
+        const auto h_heights_clip_scale = HOT(heights_clip_scale);
+        const auto h_heights_offset = HOT(heights_offset);
+        const auto h_kd_offset = HOT(kd_offset);
+        const auto h_kp_offset = HOT(kp_offset);
+        const auto h_max_episode_length = HOT(max_episode_length);
+        const auto h_max_projected_gravity = HOT(max_projected_gravity);
+        const auto h_max_push_vel_xy = HOT(max_push_vel_xy);
+        const auto h_max_terrain_level = HOT(max_terrain_level);
+        const auto h_noise_act0 = HOT(noise_act0);
+        const auto h_noise_lead_0 = HOT(noise_lead[0]);
+        const auto h_noise_lead_1 = HOT(noise_lead[1]);
+        const auto h_noise_lead_2 = HOT(noise_lead[2]);
+        const auto h_noise_lead_3 = HOT(noise_lead[3]);
+        const auto h_noise_lead_4 = HOT(noise_lead[4]);
+        const auto h_noise_lead_5 = HOT(noise_lead[5]);
+        const auto h_num_labels = HOT(num_labels);
+        const auto h_num_obs = HOT(num_obs);
+        const auto h_num_priv_obs = HOT(num_priv_obs);
+        const auto h_o_base_init_pos_0 = HOT(o_base_init_pos[0]);
+        const auto h_o_base_init_pos_1 = HOT(o_base_init_pos[1]);
+        const auto h_o_base_init_pos_2 = HOT(o_base_init_pos[2]);
+        const auto h_obs_frame = HOT(obs_frame);
+        const auto h_obs_scale_ang_vel = HOT(obs_scale_ang_vel);
+        const auto h_obs_scale_dof_pos = HOT(obs_scale_dof_pos);
+        const auto h_obs_scale_dof_vel = HOT(obs_scale_dof_vel);
+        const auto h_obs_scale_height = HOT(obs_scale_height);
+        const auto h_obs_scale_lin_vel = HOT(obs_scale_lin_vel);
+        const auto h_obs_sets = HOT(obs_sets);
+        const auto h_obs_slack = HOT(obs_slack);
+        const auto h_obs_stack = HOT(obs_stack);
+        const auto h_only_positive_rewards = HOT(only_positive_rewards);
+        const auto h_priv_frame = HOT(priv_frame);
+        const auto h_priv_stack = HOT(priv_stack);
+        const auto h_push_interval = HOT(push_interval);
+        const auto h_resample_steps = HOT(resample_steps);
+        const auto h_reset_ang_vel_lo = HOT(reset_ang_vel_lo);
+        const auto h_reset_ang_vel_span = HOT(reset_ang_vel_span);
+        const auto h_reset_lin_vel_lo = HOT(reset_lin_vel_lo);
+        const auto h_reset_lin_vel_span = HOT(reset_lin_vel_span);
+        const auto h_reset_root_xy_lo = HOT(reset_root_xy_lo);
+        const auto h_reset_root_xy_span = HOT(reset_root_xy_span);
+        const auto h_seed = HOT(seed);
+        const auto h_sit_percent = HOT(sit_percent);
+        const auto h_slots_cb_cmd = HOT(slots.cb_cmd);
+        const auto h_slots_dr_kd = HOT(slots.dr_kd);
+        const auto h_slots_dr_kp = HOT(slots.dr_kp);
+        const auto h_slots_push = HOT(slots.push);
+        const auto h_slots_reset_dof = HOT(slots.reset_dof);
+        const auto h_slots_reset_root_xy = HOT(slots.reset_root_xy);
+        const auto h_slots_task_reset = HOT(slots.task_reset);
+        const auto h_terrain_cols_n = HOT(terrain_cols_n);
+        const auto h_terrain_curriculum = HOT(terrain_curriculum);
+        const auto h_terrain_env_length = HOT(terrain_env_length);
+        const auto h_tracking_sigma = HOT(tracking_sigma);
+        const auto h_yaw_clip_0 = HOT(yaw_clip[0]);
+        const auto h_yaw_clip_1 = HOT(yaw_clip[1]);
+        asm volatile("" ::: "memory");
+        const float cdt = h_control_dt;
+        const unsigned rmask = (unsigned)p.k.reward_mask;
+        const bool heading = h_heading_command != 0;
+        unsigned k0, k1, e_lo, e_hi;
+        {
+            const unsigned long long seed = h_seed, gid = (unsigned long long)(h_env_id_offset + e);
+            k0 = (unsigned)(seed & 0xFFFFFFFFu); k1 = (unsigned)(seed >> 32);
+            e_lo = (unsigned)(gid & 0xFFFFFFFFu); e_hi = (unsigned)(gid >> 32);
+        }
+        const unsigned rstep = (unsigned)p.counter;
+        auto philox = [&](unsigned c3) { const U4 c = {e_lo, e_hi, rstep, c3}; return philox4x32_10(c, k0, k1); };
+        auto philox_e = [&](unsigned elo, unsigned ehi, unsigned c3) { const U4 c = {elo, ehi, rstep, c3}; return philox4x32_10(c, k0, k1); };
+        auto pick = [](const U4 &r, int k) { return k == 0 ? r.x : (k == 1 ? r.y : (k == 2 ? r.z : r.w)); };
+        auto anyl = [](bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; };
+        // lane l8 (0..7) of this env, to every lane of the env
+        auto fetch8 = [&](float v, int l8) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)((threadIdx.x & 56u) | (unsigned)l8) << 2, __float_as_int(v))); };
+        auto jsum = [&](float v) { return bc<0>(legsum<LEGS>(sum3(v))); };       // over the env's joints (value in joint lanes), to all lanes
+        auto vnorm2 = [&](float v) { return bc<0>(sum3(v * v)); };               // |v|^2 of a component-layout vector, to the quad
+        const int el = ei;                                                       // lane of the env: 4 leg + c
+
+        float cmdv = m_cmd, air = m_air;
+        float es[4] = {b_es[0], b_es[1], b_es[2], b_es[3]};
+        float o_fric = dr_fric, o_mass = dr_mass, o_com = dr_com, o_kp = dr_kp, o_kd = dr_kd, o_push = w_push;   // what the critic frame shows
+        float o_jnt = L.sel(dr_arm, dr_jf, dr_jd);                               // per-env joint DR (armature, frictionloss, damping), component c
+        int ep_len = m_ep + 1, failb = m_fail, last_contact = m_lc;              // legged_robot.py:60
+        float gait_time = w_gt, phi = w_phi, theta = w_th, expC = w_ec;
+        const float gait_period = h_gait_period_fixed;
+        const float CRlo = L.is0 ? CR(0) : (L.is1 ? CR(2) : (L.is2 ? CR(4) : CR(6)));
+        const float CRhi = L.is0 ? CR(1) : (L.is1 ? CR(3) : (L.is2 ? CR(5) : CR(7)));
+        auto resample = [&](float cv, float u0, float u1, float u2) {            // legged_robot.py:317-334
+            const float u = L.is0 ? u0 : (L.is1 ? u1 : u2);
+            const bool upd = heading ? !L.is2 : !L.is3;                          // heading mode draws the heading, not the yaw rate
+            cv = upd ? (CRhi - CRlo) * u + CRlo : cv;
+            const float keep = sqrtf(bc<0>(sum3(cv * cv))) > 0.2f ? 1.f : 0.f;
+            return L.is3 ? cv : cv * keep;
+        };
+        // ---- _post_physics_step_callback (legged_robot.py:300-315) ----
+        {
+            const bool need = (ep_len % h_resample_steps) == 0;
+            if (anyl(need)) {
+                const U4 r = philox(0x40000000u + (unsigned)h_slots_cb_cmd);
+                const float nc = resample(cmdv, u01(r.x), u01(r.y), u01(r.z));
+                cmdv = need ? nc : cmdv;
+            }
+        }
+        if (heading) {   // forward = quat_apply(base_quat, [1,0,0]) (math_utils.py:34-40): t = 2 xyz x b = (0, 2 qz, -2 qy)
+            const float ty = 2.f * qz, tz = -2.f * qy;
+            const float fx = 1.f + (qy * tz - qz * ty), fy = ty * qw + (0.f - qx * tz);
+            const float hd = atan2f(fy, fx);
+            const float c2 = clampf(0.5f * wrap_to_pi(bc<3>(cmdv) - hd), h_yaw_clip_0, h_yaw_clip_1);
+            cmdv = L.is2 ? c2 : cmdv;
+        }
+        {
+            const int pi_ = h_push_interval;
+            if (pi_ > 0 && (p.counter % pi_) == 0) {   // genesis_simulator.py:150-158; lanes 0 / 1 evaluate the two draws' blocks side by side
+                const int slot = h_slots_push + (L.is1 ? 1 : 0);
+                const U4 r = philox((unsigned)(slot >> 2));
+                const float m = h_max_push_vel_xy;
+                const float pv = (m + m) * u01(pick(r, slot & 3)) - m;
+                const bool xy = L.c < 2;
+                vw = xy ? vw + pv : vw;
+                o_push = xy ? pv : o_push;
+                if (live && leg == 0 && xy) { B.rand_push_vels[3 * e + L.c] = pv; B.base_lin_vel_w[3 * e + L.c] = vw; }
+            }
+        }
+        const float cmd0 = bc<0>(cmdv), cmd1 = bc<1>(cmdv), cmd2 = bc<2>(cmdv);
+        STAMP(6);
+        // ---- check_termination (legged_robot.py:78-92) ----
+        const unsigned tmask = M->term_link_mask, pmask = M->pen_link_mask;
+        const int l0 = foot_link - 3;
+        float n2[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) n2[k] = vnorm2(f_link[k]);
+        const float nb2 = vnorm2(f_base);
+        const float pgz = bc<2>(pg);
+        int fail = 0;
+#pragma unroll
+        for (int k = 0; k < 4; k++) fail |= (((tmask >> (l0 + k)) & 1u) && n2[k] > 100.0f) ? 1 : 0;
+        fail |= __builtin_amdgcn_ds_swizzle(fail, 0x101F);                       // the other leg (lane ^ 4)
+        fail |= ((tmask & 1u) && nb2 > 100.0f) ? 1 : 0;
+        fail |= pgz > h_max_projected_gravity ? 1 : 0;
+        if (guard_bad) failb = LG_FAIL_NONFINITE;   // a re-seated env ends its episode here (lgsim.h)
+        failb += fail;
+        const bool time_out = (float)ep_len > h_max_episode_length;
+        const bool reset = ((float)failb > h_fail_threshold) || time_out;
+
+        // ---- compute_reward (legged_robot.py:150-168): every term replicated over the env's lanes, summed in alphabetical order ----
+        float scl[LG_R_COUNT];
+#pragma unroll
+        for (int k = 0; k < LG_R_COUNT; k++) scl[k] = HOT(reward_scales[k]);
+        float total = 0.f;
+        auto add = [&](int id, float r) {            // `id` is a compile-time constant at every call
+            const float rew = r * scl[id];
+            total += rew;
+            es[id >> 3] = el == (id & 7) ? es[id >> 3] + rew : es[id >> 3];
+        };
+        const float cmd_xy = sqrtf(cmd0 * cmd0 + cmd1 * cmd1);
+        const float cmd_xyz = sqrtf(cmd0 * cmd0 + cmd1 * cmd1 + cmd2 * cmd2);
+        const float dq0 = q - q0;
+        const float fz = bc<2>(f_link[3]);                          // vertical foot force of this leg
+        const float fpx = bc<0>(foot_p), fpy = bc<1>(foot_p), fpz = bc<2>(foot_p), fvx = bc<0>(foot_v), fvy = bc<1>(foot_v), fvz = bc<2>(foot_v);
+        // mean over the terrain samples of (base z - height) (legged_robot.py:470-476, tron1_pf_ee.py:435-440): every lane adds its own samples
+        float mean_height = bc<2>(pos);
+        if (P > 0) {
+            const float pzv = bc<2>(pos);
+            float acc = 0.f;
+#pragma unroll
+            for (int i = 0; i < HQ; i++) acc += (hk0 + i * kstride < P) ? pzv - hq[i] : 0.f;
+            mean_height = legsum<LEGS>(sum4(acc)) / (float)P;
+        }
+        if (RON(LG_R_ACTION_RATE)) { const float d = last_act - act; add(LG_R_ACTION_RATE, jsum(d * d)); }                     // :495-497
+        if (RON(LG_R_ACTION_SMOOTHNESS)) { const float d = act - 2.f * last_act + llast_act; add(LG_R_ACTION_SMOOTHNESS, jsum(d * d)); }   // :499-503
+        if (RON(LG_R_ANG_VEL_XY)) { const float bx = bc<0>(bav), by = bc<1>(bav); add(LG_R_ANG_VEL_XY, bx * bx + by * by); }    // :462-464
+        if (RON(LG_R_BASE_HEIGHT)) { const float d = mean_height - h_base_height_target; add(LG_R_BASE_HEIGHT, d * d); }        // :470-476
+        if (RON(LG_R_BIPED_PERIODIC_GAIT)) {                                                                                     // tron1_pf_ee.py:347-433 ("step" indicator)
+            const float two_pi = 6.283185307179586f;
+            float ph = phi + theta;
+            ph = (ph - floorf(ph)) * two_pi;
+            const float b_sw = h_b_swing * two_pi;
+            const float c_frc = (ph >= 0.f && ph < b_sw) ? -1.f : 0.f;
+            const float c_spd = (ph >= b_sw && ph < two_pi) ? -1.f : 0.f;
+            expC = c_frc;
+            add(LG_R_BIPED_PERIODIC_GAIT, __expf(legsum<LEGS>(c_spd * sqrtf(vnorm2(foot_v)) + c_frc * sqrtf(n2[3]))));
+        }
+        if (RON(LG_R_COLLISION)) {                                                                                               // :505-512
+            float sc_ = 0.f;
+#pragma unroll
+            for (int k = 0; k < 4; k++) sc_ += (((pmask >> (l0 + k)) & 1u) && n2[k] > 0.1f * 0.1f) ? 1.f : 0.f;
+            sc_ = legsum<LEGS>(sc_);
+            sc_ += ((pmask & 1u) && nb2 > 0.1f * 0.1f) ? 1.f : 0.f;
+            add(LG_R_COLLISION, sc_);
+        }
+        if (RON(LG_R_DOF_ACC)) { const float d = (qd_start - qd) / cdt; add(LG_R_DOF_ACC, jsum(d * d)); }                       // :490-493
+        if (RON(LG_R_DOF_CLOSE_TO_DEFAULT)) add(LG_R_DOF_CLOSE_TO_DEFAULT, jsum(dq0 * dq0));                                     // :571-573
+        if (RON(LG_R_DOF_POS_LIMITS)) add(LG_R_DOF_POS_LIMITS, jsum(-fminf(q - m_slo, 0.f) + fmaxf(q - m_shi, 0.f)));            // :518-522
+        if (RON(LG_R_DOF_POS_STAND_STILL)) add(LG_R_DOF_POS_STAND_STILL, jsum(dq0 * dq0) * (cmd_xyz < 0.1f ? 1.f : 0.f));        // :561-563
+        if (RON(LG_R_DOF_POWER)) add(LG_R_DOF_POWER, jsum(fabsf(torque * qd)));                                                  // :486-488
+        if (RON(LG_R_DOF_VEL)) add(LG_R_DOF_VEL, jsum(qd * qd));                                                                 // :482-484
+        if (RON(LG_R_DOF_VEL_STAND_STILL)) add(LG_R_DOF_VEL_STAND_STILL, jsum(fabsf(qd)) * (cmd_xyz < 0.1f ? 1.f : 0.f));        // :557-559
+        if (RON(LG_R_FEET_AIR_TIME)) {                                                                                           // :545-555 (stateful)
+            const int contact = fz > 1.0f ? 1 : 0;
+            const int filt = contact | last_contact;
+            last_contact = contact;
+            const float first = (air > 0.f ? 1.f : 0.f) * (float)filt;
+            air += cdt;
+            float r = legsum<LEGS>((air - h_feet_air_time_threshold) * first);
+            r *= (h_air_time_cmd_dims == 3 ? cmd_xyz : cmd_xy) > 0.1f ? 1.f : 0.f;
+            air *= filt ? 0.f : 1.f;
+            add(LG_R_FEET_AIR_TIME, r);
+        }
+        if (RON(LG_R_FEET_CONTACT_STAND_STILL)) {                                                                                // :565-569
+            const float cnt = legsum<LEGS>(fz > 0.1f ? 1.f : 0.f);
+            add(LG_R_FEET_CONTACT_STAND_STILL, (cnt == (float)LEGS ? 1.f : 0.f) * (cmd_xyz < 0.1f ? 1.f : 0.f));
+        }
+        if (RON(LG_R_FEET_DISTANCE)) {                                                                                           // tron1_pf_ee.py:458-463
+            const float ox = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(fpx), 0x101F));
+            const float oy = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(fpy), 0x101F));
+            const float dxy = sqrtf((fpx - ox) * (fpx - ox) + (fpy - oy) * (fpy - oy));
+            add(LG_R_FEET_DISTANCE, fmaxf(0.f, h_foot_distance_threshold - dxy));
+        }
+        if (RON(LG_R_FOOT_ACC)) { const float a = (foot_v - last_foot_v) * (1.f / cdt); add(LG_R_FOOT_ACC, legsum<LEGS>(vnorm2(a))); }    // :605-608
+        if (RON(LG_R_FOOT_CLEARANCE)) {                                                                                          // :575-588, tron1_pf_ee.py:442-456
+            const float vxy = sqrtf(fvx * fvx + fvy * fvy);
+            const float d = fpz - (h_foot_clearance_ref == 1 ? f_hmean : (h_foot_clearance_ref == 2 ? f_hmax : 0.f)) - h_foot_clearance_target - h_foot_height_offset;
+            add(LG_R_FOOT_CLEARANCE, __expf(-legsum<LEGS>(vxy * (d * d)) / h_foot_clearance_sigma));
+        }
+        if (RON(LG_R_FOOT_LANDING_VEL)) {                                                                                        // :590-599
+            const bool land = ((fpz - h_foot_height_offset) < h_about_landing_threshold) && !(fz > 0.1f) && (fvz < 0.f);
+            const float vz = land ? fvz : 0.f;
+            add(LG_R_FOOT_LANDING_VEL, legsum<LEGS>(vz * vz));
+        }
+        if (RON(LG_R_HIP_POS)) { const float h = bc<0>(dq0); add(LG_R_HIP_POS, legsum<LEGS>(h * h)); }                           // go2_ee.py:152-159
+        if (RON(LG_R_KEEP_BALANCE)) add(LG_R_KEEP_BALANCE, 1.f);                                                                 // :601-603
+        if (RON(LG_R_LIN_VEL_Z)) { const float z = bc<2>(blv); add(LG_R_LIN_VEL_Z, z * z); }                                     // :458-460
+        if (RON(LG_R_NO_FLY)) add(LG_R_NO_FLY, legsum<LEGS>(fz > kT->no_fly_contact_threshold ? 1.f : 0.f) == 1.f ? 1.f : 0.f);  // tron1_pf.py:151-154
+        if (RON(LG_R_ORIENTATION)) { const float x = bc<0>(pg), y = bc<1>(pg); add(LG_R_ORIENTATION, x * x + y * y); }           // :466-468
+        if (RON(LG_R_TORQUES)) add(LG_R_TORQUES, jsum(torque * torque));                                                         // :478-480
+        if (RON(LG_R_TRACKING_ANG_VEL)) { const float d = cmd2 - bc<2>(bav); add(LG_R_TRACKING_ANG_VEL, __expf(-(d * d) / h_tracking_sigma)); }   // :539-543
+        if (RON(LG_R_TRACKING_BASE_HEIGHT)) { const float d = mean_height - h_base_height_target; add(LG_R_TRACKING_BASE_HEIGHT, __expf(-(d * d) / h_base_height_sigma)); }   // tron1_pf_ee.py:435-440
+        if (RON(LG_R_TRACKING_LIN_VEL)) {                                                                                        // :533-537
+            const float dx = cmd0 - bc<0>(blv), dy = cmd1 - bc<1>(blv);
+            add(LG_R_TRACKING_LIN_VEL, __expf(-(dx * dx + dy * dy) / h_tracking_sigma));
+        }
+        if (h_only_positive_rewards) total = fmaxf(total, 0.f);                                                               // :161-162
+        if (RON(LG_R_TERMINATION)) add(LG_R_TERMINATION, (reset && !time_out) ? 1.f : 0.f);                                      // :163-168
+        {   // gait clock (tron1_pf_ee.py:28-35)
+            gait_time += cdt;
+            if (gait_time >= gait_period - cdt / 2.f) gait_time = 0.f;
+            phi = gait_time / gait_period;
+        }
+
+        STAMP(7);
+        // ---- Philox calls A and B (every step; see the head of this block) ----
+        const U4 rA = philox(0x80000000u + (L.is0 ? (unsigned)(2 * leg) : (L.is1 ? (unsigned)(2 * leg) + 1u
+                                           : (L.is2 ? (unsigned)(2 * LEGS + 2 + leg) : (unsigned)(3 * LEGS + 2 + leg)))));
+        const bool coin_lane = el == 7;
+        const U4 rB = philox_e(coin_lane ? 0xFFFFFFFFu : e_lo, coin_lane ? 0xFFFFFFFFu : e_hi,
+                               el == 0 ? 0x80000000u + (unsigned)(2 * LEGS) : (coin_lane ? (unsigned)(h_slots_task_reset >> 2) : 0x80000000u + 0x200u + (unsigned)(el - 1)));
+        const float ax = u01(rA.x), ay = u01(rA.y), az = u01(rA.z), aw = u01(rA.w);
+        const float bx = u01(rB.x), by = u01(rB.y), bz = u01(rB.z), bw = u01(rB.w);
+        // ---- reset_idx (legged_robot.py:94-148, tron1_pf_ee.py:193-256, 277-310) + simulator.reset_idx (genesis_simulator.py:62-82) ----
+        if (anyl(reset)) {
+            // element c of the bundle block held by lane `src` of the env (uniform i of the bundle = block i / 4, word i % 4; slots of
+            // env_step_body's eu[]: 0-2 commands, 3 friction, 4-6 CoM, 7 mass, 8-10 root lin vel, 12-14 root ang vel, 16-18 joint
+            // armature / friction / damping, 19-20 gait phase offsets, 21 terrain level)
+            auto bundle_c = [&](int src) { return L.sel4(fetch8(bx, src), fetch8(by, src), fetch8(bz, src), fetch8(bw, src)); };
+            const float v0 = bundle_c(1), v1 = bundle_c(2), v2 = bundle_c(3), v3_ = bundle_c(4), v4 = bundle_c(5);
+            const float u_gt = fetch8(bx, 6), u_tl = fetch8(by, 6);                               // uniforms 20, 21
+            const float u_coin = fetch8(u01(pick(rB, h_slots_task_reset & 3)), 7);                // tron1_pf_ee.py:204-210: one coin for the whole job
+            // call C: lane 0 / 1 / 2 of the quad: the leg's `_reset_dofs` / kp / kd blocks, lane 3 of leg 0: the root xy block
+            const int sxy = h_slots_reset_root_xy;
+            const U4 rC = philox(L.is0 ? 0x40000000u + (unsigned)(h_slots_reset_dof + d0) : (L.is1 ? 0x40000000u + (unsigned)(h_slots_dr_kp + d0)
+                                       : (L.is2 ? 0x40000000u + (unsigned)(h_slots_dr_kd + d0) : (unsigned)(sxy >> 2))));
+            const float cx_ = u01(rC.x), cy_ = u01(rC.y), cz_ = u01(rC.z);
+            const float ud = L.sel(bc<0>(cx_), bc<0>(cy_), bc<0>(cz_));                           // element c of lane 0's block
+            const float nkp = h_dr_kp_span * L.sel(bc<1>(cx_), bc<1>(cy_), bc<1>(cz_)) + h_dr_kp_lo;
+            const float nkd = h_dr_kd_span * L.sel(bc<2>(cx_), bc<2>(cy_), bc<2>(cz_)) + h_dr_kd_lo;
+            const float pxy0 = u01(pick(rC, sxy & 3)), pxy1 = u01(pick(rC, (sxy + 1) & 3));      // valid in lane 3 of leg 0
+            const float u_x = fetch8(pxy0, 3), u_y = fetch8(pxy1, 3);
+            const float u_xy = L.is0 ? u_x : u_y;
+            const bool sit = h_sit_percent > 0.f && u_coin < h_sit_percent;
+            // terrain curriculum (legged_robot.py:254-272 + genesis_simulator.py:140-148; skipped on the construction-time reset)
+            float norg = origin;
+            int nlvl = w_lvl;
+            const bool curr = h_terrain_curriculum && p.counter > 0;
+            if (curr) {
+                const float dd = pos - origin;
+                const float dx = bc<0>(dd), dy = bc<1>(dd);
+                const float dist = sqrtf(dx * dx + dy * dy);
+                const bool up = dist > h_terrain_env_length / 2.f;
+                const bool down = (dist < sqrtf(cmd0 * cmd0 + cmd1 * cmd1) * h_episode_length_s * 0.5f) && !up;
+                int lvl = w_lvl + (up ? 1 : 0) - (down ? 1 : 0);
+                if (lvl >= h_max_terrain_level) lvl = min((int)floorf(u_tl * (float)h_max_terrain_level), h_max_terrain_level - 1);
+                else lvl = max(lvl, 0);
+                nlvl = lvl;
+                norg = B.terrain_origins[((size_t)lvl * h_terrain_cols_n + w_type) * 3 + cj];
+            }
+            const float ncmd = resample(cmdv, bc<0>(v0), bc<1>(v0), bc<2>(v0));
+            float ipos = (sit ? b_sitp : L.sel(h_o_base_init_pos_0, h_o_base_init_pos_1, h_o_base_init_pos_2)) + norg;
+            if (h_custom_origins && L.c < 2) ipos += h_reset_root_xy_span * u_xy + h_reset_root_xy_lo;          // legged_robot.py:288
+            const float iq = sit ? b_sitr : (L.is3 ? h_base_init_quat_3 : L.sel(h_base_init_quat_0, h_base_init_quat_1, h_base_init_quat_2));
+            const float nvw = sit ? 0.f : h_reset_lin_vel_span * v2 + h_reset_lin_vel_lo;                        // legged_robot.py:289-292; tron1_pf_ee.py:304-309
+            const float nww = sit ? 0.f : h_reset_ang_vel_span * v3_ + h_reset_ang_vel_lo;
+            // quad broadcasts stay outside the divergent branch
+            const float nfric = h_dr_friction_span * bc<3>(v0) + h_dr_friction_lo, nmass = h_dr_mass_span * bc<3>(v1) + h_dr_mass_lo;
+            const float ncom = L.sel(h_dr_com_span_0, h_dr_com_span_1, h_dr_com_span_2) * v1 + L.sel(h_dr_com_lo_0, h_dr_com_lo_1, h_dr_com_lo_2);
+            const float njnt = L.sel(h_dr_joint_span_0, h_dr_joint_span_1, h_dr_joint_span_2) * v4 + L.sel(h_dr_joint_lo_0, h_dr_joint_lo_1, h_dr_joint_lo_2);
+            const float th0 = b_th0 + bc<3>(v4);                                                                  // tron1_pf_ee.py:220-226
+            const float ntheta = foot_slot == 0 ? th0 : th0 + (b_th1 - b_th0);
+            if (reset) {
+                theta = ntheta; gait_time = u_gt * gait_period; phi = gait_time / gait_period;
+                if (h_dr_pd_on) { o_kp = nkp; o_kd = nkd; }
+                if (h_dr_friction_on) o_fric = nfric;
+                if (h_dr_mass_on) o_mass = nmass;
+                if (h_dr_com_on) o_com = ncom;
+                if (h_dr_joint_on && B.joint_armature) o_jnt = njnt;
+                cmdv = ncmd;
+                q = sit ? b_sitq : q0 + (m_rsp * ud + m_rlo); qd = 0.f;
+                act = 0.f; last_act = 0.f; llast_act = 0.f;
+                pos = ipos; quat = iq; vw = nvw; ww = nww;
+                air = 0.f; ep_len = 0; failb = 0;
+            }
+            // the reference stores the commanded reset twist verbatim in the body-frame properties (genesis_simulator.py:128-129)
+            // and refreshes projected gravity (:125)
+            const QM Rr = quat_rows(L, quat);
+            const float npg = -L.sel(bc<2>(Rr.c0), bc<2>(Rr.c1), bc<2>(Rr.c2));
+            if (reset) { blv = vw; bav = ww; pg = npg; }
+            if (reset && st) {
+                B.dof_pos[ja] = q; B.dof_vel[ja] = 0.f; B.last_dof_vel[ja] = 0.f;
+                B.actions[ja] = 0.f; B.last_actions[ja] = 0.f; B.llast_actions[ja] = 0.f;
+                if (h_dr_pd_on) { B.kp_scale[ja] = o_kp; B.kd_scale[ja] = o_kd; }
+                B.last_feet_vel[(e * F + foot_slot) * 3 + cj] = 0.f;
+                if (leg == 0) {
+                    if (curr) { B.env_origins[3 * e + cj] = norg; if (L.is0) B.terrain_levels[e] = nlvl; }
+                    B.base_pos[3 * e + cj] = pos; B.base_lin_vel_w[3 * e + cj] = vw; B.base_ang_vel_w[3 * e + cj] = ww;
+                    B.base_lin_vel[3 * e + cj] = blv; B.base_ang_vel[3 * e + cj] = bav; B.projected_gravity[3 * e + cj] = pg;
+                    B.last_base_lin_vel[3 * e + cj] = 0.f; B.last_base_ang_vel[3 * e + cj] = 0.f;
+                    if (h_dr_com_on) B.base_com_bias[3 * e + cj] = o_com;
+                }
+                if (leg == 1 && h_dr_joint_on && B.joint_armature) {   // genesis_simulator.py:704-733: one value per env each
+                    float *jp = L.is0 ? B.joint_armature : (L.is1 ? B.joint_friction : B.joint_damping);
+                    jp[e] = o_jnt;
+                }
+            }
+            if (reset && live && leg == 0) {
+                B.base_quat[4 * e + L.c] = quat;
+                if (L.is3) {
+                    if (h_dr_friction_on) B.friction_values[e] = o_fric;
+                    if (h_dr_mass_on) B.added_base_mass[e] = o_mass;
+                    B.episode_done_step[e] = (int)p.counter;
+                }
+            }
+            if (reset && live) {    // extras["episode"] snapshot (legged_robot.py:128-132), then the sums restart
+#pragma unroll
+                for (int k = 0; k < 4; k++)
+                    if (el + 8 * k < LG_R_COUNT && ((rmask >> (el + 8 * k)) & 1u)) { B.episode_done_sums[(size_t)(el + 8 * k) * N + e] = es[k]; es[k] = 0.f; }
+            }
+        }
+        STAMP(9);
+        {
+            // ---- compute_observations + clip, tron1_pf_ee.py:53-141.  actor frame: 9 + 3 A + clock 2 F, stacked 10 deep; critic frame: the
+            //      frame without noise | DR (7 + 2 A + 3) | gait F | contact states K | heights P | normals 3 F | clip(foot_z - h9) 9 F,
+            //      stacked 10 deep; labels: v_b 3 | K | foot height above the local terrain max F | normals 3 F.  Same window / copy /
+            //      blanking bookkeeping as the quadruped tails; the env's 8 lanes write consecutive columns.
+            const float co = h_clip_obs;
+            const bool nz = h_add_noise != 0;
+            const int FR = h_obs_frame, PF = h_priv_frame, ST = h_obs_stack, PST = h_priv_stack, SL = h_obs_slack;
+            const size_t orow = (size_t)(h_num_obs + SL * FR), prow = (size_t)(h_num_priv_obs + SL * PF);
+            const bool two = h_obs_sets > 1;
+            const int cs = two ? p.obs_set : 0, xs = (two && cs < 2) ? 1 - cs : cs;
+            // Every destination = a wave-uniform base (this set's / the other set's allocation) + a 32-bit byte offset per lane: the store takes
+            // the base from scalar registers (saddr form) and the offset costs one add, instead of a 64-bit pointer computation per store
+            // (~5 VALU instructions each, ~70 stores per lane).  The allocations stay below 4 GiB (lg_host.hip biped_profile).
+            float *const ob_c = B.obs_buf + (size_t)cs * N * orow, *const ob_x = B.obs_buf + (size_t)xs * N * orow;
+            float *const pb_c = B.priv_obs_buf + (size_t)cs * N * prow, *const pb_x = B.priv_obs_buf + (size_t)xs * N * prow;
+            float *const lb_c = B.labels_buf + (size_t)cs * N * h_num_labels;
+            const unsigned io4 = ((unsigned)e * (unsigned)orow + (unsigned)(p.obs_win * FR + (ST - 1) * FR)) * 4u;     // newest frame of this launch's window
+            const unsigned ip4 = ((unsigned)e * (unsigned)prow + (unsigned)(p.obs_win * PF + (PST - 1) * PF)) * 4u;
+            const unsigned il4 = (unsigned)e * (unsigned)h_num_labels * 4u;
+            auto SO = [](float *base, unsigned off, float v) { *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + off) = v; };
+            if (anyl(reset)) {                         // legged_robot_ee.py: the histories of a reset env restart from zeros
+                blank_histories(__builtin_amdgcn_ballot_w64(reset && live && el == 0), e, B.obs_buf + (size_t)cs * N * orow + (size_t)p.obs_win * FR, orow, (ST - 1) * FR,
+                                B.priv_obs_buf + (size_t)cs * N * prow + (size_t)p.obs_win * PF, prow, (PST - 1) * PF);
+            }
+            if (two && anyl(!reset && w_dirty != 0)) {
+                blank_histories(__builtin_amdgcn_ballot_w64(!reset && w_dirty != 0 && live && el == 0), e, B.obs_buf + (size_t)cs * N * orow + (size_t)p.obs_win * FR, orow,
+                                (ST - 2) * FR, B.priv_obs_buf + (size_t)cs * N * prow + (size_t)p.obs_win * PF, prow, (PST - 2) * PF);
+            }
+            const bool w2o = two && ST > 1, w2p = two && PST > 1;
+            float uq = 0.5f, uqd = 0.5f, uact = 0.5f, uclk = 0.5f, ug = 0.5f, ua = 0.5f;
+            if (nz) {
+                uq = L.sel(bc<0>(ax), bc<0>(ay), bc<0>(az));                 // block 2 leg in lane 0 of the quad: the three joints' uniforms
+                uqd = L.sel(bc<1>(ax), bc<1>(ay), bc<1>(az));                // block 2 leg + 1 in lane 1
+                // base uniforms (env_step_body's ub[]): 0 / 1 = fourth words of leg 0's two blocks, 2-5 = block 2 LEGS (call B, lane 0)
+                ug = L.sel(fetch8(aw, 0), fetch8(aw, 1), fetch8(bx, 0));
+                ua = L.sel(fetch8(by, 0), fetch8(bz, 0), fetch8(bw, 0));
+                if (h_noise_act0 != 0.f) {                                   // tron1_pf_ee.py:338-342 (quirk 4): actions and clock are noisy too
+                    uact = L.sel(bc<2>(ax), bc<2>(ay), bc<2>(az));           // block 2 LEGS + 2 + leg in lane 2
+                    const float ck0 = bc<3>(ax), ck1 = bc<3>(ay);            // block 3 LEGS + 2 + leg in lane 3: sin / cos entries
+                    uclk = L.is0 ? ck0 : ck1;
+                }
+            }
+            auto W = [&](int idx, float v, float u, float ns) {            // an actor-frame entry: noisy into the actor windows, noise-free into the critic frame
+                const float cl = clampf(v, -co, co);
+                const float nv = clampf(nz ? v + (2.f * u - 1.f) * ns : v, -co, co);
+                const unsigned o4 = io4 + 4u * (unsigned)idx, p4 = ip4 + 4u * (unsigned)idx;
+                SO(ob_c, o4, nv); if (w2o) SO(ob_x, o4, nv);
+                SO(pb_c, p4, cl); if (w2p) SO(pb_x, p4, cl);
+            };
+            auto WP = [&](int idx, float v) { const float cl = clampf(v, -co, co); const unsigned p4 = ip4 + 4u * (unsigned)idx; SO(pb_c, p4, cl); if (w2p) SO(pb_x, p4, cl); };
+            auto WL = [&](int idx, float v) { SO(lb_c, il4 + 4u * (unsigned)idx, v); };
+            const float ang = 6.283185307179586f * (phi + theta);            // clock inputs (tron1_pf_ee.py:186-191)
+            const float sn = sinf(ang), csn = cosf(ang);
+            // quad broadcasts outside the divergent branches
+            const float env4 = L.sel4(o_fric - h_friction_offset, o_mass, bc<0>(o_push), bc<1>(o_push));
+            const float pzn = bc<2>(pos);
+            const unsigned smask = M->state_link_mask;
+            const int K = __popc(smask);
+            const float csv = (L.sel4(n2[0], n2[1], n2[2], n2[3]) > 1.f) ? 1.f : 0.f;     // contact state of link l0 + c (physics read-back, stale after a reset as in the reference)
+            const int cl_ = l0 + L.c;
+            const bool chas = ((smask >> cl_) & 1u) != 0;
+            const int cidx = __popc(smask & ((1u << cl_) - 1u));
+            const int oDR = FR, oG = FR + 7 + 2 * A + 3, oK = oG + F, oH = oK + K, oN = oH + P, oR = oN + 3 * F;
+            const float clr = clampf(fpz - f_hmax - h_foot_height_offset, -1.f, 1.f);
+            const float nrm = L.sel(f_n3[0], f_n3[1], f_n3[2]);
+            if (st) {
+                W(9 + d0 + cj, (q - q0) * h_obs_scale_dof_pos, uq, m_nq);
+                W(9 + A + d0 + cj, qd * h_obs_scale_dof_vel, uqd, m_nqd);
+                W(9 + 2 * A + d0 + cj, act, uact, b_nact);
+                if (L.c < 2) W(9 + 3 * A + (L.is0 ? 0 : F) + foot_slot, L.is0 ? sn : csn, uclk, L.is0 ? b_nclk0 : b_nclk1);
+                WP(oDR + 7 + d0 + cj, o_kp - h_kp_offset);
+                WP(oDR + 7 + A + d0 + cj, o_kd - h_kd_offset);
+                WP(oN + 3 * foot_slot + cj, nrm);
+                WL(3 + K + F + 3 * foot_slot + cj, nrm);
+                if (L.is2) { WP(oG + foot_slot, expC); WL(3 + K + foot_slot, clr); }
+                if (leg == 0) {
+                    W(cj, cmdv * (L.is2 ? h_obs_scale_ang_vel : h_obs_scale_lin_vel), 0.5f, 0.f);
+                    W(3 + cj, pg, ug, L.sel(h_noise_lead_0, h_noise_lead_1, h_noise_lead_2));
+                    W(6 + cj, bav * h_obs_scale_ang_vel, ua, L.sel(h_noise_lead_3, h_noise_lead_4, h_noise_lead_5));
+                    WP(oDR + 2 + cj, o_com);
+                    WP(oDR + 7 + 2 * A + cj, o_jnt);
+                    WL(cj, blv * h_obs_scale_lin_vel);
+                }
+            }
+            if (live) {
+                if (leg == 1) WP(oDR + (L.c < 2 ? L.c : 3 + L.c), env4);                 // friction, mass | push x, y at oDR + 5, 6
+                if (chas) { WP(oK + cidx, csv); WL(3 + cidx, csv); }
+                if (leg == 0 && L.is3 && (smask & 1u)) { const float cb = nb2 > 1.f ? 1.f : 0.f; WP(oK, cb); WL(3, cb); }
+#pragma unroll
+                for (int i = 0; i < HQ; i++) {
+                    const int k = hk0 + i * kstride;
+                    float hv = pzn - h_heights_offset - hq[i];
+                    if (h_heights_clip_scale) hv = clampf(hv, -1.f, 1.f) * h_obs_scale_height;
+                    if (k < P) WP(oH + k, hv);
+                }
+#pragma unroll
+                for (int k = 0; k < 9; k++)
+                    if ((k & 3) == L.c) WP(oR + 9 * foot_slot + k, clampf(fpz - f_h9[k], -1.f, 1.f));
+                // task state as the env class exposes it (tron1_pf_ee.py:167-184), the second action-history shift
+                // (tron1_pf_ee.py:45-46: afterwards last == llast == a_t)
+                float *ts = B.task_state + (size_t)e * LG_TASK_STATE_BIPED;
+                if (L.is0) { ts[4 + foot_slot] = theta; ts[10 + foot_slot] = expC; }
+                if (L.c < 2) ts[6 + (L.is0 ? 0 : F) + foot_slot] = L.is0 ? sn : csn;
+                if (leg == 0 && L.c < 3) ts[L.c] = L.sel(gait_time, phi, gait_period);
+                if (leg == 0 && L.is0 && B.obs_dirty) B.obs_dirty[e] = reset ? 1 : 0;
+            }
+            if (st) {
+                B.llast_actions[ja] = reset ? 0.f : last_act;
+                B.last_actions[ja] = act;
+            }
+        }
+        STAMP(10);
+        // ---- persistent MDP state ----
+        if (live) {
+            const unsigned es4 = ((unsigned)el * (unsigned)N + (unsigned)e) * 4u;      // (term, N) rows: uniform base + 32-bit offset per lane
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (el + 8 * k < LG_R_COUNT && ((rmask >> (el + 8 * k)) & 1u))
+                    *reinterpret_cast<float *>(reinterpret_cast<char *>(B.episode_sums + (size_t)8 * k * N) + es4) = es[k];
+            if (L.is0) { B.feet_air_time[e * F + foot_slot] = air; B.last_contacts[e * F + foot_slot] = (uint8_t)last_contact; }
+            if (leg == 0) {
+                B.commands[4 * e + L.c] = cmdv;
+                if (L.is0) {
+                    B.episode_length_buf[e] = ep_len; B.fail_buf[e] = (long long)failb;
+                    B.reset_buf[e] = reset ? 1 : 0; B.time_out_buf[e] = time_out ? 1 : 0; B.rew_buf[e] = total;
+                }
+            }
+        }
+        STAMP(11);
+    }
     // ---------------- MDP phases in the same launch (every other task): leg-per-lane body on the first 16 lanes -----
-    if (MPH != 0 && !QTAIL) {
+    if (MPH != 0 && !CTAIL) {
         // hand the results to the MDP phases through LDS (layout: lg_kernel.h, XA .. XFB): leg-lane l of the tail is quad l
         // of this wave; a quad lane writes its own component.  Nothing the tail reads then comes from the arrays stored
         // above, so those stores drain in the background instead of being waited for.
@@ -1962,7 +2552,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         // the wave's 64 lanes run the leg-per-lane body as FOUR replicas of its 16 leg-lanes (lane = 16 replica + leg-lane): every replica
         // computes the same values, replica 0 owns the state stores, and the observation section deals its stores over the replicas
         // (the four destinations of an actor-frame entry, the two of a critic entry; blanking with 64 lanes)
-        env_step_body<LEGS, MPH, true, PROF>(p, sMraw, sHot, sStF, sX, wg * 16 + ((int)threadIdx.x & 15), (int)threadIdx.x & 15);
+        env_step_body<LEGS, MPH, true, (PROF == 5 ? 0 : PROF)>(p, sMraw, sHot, sStF, sX, wg * 16 + ((int)threadIdx.x & 15), (int)threadIdx.x & 15);
     }
     STAMPB(12288);
 }
