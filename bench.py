@@ -376,23 +376,70 @@ def build_flags():
         return None
 
 
-def launcher_dry_run(args, world, rank):
-    """N > 1 plumbing of this file without a GPU: gloo process group, the same StepGather, barrier + max-over-ranks clock,
-    ONE JSON line on rank 0.  The env step is replaced by writing the rank id into a fake observation."""
+def select_gather(args, world, n_local, widths, dev, probe_with, flag_device):
+    """Time `probe_with(gather, steps)` (microseconds per step) under each candidate transport and build the one every rank agrees is
+    fastest (hcr_genesis_lr_cl_amd.distributed.pick_fastest: the mode whose slowest rank is fastest).  A transport that raises on some
+    rank (e.g. peer mappings unavailable) drops out on all.  -> (gather, info dict for the JSON line)."""
     import torch
     import torch.distributed as dist
-    from hcr_genesis_lr_cl_amd.distributed import StepGather
+    from hcr_genesis_lr_cl_amd.distributed import GATHER_MODES, make_gather, pick_fastest
+    n_probe = 6 * max(args.gather_batch, 1)
+    step_alone = probe_with(None, n_probe)
+    forced = "rccl-sync" if args.sync_gather else (None if args.gather_mode == "auto" else args.gather_mode)
+    cand, errors = {}, {}
+    for mode in ([forced] if forced else GATHER_MODES):
+        g = None
+        try:
+            g = make_gather(mode, n_local, widths, world, dev, batch=args.gather_batch)
+            g.prime()           # communicator / peer-mapping set-up is initialisation, not a step
+            probe_with(g, n_probe)
+            cand[mode] = probe_with(g, n_probe)
+        except Exception as e:      # noqa: BLE001
+            errors[mode] = repr(e)[:200]
+        if g is not None and hasattr(g, "close"):
+            g.close()
+    flags = torch.tensor([1.0 if m in cand else 0.0 for m in GATHER_MODES], device=flag_device)
+    dist.all_reduce(flags, op=dist.ReduceOp.MIN)
+    ok = [m for m, f in zip(GATHER_MODES, flags.tolist()) if f > 0.5]
+    if not ok:
+        raise SystemExit(f"bench.py: no gather transport works on every rank: {errors}")
+    mode, cand_max = pick_fastest({m: cand[m] for m in ok})
+    g = make_gather(mode, n_local, widths, world, dev, batch=args.gather_batch)
+    g.prime()
+    return g, {"mode": mode, "selected": "forced" if forced else "fastest of the candidates timed during the warm-up",
+               "candidates_us": cand_max, "candidate_errors": errors or None, "probe_steps": n_probe,
+               "step_us_alone": step_alone, "steps_per_exchange": int(g.batch)}
+
+
+def launcher_dry_run(args, world, rank):
+    """N > 1 plumbing of this file without a GPU: gloo process group, the same transport selection (select_gather: all three
+    transports -- the peer-write one over /dev/shm -- timed, the fastest built), barrier + max-over-ranks clock, ONE JSON line on
+    rank 0.  The env step is replaced by writing the rank id into a fake observation."""
+    import torch
+    import torch.distributed as dist
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group("gloo")
     n_local, widths = 32, [5, 3]
-    gather = StepGather(n_local, widths, world, "cpu", overlap=not args.sync_gather, batch=args.gather_batch) if world > 1 else None
-    if gather is not None:
-        gather.prime()
     obs = [torch.full((n_local, w), float(rank)) for w in widths]
     rew, done = torch.full((n_local,), 0.5 + rank), torch.zeros(n_local, dtype=torch.bool)
     done[rank] = True
+    gather, info, out = None, None, None
+
+    def probe_with(g, n_steps):
+        if world > 1:
+            dist.barrier()
+        t0 = time.perf_counter()
+        for _ in range(n_steps):
+            if g is not None:
+                g(obs, rew, done)
+        if g is not None:
+            g.finish()
+        if world > 1:
+            dist.barrier()
+        return (time.perf_counter() - t0) / n_steps * 1e6
     if world > 1:
+        gather, info = select_gather(args, world, n_local, widths, "cpu", probe_with, "cpu")
         dist.barrier()
     t0 = time.perf_counter()
     for i in range(args.steps):
@@ -413,8 +460,11 @@ def launcher_dry_run(args, world, rank):
             ok &= all(bool((p_ == k).all()) for p_ in parts) and bool((r == 0.5 + k).all()) and int(d.sum()) == 1 and bool(d[k])
     if rank == 0:
         print(json.dumps({"metric": "launcher dry run", "value": n_local * world * args.steps / max(elapsed, 1e-9), "unit": "records/s",
-                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "gather_ok": bool(ok), "data": "synthetic"}), file=_REAL_STDOUT, flush=True)
+                          "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "gather_ok": bool(ok), "gather": info, "data": "synthetic"}),
+              file=_REAL_STDOUT, flush=True)
     if world > 1:
+        if hasattr(gather, "close"):
+            gather.close()
         dist.destroy_process_group()
     return 0 if ok else 1
 
@@ -435,6 +485,10 @@ def main():
                          "latency-bound 6 MB ones, and a short exposed flush at the end of a 20-step run; 1 = one collective per step)")
     ap.add_argument("--sync-gather", action="store_true",
                     help="wait for each step's all-gather before the next step (default: it overlaps the next step, double-buffered)")
+    ap.add_argument("--gather-mode", default="auto", choices=["auto", "rccl", "rccl-sync", "copy-engine"],
+                    help="transport of the per-step record exchange at N>1: rccl = one all-gather per --gather-batch steps, overlapped; rccl-sync = "
+                         "one per step, awaited; copy-engine = peer writes by the SDMA engines (no collective kernel on the CUs); auto (default) "
+                         "times a few steps under each during the warm-up and runs the timed regions with the fastest (reported in `gather`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-timer-stride", type=int, default=8, help="time the physics kernel of every n-th step (0 = off)")
     ap.add_argument("--task", default="go2", choices=list(WORKLOADS),
@@ -494,22 +548,49 @@ def main():
     env.episode_length_buf[:] = torch.randint(0, int(env.max_episode_length), (n_local,), generator=g, device=dev, dtype=torch.int32)
     # fixed synthetic action stream: a small bank of N(0,1) batches cycled (clipped +-100 in-kernel)
     bank = [torch.randn(n_local, env.num_actions, generator=g, device=dev) for _ in range(16)]
-    from hcr_genesis_lr_cl_amd.distributed import StepGather
-
     def obs_outputs(out):      # every observation tensor step() returns: 5-tuple (obs, priv) or 6-tuple (features, labels, critic)
         return [o for o in out[:-3] if o is not None]
     widths = [int(o.shape[1]) for o in obs_outputs(env.step(bank[0]))]
-    gather = StepGather(n_local, widths, world, dev, overlap=not args.sync_gather, batch=args.gather_batch) if world > 1 and not args.no_gather else None
-    if gather is not None:
-        gather.prime()         # communicator set-up of the all-gather is initialisation, not a step (W may be smaller than the batch)
+    gather = None
+    gather_info = None
 
     def one_step(i):
         out = env.step(bank[i % len(bank)])
         if gather is not None:
             gather(obs_outputs(out), out[-3], out[-2])      # same tail in both arities: (rew, done, extras)
 
+    def probe(n_steps):         # microseconds per step of n_steps steps under the current `gather`, bracketed like a timed region
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for i in range(n_steps):
+            one_step(i)
+        if gather is not None:
+            gather.finish()
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        return (time.perf_counter() - t0) / n_steps * 1e6
+
+    if world > 1 and not args.no_gather:
+        # SURVEY 8e / DESIGN 5: which transport hides best behind the step is a property of the node (RCCL's collective kernel cannot
+        # share a SIMD with the step kernel; the copy engines leave the CUs alone but need peer mappings): measured here, not assumed
+        def probe_with(g, n_steps):
+            nonlocal gather
+            gather = g
+            for i in range(4):
+                one_step(i)
+            us = probe(n_steps)
+            gather = None
+            return us
+        gather, gather_info = select_gather(args, world, n_local, widths, dev, probe_with, dev if args.backend == "nccl" else "cpu")
+
     for i in range(args.warmup):
         one_step(i)
+    if gather is not None:
+        gather.finish()
+        gather.wait_s = gather.finish_s = 0.0
     # roofline: the dominant kernel (physics) of every 8th step is bracketed by HIP events on the launch stream
     env._engine.profile(args.kernel_timer_stride)
     # R timed regions of `--steps` steps each after the one warm-up, median reported.  A region is bracketed by a
@@ -539,6 +620,13 @@ def main():
             el = float(t.item())
         region_s.append(el)
         region_dev_ms.append(ev0.elapsed_time(ev1))
+    if gather_info is not None:
+        n_timed = args.steps * max(args.repeats, 1)
+        gather_info.update({"step_us_with_gather": sorted(region_s)[len(region_s) // 2] / args.steps * 1e6,
+                            "wait_us_per_step": gather.wait_s / n_timed * 1e6, "exposed_us_per_step": gather.finish_s / n_timed * 1e6,
+                            "exposed_us_per_region": gather.finish_s / max(args.repeats, 1) * 1e6,
+                            "note": "rank 0's own waits; wait = host time blocked on an exchange inside the steps, exposed = time from the last step's "
+                                    "completion to the arrival of every record (gather.finish()), both inside the timed regions"})
     order = sorted(range(len(region_s)), key=lambda k: region_s[k])
     mid = order[len(order) // 2]                     # the median region (upper median for an even count)
     elapsed, dev_ms = region_s[mid], region_dev_ms[mid]
@@ -575,7 +663,7 @@ def main():
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{WORKLOADS[args.task]}, {n_local} envs per GPU, fused LeggedRobot.step "
                                    f"(4 sub-steps dt=0.005) with synthetic N(0,1) actions",
-                       "envs_total": total_envs, "parallelism": f"env-shard x{world}" + (" [gloo rehearsal, ranks may share a GPU]" if world > 1 and args.backend == "gloo" else "") + ((f" + all-gather(obs,rew,done) of every step, {args.gather_batch} steps per collective" + ("" if args.sync_gather else ", overlapped with the following steps")) if world > 1 and not args.no_gather else "")},
+                       "envs_total": total_envs, "parallelism": f"env-shard x{world}" + (" [gloo rehearsal, ranks may share a GPU]" if world > 1 and args.backend == "gloo" else "") + ((f" + exchange of (obs, rew, done) of every step by {gather_info['mode']}, {gather_info['steps_per_exchange']} step(s) per exchange" + ("" if gather_info["mode"] == "rccl-sync" else ", overlapped with the following steps")) if gather_info else "")},
             "repeats": len(region_s), "repeats_ms_per_step": [x / args.steps * 1e3 for x in region_s],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
                          "frac": achieved / HBM_PEAK_GBS, "traffic": traffic, "traffic_counters": traffic_stamp,
@@ -587,6 +675,8 @@ def main():
                          "valu": valu_roofline(wkey, launch_s, n_local)},
             "build_flags": build_flags(), "source_hash": _built_source_hash(),
         }
+        if gather_info is not None:
+            out["gather"] = gather_info
         if world == 1 and args.ppo_rollout > 0:
             del env
             try:

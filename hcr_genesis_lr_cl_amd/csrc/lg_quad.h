@@ -2183,6 +2183,21 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         failb += fail;
         const bool time_out = (float)ep_len > h_max_episode_length;
         const bool reset = ((float)failb > h_fail_threshold) || time_out;
+        // terrain curriculum of a resetting env (legged_robot.py:254-272): the level it moves to is known here, except when it has solved
+        // the last one (a random level, drawn below).  The origin of that level is loaded NOW, so that the round trip passes under the
+        // reward terms instead of sitting in the reset block of the wave that ends the launch.
+        const bool curr = h_terrain_curriculum && p.counter > 0;
+        int lvl_pre = w_lvl;
+        float norg_pre = origin;
+        if (curr && anyl(reset)) {
+            const float dd = pos - origin;
+            const float dx = bc<0>(dd), dy = bc<1>(dd);
+            const float dist = sqrtf(dx * dx + dy * dy);
+            const bool up = dist > h_terrain_env_length / 2.f;
+            const bool down = (dist < sqrtf(cmd0 * cmd0 + cmd1 * cmd1) * h_episode_length_s * 0.5f) && !up;
+            lvl_pre = w_lvl + (up ? 1 : 0) - (down ? 1 : 0);
+            norg_pre = B.terrain_origins[((size_t)min(max(lvl_pre, 0), h_max_terrain_level - 1) * h_terrain_cols_n + w_type) * 3 + cj];
+        }
 
         // ---- compute_reward (legged_robot.py:150-168): every term replicated over the env's lanes, summed in alphabetical order ----
         float scl[LG_R_COUNT];
@@ -2322,18 +2337,14 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             // terrain curriculum (legged_robot.py:254-272 + genesis_simulator.py:140-148; skipped on the construction-time reset)
             float norg = origin;
             int nlvl = w_lvl;
-            const bool curr = h_terrain_curriculum && p.counter > 0;
             if (curr) {
-                const float dd = pos - origin;
-                const float dx = bc<0>(dd), dy = bc<1>(dd);
-                const float dist = sqrtf(dx * dx + dy * dy);
-                const bool up = dist > h_terrain_env_length / 2.f;
-                const bool down = (dist < sqrtf(cmd0 * cmd0 + cmd1 * cmd1) * h_episode_length_s * 0.5f) && !up;
-                int lvl = w_lvl + (up ? 1 : 0) - (down ? 1 : 0);
-                if (lvl >= h_max_terrain_level) lvl = min((int)floorf(u_tl * (float)h_max_terrain_level), h_max_terrain_level - 1);
-                else lvl = max(lvl, 0);
+                int lvl = lvl_pre;
+                norg = norg_pre;
+                if (lvl >= h_max_terrain_level) {      // solved the last level: a random one (rare), its origin loaded here
+                    lvl = min((int)floorf(u_tl * (float)h_max_terrain_level), h_max_terrain_level - 1);
+                    norg = B.terrain_origins[((size_t)lvl * h_terrain_cols_n + w_type) * 3 + cj];
+                } else lvl = max(lvl, 0);
                 nlvl = lvl;
-                norg = B.terrain_origins[((size_t)lvl * h_terrain_cols_n + w_type) * 3 + cj];
             }
             const float ncmd = resample(cmdv, bc<0>(v0), bc<1>(v0), bc<2>(v0));
             float ipos = (sit ? b_sitp : L.sel(h_o_base_init_pos_0, h_o_base_init_pos_1, h_o_base_init_pos_2)) + norg;

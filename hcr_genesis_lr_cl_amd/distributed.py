@@ -47,6 +47,8 @@ class StepGather:
     The inputs may be strided views (sliding history windows) and `done` a bool tensor: the packing is one `torch.cat`
     into the float record."""
 
+    MODE = "rccl"
+
     def __init__(self, n_local, widths, world, device, dtype=torch.float32, overlap=False, batch=1):
         """`batch` = control steps per collective: the records of `batch` consecutive steps travel in ONE all-gather (issued after
         the last of them).  A per-step gather of the go2 record is 0.77 MB per rank -- at 8 ranks 5.4 MB in per rank every 28 us,
@@ -62,6 +64,8 @@ class StepGather:
         self.recs = [torch.empty(self.batch * n_local, W, device=device, dtype=dtype) for _ in range(nb)]
         self.outs = [torch.empty(world * self.batch * n_local, W, device=device, dtype=dtype) if world > 1 else r for r in self.recs]
         self.work = [None] * nb
+        self.wait_s = 0.0          # host time spent waiting for a collective inside __call__ (attribution: bench.py `gather.wait_us_per_step`)
+        self.finish_s = 0.0        # ... and inside finish(): what of the exchange was NOT hidden behind the steps
         self.t = 0
         self.last_fill = self.batch
         self.rec, self.out = self.recs[0], self.outs[0]
@@ -76,7 +80,12 @@ class StepGather:
             if self.overlap:
                 self.work[i] = dist.all_gather_into_tensor(out, rec, async_op=True)
             else:
+                import time
+                t0 = time.perf_counter()
                 dist.all_gather_into_tensor(out, rec)
+                if rec.is_cuda:
+                    torch.cuda.current_stream(rec.device).synchronize()      # "sync": the step that follows starts after the records arrived
+                self.wait_s += time.perf_counter() - t0
 
     def __call__(self, obs, rew, done):
         """Pack this step's outputs; every `batch`-th call issues the collective.  Returns the buffer the records of the current
@@ -85,7 +94,10 @@ class StepGather:
         slot = self.t % self.batch
         self.t += 1
         if slot == 0 and self.work[i] is not None:   # the collective that last used this buffer pair must have finished
+            import time
+            t0 = time.perf_counter()
             self.work[i].wait()
+            self.wait_s += time.perf_counter() - t0
             self.work[i] = None
         self.out = self.outs[i]
         r = self.rec = self.recs[i][slot * self.n_local:(slot + 1) * self.n_local]
@@ -112,6 +124,10 @@ class StepGather:
     def finish(self):
         """Send a partly filled batch (only the steps it holds: `last_fill` of them, laid out as a batch of that size -- pass it to
         `step_view`), then wait for every outstanding gather (end of rollout / end of the timed region)."""
+        import time
+        if self.recs[0].is_cuda:
+            torch.cuda.current_stream(self.recs[0].device).synchronize()    # the steps themselves: not part of the exchange's exposed time
+        t0 = time.perf_counter()
         self.last_fill = self.batch
         if self.t % self.batch != 0:
             self.last_fill = self.t % self.batch
@@ -121,6 +137,9 @@ class StepGather:
             if w is not None:
                 w.wait()
                 self.work[i] = None
+        if self.recs[0].is_cuda:
+            torch.cuda.current_stream(self.recs[0].device).synchronize()
+        self.finish_s += time.perf_counter() - t0
 
     def step_view(self, out, rank, slot, fill=None):
         """The (n_local, W) record of `rank` at step `slot` of a gathered batch (`fill`: steps in it, for the partly filled batch
@@ -138,3 +157,175 @@ class StepGather:
             parts.append(o[:, c:c + w])
             c += w
         return parts, o[:, self.num_obs], o[:, self.num_obs + 1] > 0.5
+
+
+class PeerGather(StepGather):
+    """The same record exchange WITHOUT a collective kernel: every rank owns a receive buffer of (world, batch * n_local, W) floats, the
+    other ranks map it once (GPU: IPC memory handles exchanged through the process group; CPU tests: a file in /dev/shm) and from then on
+    WRITE their batch straight into their slot of every peer's buffer -- device-to-device copies enqueued on a side stream, which the
+    runtime hands to the SDMA copy engines, so no compute unit is taken from the step kernel.  (RCCL's all-gather runs in a kernel of
+    its own -- `rcclGenericKernel`, 256-thread workgroups at 261-280 registers per wave on gfx950 -- which cannot share a SIMD with the
+    256-register step kernel: DESIGN.md section 5.)  north_star's RCCL all-gather stays the control plane here: the process group carries
+    the handles and the final barrier.
+
+    Contract = StepGather(overlap=True): `__call__` packs the step's record; every `batch`-th call enqueues the peer writes and returns
+    at once; the gathered records are complete after `finish()` (every rank drains its copy stream, then all ranks meet at a barrier).
+    Buffers are reused every other batch, as there."""
+
+    MODE = "copy-engine"
+
+    def __init__(self, n_local, widths, world, device, dtype=torch.float32, batch=1, rank=None):
+        super().__init__(n_local, widths, world, device, dtype=dtype, overlap=True, batch=batch)
+        import torch.distributed as dist
+        self.rank = int(rank if rank is not None else (dist.get_rank() if world > 1 else 0))
+        self.device = torch.device(device)
+        self._shm = []
+        self.peers = [None, None]          # [buffer pair][rank] -> that rank's receive buffer (ours: self.outs[i])
+        self.copy_stream = torch.cuda.Stream(device=self.device) if self.device.type == "cuda" else None
+        self.sent = [None, None]           # event after the last copy out of recs[i]
+        if world > 1:
+            self._open_peers()
+
+    # ---- peer mapping -------------------------------------------------------------------------------------------------
+    def _open_peers(self):
+        import torch.distributed as dist
+        W = self.num_obs + 2
+        shape = (self.world * self.batch * self.n_local, W)
+        if self.device.type == "cuda":
+            from torch.multiprocessing.reductions import reduce_tensor
+            mine = [reduce_tensor(o) for o in self.outs]                 # (rebuild function, arguments with the IPC memory handle)
+        else:
+            import os
+            import uuid
+            import numpy as np
+            mine = []
+            for i in range(2):
+                path = f"/dev/shm/lg_gather_{uuid.uuid4().hex}_{self.rank}_{i}"
+                mm = np.memmap(path, dtype=np.float32, mode="w+", shape=shape)
+                self._shm.append(path)
+                self.outs[i] = torch.from_numpy(mm)                      # our receive buffer lives in the shared file
+                mine.append(path)
+            self.out = self.outs[0]
+        everyone = [None] * self.world
+        dist.all_gather_object(everyone, mine)
+        for i in range(2):
+            row = []
+            for r in range(self.world):
+                if r == self.rank:
+                    row.append(self.outs[i])
+                elif self.device.type == "cuda":
+                    fn, args = everyone[r][i]
+                    row.append(fn(*args))                                # opens the peer's allocation in this process
+                else:
+                    import numpy as np
+                    row.append(torch.from_numpy(np.memmap(everyone[r][i], dtype=np.float32, mode="r+", shape=shape)))
+            self.peers[i] = row
+        dist.barrier()
+
+    # ---- the exchange ---------------------------------------------------------------------------------------------------
+    def _issue(self, i, fill=None):
+        if self.world <= 1:
+            return
+        b = self.batch if fill is None or fill >= self.batch else int(fill)
+        rows = b * self.n_local
+        src = self.recs[i][:rows]
+        lo = self.rank * rows                                             # layout of a gathered batch of b steps: (world, b, n_local, W)
+        if self.copy_stream is not None:
+            self.copy_stream.wait_stream(torch.cuda.current_stream(self.device))      # the records were packed on the compute stream
+            with torch.cuda.stream(self.copy_stream):
+                for r in range(self.world):
+                    self.peers[i][r][lo:lo + rows].copy_(src, non_blocking=True)
+                ev = torch.cuda.Event()
+                ev.record(self.copy_stream)
+            self.sent[i] = ev
+        else:
+            for r in range(self.world):
+                self.peers[i][r][lo:lo + rows].copy_(src)
+
+    def __call__(self, obs, rew, done):
+        i = (self.t // self.batch) % 2
+        if self.t % self.batch == 0 and self.sent[i] is not None:
+            # the copies out of this record buffer (two batches ago) must have been issued to the engines before it is overwritten:
+            # the compute stream waits for them on the device, the host does not block
+            torch.cuda.current_stream(self.device).wait_event(self.sent[i])
+            self.sent[i] = None
+        return super().__call__(obs, rew, done)
+
+    def prime(self):
+        if self.world > 1:
+            import torch.distributed as dist
+            for i in range(2):
+                self.recs[i].zero_()
+                self._issue(i)
+            if self.copy_stream is not None:
+                self.copy_stream.synchronize()
+            self.sent = [None, None]
+            dist.barrier()
+
+    def finish(self):
+        import time
+        import torch.distributed as dist
+        if self.device.type == "cuda":
+            torch.cuda.current_stream(self.device).synchronize()        # the steps themselves: not part of the exchange's exposed time
+        t0 = time.perf_counter()
+        self.last_fill = self.batch
+        if self.t % self.batch != 0:
+            self.last_fill = self.t % self.batch
+            self._issue((self.t // self.batch) % 2, self.last_fill)
+            self.t += self.batch - self.t % self.batch
+        if self.copy_stream is not None:
+            self.copy_stream.synchronize()
+        if self.world > 1:
+            dist.barrier()                                               # every rank's writes into every buffer have landed
+        self.finish_s += time.perf_counter() - t0
+
+    def close(self):
+        import os
+        self.peers = [None, None]
+        for pth in self._shm:
+            try:
+                os.remove(pth)
+            except OSError:
+                pass
+        self._shm = []
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+GATHER_MODES = ("rccl", "rccl-sync", "copy-engine")
+
+
+def make_gather(mode, n_local, widths, world, device, batch=4):
+    """The record exchange of bench.py / a learner at N > 1 in one of the three transports:
+      "rccl"         one RCCL all-gather per `batch` steps, overlapped with the following steps (double-buffered)
+      "rccl-sync"    one RCCL all-gather per step, awaited before the next step (north_star's literal reading)
+      "copy-engine"  peer writes by the copy engines, `batch` steps per write (PeerGather)"""
+    if mode == "rccl":
+        g = StepGather(n_local, widths, world, device, overlap=True, batch=batch)
+    elif mode == "rccl-sync":
+        g = StepGather(n_local, widths, world, device, overlap=False, batch=1)
+    elif mode == "copy-engine":
+        g = PeerGather(n_local, widths, world, device, batch=batch)
+    else:
+        raise ValueError(f"gather mode {mode!r}: one of {GATHER_MODES}")
+    g.mode = mode
+    return g
+
+
+def pick_fastest(times_us):
+    """{mode: microseconds per step measured on this rank} -> the mode every rank agrees on: the one whose SLOWEST rank is fastest
+    (all-reduce MAX over ranks, then argmin; ties go to the earlier entry of GATHER_MODES).  Returns (mode, {mode: max over ranks})."""
+    import torch.distributed as dist
+    modes = [m for m in GATHER_MODES if m in times_us]
+    t = torch.tensor([float(times_us[m]) for m in modes], dtype=torch.float64)
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+        if dist.get_backend() == "nccl":
+            t = t.cuda()
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        t = t.cpu()
+    best = int(torch.argmin(t))
+    return modes[best], {m: float(v) for m, v in zip(modes, t)}

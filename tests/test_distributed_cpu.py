@@ -7,7 +7,7 @@ import numpy as np
 import torch
 import torch.multiprocessing as mp
 
-from hcr_genesis_lr_cl_amd.distributed import StepGather, global_mean, shard
+from hcr_genesis_lr_cl_amd.distributed import GATHER_MODES, PeerGather, StepGather, global_mean, make_gather, pick_fastest, shard
 
 
 def _free_port():
@@ -49,6 +49,29 @@ def _worker(rank, world, port, q):
             assert torch.allclose(rec[:, 5], ids_k * (2 + k)) and torch.allclose(rec[:, 0], ids_k + k), (k, rk)
     (p3,), r3, d3 = g3.split(g3.step_view(outs3[5], 1, 2))
     assert p3.shape == (n, 5) and d3.dtype == torch.bool
+    # the three transports behind one interface (make_gather): the same 7 steps, the same records after finish() -- "copy-engine" = peer
+    # writes into mapped buffers (here: files in /dev/shm), no collective on the data path
+    for mode in GATHER_MODES:
+        gm_ = make_gather(mode, n, 5, world, "cpu", batch=3)
+        assert (mode == "copy-engine") == isinstance(gm_, PeerGather) and gm_.mode == mode
+        gm_.prime()
+        assert gm_.t == 0
+        outs_m = [gm_(obs + k, ids * (2 + k), (ids % 3 == 0).float()) for k in range(7)]
+        gm_.finish()
+        b = gm_.batch
+        for k in ((6,) if mode == "rccl-sync" else (3, 5, 6)):     # awaited mode: one buffer, a record is read before the next step overwrites it
+            slot, fill = k % b, (gm_.last_fill if k // b == 6 // b else None)
+            for rk in range(world):
+                o_k, n_k = shard(64, world, rk)
+                rec = gm_.step_view(outs_m[k], rk, slot, fill)
+                ids_k = torch.arange(o_k, o_k + n_k, dtype=torch.float32)
+                assert torch.allclose(rec[:, 5], ids_k * (2 + k)) and torch.allclose(rec[:, 0], ids_k + k), (mode, k, rk)
+        assert gm_.wait_s >= 0.0 and gm_.finish_s > 0.0
+        if hasattr(gm_, "close"):
+            gm_.close()
+    # the ranks agree on the transport: each rank's slowest-rank times decide (rank 1 alone would have picked rccl-sync)
+    mode, agreed = pick_fastest({"rccl": 30.0 + 10 * rank, "rccl-sync": 50.0 - 20 * rank, "copy-engine": 35.0})
+    assert mode == "copy-engine" and agreed == {"rccl": 40.0, "rccl-sync": 50.0, "copy-engine": 35.0}, (mode, agreed)
     q.put((rank, o.numpy().copy(), r.numpy().copy(), d.numpy().copy()))
     dist.barrier()
     dist.destroy_process_group()
@@ -110,6 +133,16 @@ def test_bench_launcher_spawns_the_ranks_it_was_asked_for():
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["steps"] == 5 and out["gather_ok"] is True
+    # the transport was chosen by measurement: all three candidates were timed, the line says which one ran
+    g = out["gather"]
+    assert set(g["candidates_us"]) == set(GATHER_MODES) and g["mode"] == min(g["candidates_us"], key=g["candidates_us"].get)
+    assert g["step_us_alone"] > 0 and g["steps_per_exchange"] in (1, 4) and g["selected"].startswith("fastest")
+    for forced in ("copy-engine", "rccl-sync"):
+        rf = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--steps", "5", "--warmup", "1", "--launcher-dry-run",
+                             "--gather-mode", forced], capture_output=True, text=True, timeout=300, env=env)
+        assert rf.returncode == 0, rf.stderr[-2000:]
+        of = json.loads([l for l in rf.stdout.splitlines() if l.startswith("{")][0])
+        assert of["gather_ok"] is True and of["gather"]["mode"] == forced and of["gather"]["selected"] == "forced"
     # a launcher that started a different number of ranks than --gpus says is refused, not silently accepted
     env2 = dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
     r2 = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--launcher-dry-run"], capture_output=True, text=True,

@@ -389,6 +389,55 @@ def test_step_gather_packs_strided_windows_and_bool_done_on_device():
     check(buf, kept, sg.last_fill)
 
 
+def _peer_worker(rank, world, port, q):
+    import os
+    import torch
+    import torch.distributed as dist
+    from hcr_genesis_lr_cl_amd.distributed import GATHER_MODES, make_gather, shard
+    os.environ["MASTER_ADDR"], os.environ["MASTER_PORT"] = "127.0.0.1", str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.cuda.set_device(0)
+    off, n = shard(256, world, rank)
+    ids = torch.arange(off, off + n, dtype=torch.float32, device="cuda")
+    wide = torch.zeros(n, 40, device="cuda")
+    wide[:, 7:12] = ids[:, None] + torch.arange(5, device="cuda") * 0.1
+    obs = wide[:, 7:12]                                   # a strided window, as the history tasks return
+    ok = True
+    for mode in GATHER_MODES:
+        g = make_gather(mode, n, 5, world, "cuda:0", batch=3)
+        g.prime()
+        outs = [g(obs + k, ids * (2 + k), (ids % 3 == 0)) for k in range(7)]
+        g.finish()
+        for k in ((6,) if mode == "rccl-sync" else (3, 5, 6)):
+            slot, fill = k % g.batch, (g.last_fill if k // g.batch == 6 // g.batch else None)
+            for rk in range(world):
+                o_k, n_k = shard(256, world, rk)
+                (o,), r, d = g.split(g.step_view(outs[k], rk, slot, fill))
+                ids_k = torch.arange(o_k, o_k + n_k, dtype=torch.float32, device="cuda")
+                ok &= bool(torch.allclose(r, ids_k * (2 + k))) and bool(torch.allclose(o[:, 0], ids_k + k)) and bool(torch.equal(d, ids_k % 3 == 0))
+        if hasattr(g, "close"):
+            g.close()
+        dist.barrier()
+    q.put((rank, ok))
+    dist.destroy_process_group()
+
+
+def test_three_gather_transports_between_two_processes_on_one_gpu():
+    """The N > 1 record exchange with the records on the DEVICE, two processes sharing cuda:0 (gloo process group as the control plane):
+    all three transports of distributed.make_gather deliver the same records -- in particular "copy-engine", where each process maps the
+    other's receive buffer through an IPC memory handle and writes its batches straight into it on a side stream (no collective)."""
+    import socket
+    import torch.multiprocessing as mp
+    s_ = socket.socket(); s_.bind(("127.0.0.1", 0)); port = s_.getsockname()[1]; s_.close()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    ps = [ctx.Process(target=_peer_worker, args=(r, 2, port, q)) for r in range(2)]
+    [p_.start() for p_ in ps]
+    res = [q.get(timeout=300) for _ in range(2)]
+    [p_.join(timeout=60) for p_ in ps]
+    assert sorted(res) == [(0, True), (1, True)], res
+
+
 def _obs_tensors(out):
     """(actor obs, critic obs / labels ...) of a step()/reset() result: every tensor-valued observation output."""
     import torch
