@@ -258,6 +258,8 @@ def load_lib():
                                    C.c_void_p, C.c_void_p]
     lib.lg_rollout_record.restype = lib.lg_rollout_gae.restype = C.c_int
     lib.lg_last_error.restype = C.c_char_p
+    lib.lg_last_kernel.argtypes = [H]
+    lib.lg_last_kernel.restype = C.c_char_p
     lib.lg_abi_version.restype = C.c_int
     for f in ("lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step", "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_obs_set_select", "lg_obs_window_select", "lg_profile",
               "lg_profile_read"):
@@ -267,7 +269,7 @@ def load_lib():
 
 
 EXPORTS = ["lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step",
-           "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_obs_set_select", "lg_obs_window_select", "lg_profile", "lg_profile_read", "lg_philox", "lg_stream_copy", "lg_last_error",
+           "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_obs_set_select", "lg_obs_window_select", "lg_profile", "lg_profile_read", "lg_philox", "lg_stream_copy", "lg_last_kernel", "lg_last_error",
            "lg_abi_version"]
 ROLLOUT_EXPORTS = ["lg_rollout_record", "lg_rollout_gae"]          # include/lgrollout.h
 ROLLOUT_MAX_COPIES = 8

@@ -1,8 +1,8 @@
 """Builds csrc/liblgsim.so with hipcc for gfx950 (in-tree, so it travels to the GPU box).
 
-The library is 19 translation units: lg_host.hip (C ABI), lg_rollout.hip and lg_inst.hip compiled once per kernel-instantiation group
-(-DLG_GROUP=0..16).  They are compiled in parallel into csrc/obj/ and linked; an object is reused while the sources it depends on and
-the flags are unchanged (content hash), so an edit of lg_quad.h rebuilds the nine component-per-lane groups only."""
+The library is 20 translation units: lg_host.hip (C ABI), lg_rollout.hip and lg_inst.hip compiled once per kernel-instantiation group
+(-DLG_GROUP=0..17).  They are compiled in parallel into csrc/obj/ and linked; an object is reused while the sources it depends on and
+the flags are unchanged (content hash), so an edit of lg_quad.h rebuilds the ten component-per-lane groups only."""
 import hashlib
 import json
 import os
@@ -16,8 +16,8 @@ INC = os.path.join(HERE, "..", "include")
 # LG_BUILD_OUT: a developer variant (other flags, e.g. -DLG_DBG_STAMPS) next to the product library; load it with LG_LIB=<path>
 OUT = os.environ.get("LG_BUILD_OUT") or os.path.join(CSRC, "liblgsim.so")
 OBJ = os.path.join(CSRC, "obj" if "LG_BUILD_OUT" not in os.environ else "obj_" + os.path.splitext(os.path.basename(OUT))[0])
-N_GROUPS = 17
-QUAD_GROUPS = range(0, 9)          # lg_inst.hip: groups that include lg_quad.h
+N_GROUPS = 18
+QUAD_GROUPS = list(range(0, 9)) + [17]          # lg_inst.hip: groups that include lg_quad.h
 COMMON = ["lg_shared.h", "lg_math.h", os.path.join(INC, "lgsim.h")]
 # -fno-slp-vectorize: packing scalars into v_pk_* costs more v_mov / AGPR shuffles than it saves here.
 # iterative-ilp scheduling: the kernels run one wave per SIMD, so occupancy is irrelevant and the scheduler should fill DPP /

@@ -30,6 +30,7 @@ struct LgEngine {
     LgHot hot;           // host copy of the hot block (upload_hot)
     int obs_win = 0;     // window of the latest stacked observation (obs_slack > 0)
     int obs_set = 0;     // copy of the observation buffers the latest observation launch wrote (obs_sets == 2)
+    std::string last_kernel;   // launcher instantiation(s) of the latest lg_step (lg_last_kernel)
     // bounded run-ahead: the host never gets more than ~128 lg_step calls ahead of the device (see lg_step)
     hipEvent_t ra_ev[4] = {nullptr, nullptr, nullptr, nullptr}; long long ra_calls = 0;
     // sampling timer of the physics kernel (lg_profile)
@@ -166,12 +167,12 @@ static int prof_begin(LgEngine *h, hipStream_t st) {
 // launch with the kernel's own begin / end timestamps when this step is sampled (hipExtLaunchKernelGGL attaches the
 // events to the dispatch packet itself, so the reading is the kernel's duration, comparable with rocprofv3's).
 // `kern`: a launcher instantiation of lg_shared.h, e.g. (lg_launch_quad<4, true, 12u, 1, 3>)
-#define LG_LAUNCH(pi, kern, grid_) kern(grid_, st, (pi) >= 0 ? h->prof_ev[2 * (pi)] : nullptr, (pi) >= 0 ? h->prof_ev[2 * (pi) + 1] : nullptr, p)
+#define LG_LAUNCH(pi, kern, grid_) (h->last_kernel = #kern, kern(grid_, st, (pi) >= 0 ? h->prof_ev[2 * (pi)] : nullptr, (pi) >= 0 ? h->prof_ev[2 * (pi) + 1] : nullptr, p))
 // a control step made of two launches (physics, then the MDP phases): begin timestamp of the first, end timestamp of
 // the second, so that the sample is the whole step including the gap between the two
-#define LG_LAUNCH_FIRST(pi, kern, grid_) kern(grid_, st, (pi) >= 0 ? h->prof_ev[2 * (pi)] : nullptr, nullptr, p)
-#define LG_LAUNCH_LAST(pi, kern, grid_) kern(grid_, st, nullptr, (pi) >= 0 ? h->prof_ev[2 * (pi) + 1] : nullptr, p)
-#define LG_LAUNCH_PLAIN(kern, grid_) kern(grid_, st, nullptr, nullptr, p)
+#define LG_LAUNCH_FIRST(pi, kern, grid_) (h->last_kernel = #kern, kern(grid_, st, (pi) >= 0 ? h->prof_ev[2 * (pi)] : nullptr, nullptr, p))
+#define LG_LAUNCH_LAST(pi, kern, grid_) (h->last_kernel += " + " #kern, kern(grid_, st, nullptr, (pi) >= 0 ? h->prof_ev[2 * (pi) + 1] : nullptr, p))
+#define LG_LAUNCH_PLAIN(kern, grid_) (h->last_kernel = #kern, kern(grid_, st, nullptr, nullptr, p))
 
 static bool flat_noise_ok(const LgEngine *h) {   // commands and actions carry no observation noise (go2.py:92-117)
     const int A = h->model.n_bodies - 1;
@@ -180,7 +181,7 @@ static bool flat_noise_ok(const LgEngine *h) {   // commands and actions carry n
     return true;
 }
 // the plain go2-on-a-plane task: every switch the FLAT instantiations hard-wire (env_step_body) really has that value
-static bool flat_profile(const LgEngine *h) {
+static bool flat_profile(const LgEngine *h, bool inj = false) {   // inj: the injected-uniform test instantiation (rand_in REQUIRED instead of forbidden)
     const LgTaskCfg &t = h->task;
     const LgSimOptions &o = h->opts;
     const LgBuffers &b = h->bufs;
@@ -189,7 +190,7 @@ static bool flat_profile(const LgEngine *h) {
            t.behavior_resample_steps == 0 && t.num_labels == 0 && t.cat_enable == 0 && t.noise_vec[9 + 6 * h->model.n_legs] == 0.f && t.air_time_cmd_dims != 3 &&
            h->model.n_bodies == 1 + 3 * h->model.n_legs &&
            o.n_height_points == 0 && o.terrain_rows == 0 && o.feet_terrain_info == 0 && !b.link_contact_states && !b.task_state && !h->hf &&
-           !b.rand_in && !b.joint_armature && !t.dr_joint_on && !t.dr_pd_on && t.reset_lin_vel_span == 0.f && t.reset_ang_vel_span == 0.f && flat_noise_ok(h) &&
+           (inj ? b.rand_in != nullptr : !b.rand_in) && !b.joint_armature && !t.dr_joint_on && !t.dr_pd_on && t.reset_lin_vel_span == 0.f && t.reset_ang_vel_span == 0.f && flat_noise_ok(h) &&
            // reward terms the component-layout tail (lg_quad.h) does not carry: gait clocks, biped and wtw-only terms
            ((unsigned)h->hot.reward_mask & ((1u << LG_R_BIPED_PERIODIC_GAIT) | (1u << LG_R_QUAD_PERIODIC_GAIT) | (1u << LG_R_FEET_DISTANCE) |
                                             (1u << LG_R_TRACKING_BASE_HEIGHT) | (1u << LG_R_TRACKING_FOOT_CLEARANCE) |
@@ -197,7 +198,7 @@ static bool flat_profile(const LgEngine *h) {
 }
 
 // go2_wtw on the plane (PROF 2)
-static bool wtw_profile(const LgEngine *h) {
+static bool wtw_profile(const LgEngine *h, bool inj = false) {
     const LgTaskCfg &t = h->task;
     const LgSimOptions &o = h->opts;
     const LgBuffers &b = h->bufs;
@@ -207,14 +208,14 @@ static bool wtw_profile(const LgEngine *h) {
            // what the component-layout tail of lg_quad.h (PROF 2) hard-wires: sliding-window stacks of 61 | 99-wide frames, Philox draws,
            // no per-env joint parameters, no noise on commands / actions
            t.obs_slack > 0 && t.obs_frame == 61 && t.priv_frame == 61 + 10 + 6 * h->model.n_legs + h->model.n_legs && t.obs_stack > 1 && t.priv_stack > 1 &&
-           t.obs_sets <= 2 && (t.obs_sets < 2 || b.obs_dirty) && !b.rand_in && !b.joint_armature && !t.dr_joint_on && flat_noise_ok(h) &&
+           t.obs_sets <= 2 && (t.obs_sets < 2 || b.obs_dirty) && (inj ? b.rand_in != nullptr : !b.rand_in) && !b.joint_armature && !t.dr_joint_on && flat_noise_ok(h) &&
            h->model.n_legs == 4 && h->model.n_bodies == 13 && b.priv_obs_buf && b.rand_push_vels &&
            ((unsigned)h->hot.reward_mask & ((1u << LG_R_BIPED_PERIODIC_GAIT) | (1u << LG_R_FEET_DISTANCE))) == 0;
 }
 
 // the Go2-rough family (PROF 3: go2_ee packaging, PROF 4: observation programs -- go2_ts / go2_cts / go2_dreamwaq / go2_cat): no gait
 // clock, no sit pose, no noise on actions; terrain, curriculum, stacks and (PROF 4) CaT stay runtime
-static int rough_profile(const LgEngine *h) {
+static int rough_profile(const LgEngine *h, bool inj = false) {
     const LgTaskCfg &t = h->task;
     if (t.gait_mode != 0 || t.sit_percent != 0.f || t.behavior_resample_steps != 0 || t.noise_vec[9 + 6 * h->model.n_legs] != 0.f || h->bufs.task_state)
         return 0;
@@ -223,7 +224,7 @@ static int rough_profile(const LgEngine *h) {
     const LgBuffers &b = h->bufs;
     const int K = __builtin_popcount(h->model.state_link_mask), P = h->opts.n_height_points, A = h->model.n_bodies - 1;
     const bool common = t.double_shift == 0 && t.cat_enable == 0 && t.obs_slack > 0 && t.obs_frame == 9 + 3 * A && t.obs_stack > 1 && t.priv_stack > 1 &&
-                        t.obs_sets <= 2 && (t.obs_sets < 2 || b.obs_dirty) && !b.rand_in && !b.joint_armature && !t.dr_joint_on && flat_noise_ok(h) &&
+                        t.obs_sets <= 2 && (t.obs_sets < 2 || b.obs_dirty) && (inj ? b.rand_in != nullptr : !b.rand_in) && !b.joint_armature && !t.dr_joint_on && flat_noise_ok(h) &&
                         h->model.n_legs == 4 && h->model.n_bodies == 13 && P > 0 && P <= 7 * 16 && h->opts.feet_terrain_info && b.priv_obs_buf &&
                         b.rand_push_vels && t.air_time_cmd_dims != 3 && t.num_priv_obs > 0 &&
                         (!t.terrain_curriculum || (b.terrain_levels && b.terrain_types && b.terrain_origins && b.env_origins)) &&
@@ -244,13 +245,13 @@ static int rough_profile(const LgEngine *h) {
 }
 
 // tron1_pf_ee (PROF 6 = the component-layout tail of lg_quad.h for the three-joint biped): what it hard-wires
-static bool biped_profile(const LgEngine *h) {
+static bool biped_profile(const LgEngine *h, bool inj = false) {
     const LgTaskCfg &t = h->task;
     const LgBuffers &b = h->bufs;
     if (h->model.n_legs != 2 || h->model.n_bodies != 7 || !h->hf || h->opts.terrain_rows <= 0) return false;
     const int K = __builtin_popcount(h->model.state_link_mask), P = h->opts.n_height_points, A = 6, F = 2;
     return t.obs_layout == LG_OBS_TRON1_EE && t.gait_mode == 2 && t.double_shift == 1 && t.cat_enable == 0 && t.behavior_resample_steps == 0 &&
-           t.obs_slack > 0 && t.obs_stack > 1 && t.priv_stack > 1 && t.obs_sets <= 2 && (t.obs_sets < 2 || b.obs_dirty) && !b.rand_in &&
+           t.obs_slack > 0 && t.obs_stack > 1 && t.priv_stack > 1 && t.obs_sets <= 2 && (t.obs_sets < 2 || b.obs_dirty) && (inj ? b.rand_in != nullptr : !b.rand_in) &&
            t.obs_frame == 9 + 3 * A + 2 * F && t.priv_frame == t.obs_frame + 7 + 2 * A + 3 + F + K + P + 3 * F + 9 * F && t.num_labels == 3 + K + F + 3 * F &&
            P > 0 && P <= 7 * 8 && h->opts.feet_terrain_info && b.priv_obs_buf && b.labels_buf && b.task_state && b.rand_push_vels &&
            t.task_state_width == LG_TASK_STATE_BIPED && b.link_contact_states &&
@@ -396,6 +397,24 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
         HIPCHK(hipGetLastError());
         return 0;
     }
+    if constexpr (JPL == 3) if (ph == (LG_PHASE_PRE | PR) && h->opts.sim_layout == 2 && quad_ok && h->bufs.rand_in) {
+        // golden replays through the benchmarked tails (tests/test_gpu_mdp.py, tail = "fused-profile"): the component-layout tail of the
+        // task's profile on injected read-backs and uniforms (lg_quad.h INJ); a task outside every profile takes the leg-per-lane launch below
+        dim3 qgrid((threads * 4 + BLOCK - 1) / BLOCK);
+        bool done = true;
+        if constexpr (LEGS == 4) {
+            const int rp = rough_profile(h, true);
+            if (flat_profile(h, true)) { h->last_kernel = "(lg_launch_quad_inj<4, 1>)"; lg_launch_quad_inj<4, 1>(qgrid, st, p); }
+            else if (wtw_profile(h, true)) { h->last_kernel = "(lg_launch_quad_inj<4, 2>)"; lg_launch_quad_inj<4, 2>(qgrid, st, p); }
+            else if (rp == 3) { h->last_kernel = "(lg_launch_quad_inj<4, 3>)"; lg_launch_quad_inj<4, 3>(qgrid, st, p); }
+            else if (rp == 4) { h->last_kernel = "(lg_launch_quad_inj<4, 4>)"; lg_launch_quad_inj<4, 4>(qgrid, st, p); }
+            else done = false;
+        } else {
+            if (biped_profile(h, true)) { h->last_kernel = "(lg_launch_quad_inj<2, 6>)"; lg_launch_quad_inj<2, 6>(qgrid, st, p); }
+            else done = false;
+        }
+        if (done) { HIPCHK(hipGetLastError()); return 0; }
+    }
     const int pi = (ph & LG_PHASE_SIM) ? prof_begin(h, st) : -1;
     switch (ph) {
     case LG_PHASE_ALL:
@@ -505,6 +524,8 @@ extern "C" int lg_philox(const uint32_t counter[4], const uint32_t key[2], uint3
     if (e != hipSuccess) return fail(std::string("lg_philox: ") + hipGetErrorString(e));
     return 0;
 }
+
+extern "C" const char *lg_last_kernel(LgHandle h) { return h ? h->last_kernel.c_str() : ""; }
 
 extern "C" int lg_obs_window(LgHandle h, int32_t *first_frame) {
     if (!h || !first_frame) return fail("lg_obs_window: null argument");

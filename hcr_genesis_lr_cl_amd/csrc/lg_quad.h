@@ -362,7 +362,11 @@ LG_DEV void blank_histories(unsigned long long rm, int e, float *obs, size_t oro
 // JPL = 4 (TRON1 sole foot: two legs of four joints, physics only -- its MDP phases are the leg-per-lane launch): the fourth joint's
 // scalars live in lane 3 of the quad, the chain arrays have four entries, the foot body's sole corners take the calf's second sphere
 // slot with the sole law of lg_kernel.h's sphere_contact.
-template <int LEGS, bool DO_PRE, unsigned MPH, int PROF = 0, int JPL = 3>
+// INJ (test instantiations, lg_step without LG_PHASE_SIM on sim_layout 2): the golden vectors of tests/golden/*_mdp.npz go through the
+// component-layout tails themselves -- the sub-step loop and the read-back are skipped, what they would have left in registers (twists,
+// torques, contact forces, feet, terrain samples) is loaded from the bound buffers the test filled with the reference's recorded values,
+// and every uniform comes from LgBuffers.rand_in instead of Philox.  The MDP statements are the very ones the product instantiation runs.
+template <int LEGS, bool DO_PRE, unsigned MPH, int PROF = 0, int JPL = 3, bool INJ = false>
 #ifdef LG_PK_F32   // one wave per SIMD by design: let the allocator use the accumulation registers instead of spilling the 64-bit tuples
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1))) void quad_sim_kernel(KParams p) {
 #else
@@ -370,6 +374,8 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
 #endif
     using namespace q4;
     static_assert(JPL == 3 || (JPL == 4 && LEGS == 2 && MPH == 0 && PROF == 0), "four-joint legs: biped physics only");
+    static_assert(!INJ || (DO_PRE && MPH == (LG_PHASE_POST | LG_PHASE_RESET) && (PROF == 1 || PROF == 2 || PROF == 3 || PROF == 4 || PROF == 6)),
+                  "injected read-backs: the component-layout tails only");
     constexpr bool FLAT = PROF == 1, PLANE = PROF == 1 || PROF == 2;   // host-checked task profiles (lg_kernel.h flat_profile / wtw_profile)
     constexpr int A = JPL * LEGS;
     // The kernel argument block (KParams, ~800 B of pointers) through ONE vector load: lane i holds bytes [16 i, 16 i + 16).
@@ -613,10 +619,22 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         B.actions[ja] = act;
     }
     float last_foot_v = snap_fv, qd_start = qd;   // kept for the MDP tail (dof_acc, foot_acc)
+    // injected read-backs (INJ): what the physics of this step left behind, as the test put it into the buffers
+    float inj_tq = 0.f, inj_fl[4] = {0.f, 0.f, 0.f, 0.f}, inj_fb = 0.f, inj_fp = 0.f, inj_pg = 0.f, inj_eul = 0.f;
+    if (INJ) {
+        qd_start = B.last_dof_vel[ja]; last_foot_v = B.last_feet_vel[(e * F + foot_slot) * 3 + cj];
+        inj_tq = B.torques[ja];
+#pragma unroll
+        for (int k = 0; k < 4; k++) inj_fl[k] = B.link_contact_forces[(e * nL + foot_link - 3 + k) * 3 + cj];
+        inj_fb = B.link_contact_forces[(e * nL) * 3 + cj];
+        inj_fp = B.feet_pos[(e * F + foot_slot) * 3 + cj];
+        inj_pg = B.projected_gravity[3 * e + cj]; inj_eul = B.base_euler[3 * e + cj];
+    } else {
     if (stj) B.last_dof_vel[ja] = qd;   // "last" snapshots (genesis_simulator.py:21-24)
     if (st) {
         B.last_feet_vel[(e * F + foot_slot) * 3 + cj] = snap_fv;
         if (leg == 0) { B.last_base_lin_vel[3 * e + cj] = snap_blv; B.last_base_ang_vel[3 * e + cj] = snap_bav; }
+    }
     }
     (void)last_foot_v; (void)qd_start;
 
@@ -700,7 +718,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     float f_link[4] = {0.f, 0.f, 0.f, 0.f};   // net contact force on hip, thigh, calf, foot links (component)
     float f_base = 0.f;
 
-    const int decim = HOT(o_decimation), iters = HOT(o_contact_iters), w_every = HOT(o_contact_w_every);
+    const int decim = INJ ? 0 : HOT(o_decimation), iters = HOT(o_contact_iters), w_every = HOT(o_contact_w_every);
     QM Ac_keep = {0.f, 0.f, 0.f};             // dt * W of this leg's foot as of its latest refresh (LgSimOptions.contact_w_every)
     const float mv = HOT(o_max_base_lin_vel), mw = HOT(o_max_base_ang_vel);
 
@@ -1086,7 +1104,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     }
     // ---------------- read-back (genesis_simulator.py:35-60) ---------------------------------------
     int guard_bad = 0;
-    {   // non-finite guard: re-seat the robot
+    if (!INJ) {   // non-finite guard: re-seat the robot
         const float chk = quat + (L.is3 ? (JPL == 4 ? q + qd : 0.f) : pos + vw + ww + q + qd) + nf_poison;
         const int bad = env_or<LEGS>(isfinite(chk) ? 0 : 1);
         const float reseat = HOT(o_base_init_pos[0]) * L.d0 + HOT(o_base_init_pos[1]) * L.d1 + HOT(o_base_init_pos[2]) * L.d2 + origin;
@@ -1151,8 +1169,12 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         foot_p = pos + r;
         foot_v = Vp.l + cross(Vp.a, r);
     }
-    if (stj) { B.dof_pos[ja] = q; B.dof_vel[ja] = qd; B.torques[ja] = torque; }
-    if (st) {
+    if (INJ) {
+        foot_p = inj_fp; foot_v = snap_fv; blv = snap_blv; bav = snap_bav; pg = inj_pg; eul = inj_eul; torque = inj_tq;
+        f_link[0] = inj_fl[0]; f_link[1] = inj_fl[1]; f_link[2] = inj_fl[2]; f_link[3] = inj_fl[3]; f_base = inj_fb;
+    }
+    if (!INJ && stj) { B.dof_pos[ja] = q; B.dof_vel[ja] = qd; B.torques[ja] = torque; }
+    if (!INJ && st) {
         const int l0 = foot_link - 3;
 #pragma unroll
         for (int k = 0; k < 4; k++) B.link_contact_forces[(e * nL + l0 + k) * 3 + cj] = f_link[k];
@@ -1166,7 +1188,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             B.link_contact_forces[(e * nL) * 3 + cj] = f_base;
         }
     }
-    if (live && leg == 0) B.base_quat[4 * e + L.c] = quat;
+    if (!INJ && live && leg == 0) B.base_quat[4 * e + L.c] = quat;
 
     // ---------------- terrain sampling around the base and the feet (genesis_simulator.py:552-610) ------
     const int P = PLANE ? 0 : HOT(o_n_height_points);
@@ -1179,7 +1201,19 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     for (int k = 0; k < 9; k++) f_h9[k] = 0.f;
 #pragma unroll
     for (int i = 0; i < HQ; i++) hq[i] = 0.f;
-    if (P > 0) {
+    if (INJ && P > 0) {   // the terrain read-backs as injected (genesis_simulator.py:552-610 ran in the reference's simulator)
+#pragma unroll
+        for (int i = 0; i < HQ; i++) hq[i] = B.measured_heights[(size_t)e * P + min(hk0 + i * kstride, P - 1)];
+        if (HOT(o_feet_terrain_info)) {
+            float sm = 0.f, mx = -1e30f;
+#pragma unroll
+            for (int k = 0; k < 9; k++) { const float hv = B.height_around_feet[((size_t)e * F + foot_slot) * 9 + k]; sm += hv; mx = fmaxf(mx, hv); f_h9[k] = hv; }
+            f_hmean = sm / 9.f; f_hmax = mx;
+#pragma unroll
+            for (int k = 0; k < 3; k++) f_n3[k] = B.normal_vector_around_feet[((size_t)e * F + foot_slot) * 3 + k];
+        }
+    }
+    if (!INJ && P > 0) {
         const float yn = rcp(fmaxf(fsqrt(qz * qz + qw * qw), 1e-9f));
         const float yz = qz * yn, yw = qw * yn;
         const float px = bc<0>(pos), py = bc<1>(pos);
@@ -1246,7 +1280,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             }
         }
     }
-    if (!PLANE && B.link_contact_states && live) {   // genesis_simulator.py:53-55
+    if (!INJ && !PLANE && B.link_contact_states && live) {   // genesis_simulator.py:53-55
         const unsigned mask = M->state_link_mask;
         const int l0 = foot_link - 3, nst = __popc(mask);
 #pragma unroll
@@ -1383,6 +1417,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             e_lo = (unsigned)(gid & 0xFFFFFFFFu); e_hi = (unsigned)(gid >> 32);
         }
         const unsigned rstep = (unsigned)p.counter;
+        const float *const rin = INJ ? B.rand_in + (size_t)e * HOT(slots.n_slots) : nullptr;   // this env's injected uniforms (LgRandSlots)
         auto philox = [&](unsigned c3) { const U4 c = {e_lo, e_hi, rstep, c3}; return philox4x32_10(c, k0, k1); };
         auto pick = [](const U4 &r, int k) { return k == 0 ? r.x : (k == 1 ? r.y : (k == 2 ? r.z : r.w)); };
         auto anyl = [](bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; };
@@ -1407,8 +1442,10 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         {
             const bool need = (ep_len % h_resample_steps) == 0;
             if (anyl(need)) {
-                const U4 r = philox(0x40000000u + (unsigned)h_slots_cb_cmd);
-                const float nc = resample(cmdv, u01(r.x), u01(r.y), u01(r.z));
+                float u0, u1, u2;
+                if constexpr (INJ) { u0 = rin[h_slots_cb_cmd]; u1 = rin[h_slots_cb_cmd + 1]; u2 = rin[h_slots_cb_cmd + 2]; }
+                else { const U4 r = philox(0x40000000u + (unsigned)h_slots_cb_cmd); u0 = u01(r.x); u1 = u01(r.y); u2 = u01(r.z); }
+                const float nc = resample(cmdv, u0, u1, u2);
                 cmdv = need ? nc : cmdv;
             }
         }
@@ -1423,9 +1460,11 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const int pi_ = h_push_interval;
             if (pi_ > 0 && (p.counter % pi_) == 0) {   // genesis_simulator.py:150-158; lanes 0 / 1 evaluate the two draws' blocks side by side
                 const int slot = h_slots_push + (L.is1 ? 1 : 0);
-                const U4 r = philox((unsigned)(slot >> 2));
+                float up;
+                if constexpr (INJ) up = rin[slot];
+                else { const U4 r = philox((unsigned)(slot >> 2)); up = u01(pick(r, slot & 3)); }
                 const float m = h_max_push_vel_xy;
-                const float pv = (m + m) * u01(pick(r, slot & 3)) - m;
+                const float pv = (m + m) * up - m;
                 const bool xy = L.c < 2;
                 vw = xy ? vw + pv : vw;
                 o_push = xy ? pv : o_push;
@@ -1442,7 +1481,9 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const float hi = L.is0 ? CR(9) : (L.is1 ? CR(11) : (L.is2 ? CR(13) : CR(15)));
             const float val = (hi - lo) * u + lo;
             const int ng = (int)CR(16);
-            const int sel = __builtin_amdgcn_readfirstlane(min((int)floorf(ug * (float)ng), ng - 1));
+            const int sel_l = min((int)floorf(ug * (float)ng), ng - 1);
+            // Philox: one gait draw per call for the whole job (env-independent counter), hence wave-uniform; injected rows carry it per env
+            const int sel = INJ ? sel_l : __builtin_amdgcn_readfirstlane(sel_l);
             const float GAS *tt = &kT->theta_table[sel][0];
             const float nth = tt[foot_slot];
             const float t0 = tt[0], t1 = tt[1], t2 = tt[2], t3 = tt[3];
@@ -1458,9 +1499,12 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const bool needb = brs > 0 && (ep_len % brs) == 0;                  // go2_wtw.py:258-263
             if (anyl(needb)) {   // rare (every resampling_time): two calls, the parameters' blocks side by side in the quad's lanes
                 const int s = h_slots_task_cb + L.c;
-                const U4 r = philox((unsigned)(s >> 2));
-                const U4 rg = philox_e(0xFFFFFFFFu, 0xFFFFFFFFu, (unsigned)((h_slots_task_cb + 4) >> 2));
-                behavior_apply(u01(pick(r, s & 3)), u01(pick(rg, (h_slots_task_cb + 4) & 3)), needb);
+                if constexpr (INJ) behavior_apply(rin[s], rin[h_slots_task_cb + 4], needb);
+                else {
+                    const U4 r = philox((unsigned)(s >> 2));
+                    const U4 rg = philox_e(0xFFFFFFFFu, 0xFFFFFFFFu, (unsigned)((h_slots_task_cb + 4) >> 2));
+                    behavior_apply(u01(pick(r, s & 3)), u01(pick(rg, (h_slots_task_cb + 4) & 3)), needb);
+                }
             }
         }
         const float cmd0 = bc<0>(cmdv), cmd1 = bc<1>(cmdv), cmd2 = bc<2>(cmdv);
@@ -1591,17 +1635,24 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         // leg's `_reset_dofs` block, lane 3: the env-level reset block 0x200 + leg.  A launch ends with its slowest wave, and that is
         // always one with a reset in it: with the reset draws inside the call every wave makes anyway, a reset costs no Philox call
         // (a call is ~800 cycles of quarter-rate multiplies).
-        const U4 rall = philox(L.is0 ? 0x80000000u + (unsigned)(2 * leg) : (L.is1 ? 0x80000000u + (unsigned)(2 * leg) + 1u
-                               : (L.is2 ? 0x40000000u + (unsigned)(h_slots_reset_dof + d0) : 0x80000000u + 0x200u + (unsigned)leg)));
+        U4 rall = {0u, 0u, 0u, 0u};
+        if constexpr (!INJ) rall = philox(L.is0 ? 0x80000000u + (unsigned)(2 * leg) : (L.is1 ? 0x80000000u + (unsigned)(2 * leg) + 1u
+                                          : (L.is2 ? 0x40000000u + (unsigned)(h_slots_reset_dof + d0) : 0x80000000u + 0x200u + (unsigned)leg)));
         const float rux = u01(rall.x), ruy = u01(rall.y), ruz = u01(rall.z), ruw = u01(rall.w);
-        const float ud = L.sel(bc<2>(rux), bc<2>(ruy), bc<2>(ruz));                          // element c of lane 2's block
+        const float ud_p = L.sel(bc<2>(rux), bc<2>(ruy), bc<2>(ruz));                        // element c of lane 2's block
+        const float ud = INJ ? rin[h_slots_reset_dof + d0 + cj] : ud_p;
         const float rc = L.sel4(bc<3>(rux), bc<3>(ruy), bc<3>(ruz), bc<3>(ruw));             // element c of lane 3's block
         // ---- reset_idx (legged_robot.py:94-148, go2.py:17-37, 119-134) + simulator.reset_idx (genesis_simulator.py:62-82) ----
         if (anyl(reset)) {
             // env-level uniforms (block 0x200 + leg sits in quad `leg`): the element each lane needs is fetched from the quad that
             // holds it: v0 = (cmd u0 u1 u2 | friction), v1 = (CoM xyz | mass), v2 / v3 = root twist (slots of env_step_body's eu[])
-            const float v0 = fetch(rc, L.c), v1 = fetch(rc, 4 + L.c);
-            const float v2 = SQ ? fetch(rc, 8 + L.c) : 0.f, v3 = SQ ? fetch(rc, 12 + L.c) : 0.f;   // root twist draws (slots 8-10, 12-14)
+            float v0 = fetch(rc, L.c), v1 = fetch(rc, 4 + L.c);
+            float v2 = SQ ? fetch(rc, 8 + L.c) : 0.f, v3 = SQ ? fetch(rc, 12 + L.c) : 0.f;   // root twist draws (slots 8-10, 12-14)
+            if constexpr (INJ) {   // the same quantities from their slots of the injected row
+                v0 = L.is3 ? rin[HOT(slots.dr_friction)] : rin[HOT(slots.reset_cmd) + cj];
+                v1 = L.is3 ? rin[HOT(slots.dr_mass)] : rin[HOT(slots.dr_com) + cj];
+                v2 = rin[HOT(slots.reset_lin_vel) + cj]; v3 = rin[HOT(slots.reset_ang_vel) + cj];
+            }
             // go2_wtw: ONE more call for what only a reset of this task draws -- lane 0 / 1: the leg's kp / kd blocks
             // (genesis_simulator.py:735-739), lanes 2 / 3 of quads 0 and 1: the four behaviour parameters' draws, lane 2 of quad 2: the
             // gait draw with the env-independent counter (go2_wtw.py:124-142, 180-218)
@@ -1612,13 +1663,17 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 const unsigned c3 = L.is0 ? 0x40000000u + (unsigned)(h_slots_dr_kp + d0)
                                           : (L.is1 ? 0x40000000u + (unsigned)(h_slots_dr_kd + d0) : (unsigned)(sb >> 2));
                 const bool envc = L.c < 2 || !gl;      // this lane's block is keyed on the env (the gait draw is not)
-                const U4 rB = philox_e(envc ? e_lo : 0xFFFFFFFFu, envc ? e_hi : 0xFFFFFFFFu, c3);
+                U4 rB = {0u, 0u, 0u, 0u};
+                if constexpr (!INJ) rB = philox_e(envc ? e_lo : 0xFFFFFFFFu, envc ? e_hi : 0xFFFFFFFFu, c3);
                 const float bx = u01(rB.x), by = u01(rB.y), bz = u01(rB.z);
-                nkp = h_dr_kp_span * L.sel(bc<0>(bx), bc<0>(by), bc<0>(bz)) + h_dr_kp_lo;       // element c of lane 0's block
-                nkd = h_dr_kd_span * L.sel(bc<1>(bx), bc<1>(by), bc<1>(bz)) + h_dr_kd_lo;       // element c of lane 1's block
+                const float kpu = L.sel(bc<0>(bx), bc<0>(by), bc<0>(bz)), kdu = L.sel(bc<1>(bx), bc<1>(by), bc<1>(bz));   // element c of lane 0's / lane 1's block
+                nkp = h_dr_kp_span * (INJ ? rin[h_slots_dr_kp + d0 + cj] : kpu) + h_dr_kp_lo;
+                nkd = h_dr_kd_span * (INJ ? rin[h_slots_dr_kd + d0 + cj] : kdu) + h_dr_kd_lo;
                 const float ub = u01(pick(rB, sb & 3));                                            // valid in lanes 2 / 3
                 // parameter c was drawn in lane 2 + (c & 1) of quad c >> 1; the gait draw in lane 2 of quad 2
-                behavior_apply(fetch(ub, (L.c < 2 ? 2 : 4) + L.c), fetch(ub, 10), reset);
+                const float ubp = fetch(ub, (L.c < 2 ? 2 : 4) + L.c), ubg = fetch(ub, 10);
+                if constexpr (INJ) behavior_apply(rin[h_slots_task_reset + L.c], rin[h_slots_task_reset + 4], reset);
+                else behavior_apply(ubp, ubg, reset);
             }
             // go2_ee: ONE more call likewise -- lane 0 / 1: the leg's kp / kd blocks, lanes 2 / 3 of quad 0: the root xy draws
             // (legged_robot.py:288), lane 2 of quad 1: the terrain-level draw (legged_robot.py:266-268)
@@ -1627,13 +1682,16 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 const int sb = leg == 0 ? h_slots_reset_root_xy + (L.c - 2) : h_slots_terrain_level;
                 const unsigned c3 = L.is0 ? 0x40000000u + (unsigned)(h_slots_dr_kp + d0)
                                           : (L.is1 ? 0x40000000u + (unsigned)(h_slots_dr_kd + d0) : (unsigned)(sb >> 2));
-                const U4 rB = philox(c3);
+                U4 rB = {0u, 0u, 0u, 0u};
+                if constexpr (!INJ) rB = philox(c3);
                 const float bx = u01(rB.x), by = u01(rB.y), bz = u01(rB.z);
-                nkp = h_dr_kp_span * L.sel(bc<0>(bx), bc<0>(by), bc<0>(bz)) + h_dr_kp_lo;
-                nkd = h_dr_kd_span * L.sel(bc<1>(bx), bc<1>(by), bc<1>(bz)) + h_dr_kd_lo;
+                const float kpu = L.sel(bc<0>(bx), bc<0>(by), bc<0>(bz)), kdu = L.sel(bc<1>(bx), bc<1>(by), bc<1>(bz));
+                nkp = h_dr_kp_span * (INJ ? rin[h_slots_dr_kp + d0 + cj] : kpu) + h_dr_kp_lo;
+                nkd = h_dr_kd_span * (INJ ? rin[h_slots_dr_kd + d0 + cj] : kdu) + h_dr_kd_lo;
                 const float ub = u01(pick(rB, sb & 3));          // valid in lanes 2 / 3
                 u_xy = fetch(ub, 2 + (L.c & 1));                 // x / y draw for components 0 / 1 (quad 0, lanes 2 / 3)
                 u_tl = fetch(ub, 6);                             // quad 1, lane 2
+                if constexpr (INJ) { u_xy = rin[h_slots_reset_root_xy + (L.c & 1)]; u_tl = rin[h_slots_terrain_level]; }
             }
             // terrain curriculum (legged_robot.py:254-272 + genesis_simulator.py:140-148; skipped on the construction-time reset, where
             // the reference returns early because init_done is False)
@@ -1739,6 +1797,10 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 uqd = L.sel(bc<1>(ux), bc<1>(uy), bc<1>(uz));
                 ug = fetch(uw, 4 * (cj >> 1) + (cj & 1));
                 ua = fetch(uw, 4 * ((3 + cj) >> 1) + ((3 + cj) & 1));
+                if constexpr (INJ) {   // the frame's entries of the injected row (slots.noise + index in the frame)
+                    const int ns_ = HOT(slots.noise);
+                    uq = rin[ns_ + 9 + d0 + cj]; uqd = rin[ns_ + 9 + A + d0 + cj]; ug = rin[ns_ + 3 + cj]; ua = rin[ns_ + 6 + cj];
+                }
             }
             // observation programs (PROF 4): where the noise-free actor frame sits in the critic frame (-1: nowhere), where the "next state"
             // copy sits in the labels row (-1: none), whether the critic frame is clipped
@@ -1891,6 +1953,10 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 uqd = L.sel(bc<1>(ux), bc<1>(uy), bc<1>(uz));
                 ug = fetch(uw, 4 * (cj >> 1) + (cj & 1));
                 ua = fetch(uw, 4 * ((3 + cj) >> 1) + ((3 + cj) & 1));
+                if constexpr (INJ) {   // the frame's entries of the injected row (slots.noise + index in the frame)
+                    const int ns_ = HOT(slots.noise);
+                    uq = rin[ns_ + 9 + d0 + cj]; uqd = rin[ns_ + 9 + A + d0 + cj]; ug = rin[ns_ + 3 + cj]; ua = rin[ns_ + 6 + cj];
+                }
             }
             // W: an actor-frame entry (noisy into the actor windows, noise-free into the critic frame); WP: a critic-only entry
             auto W = [&](int idx, float v, float u, float ns) {
@@ -1950,6 +2016,10 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 // base uniform k sits in quad k / 2, lane k % 2: gravity component c takes k = c, angular velocity k = 3 + c
                 ug = fetch(uw, 4 * (cj >> 1) + (cj & 1));
                 ua = fetch(uw, 4 * ((3 + cj) >> 1) + ((3 + cj) & 1));
+                if constexpr (INJ) {   // the frame's entries of the injected row (slots.noise + index in the frame)
+                    const int ns_ = HOT(slots.noise);
+                    uq = rin[ns_ + 9 + d0 + cj]; uqd = rin[ns_ + 9 + A + d0 + cj]; ug = rin[ns_ + 3 + cj]; ua = rin[ns_ + 6 + cj];
+                }
             }
             float *o = B.obs_buf + ((size_t)(h_obs_sets > 1 ? p.obs_set : 0) * N + e) * (size_t)(9 + 3 * A);
             auto noisy = [&](float v, float u, float ns) { if (nz) v += (2.f * u - 1.f) * ns; return clampf(v, -co, co); };
@@ -2108,6 +2178,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             e_lo = (unsigned)(gid & 0xFFFFFFFFu); e_hi = (unsigned)(gid >> 32);
         }
         const unsigned rstep = (unsigned)p.counter;
+        const float *const rin = INJ ? B.rand_in + (size_t)e * HOT(slots.n_slots) : nullptr;   // this env's injected uniforms (LgRandSlots)
         auto philox = [&](unsigned c3) { const U4 c = {e_lo, e_hi, rstep, c3}; return philox4x32_10(c, k0, k1); };
         auto philox_e = [&](unsigned elo, unsigned ehi, unsigned c3) { const U4 c = {elo, ehi, rstep, c3}; return philox4x32_10(c, k0, k1); };
         auto pick = [](const U4 &r, int k) { return k == 0 ? r.x : (k == 1 ? r.y : (k == 2 ? r.z : r.w)); };
@@ -2138,8 +2209,10 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         {
             const bool need = (ep_len % h_resample_steps) == 0;
             if (anyl(need)) {
-                const U4 r = philox(0x40000000u + (unsigned)h_slots_cb_cmd);
-                const float nc = resample(cmdv, u01(r.x), u01(r.y), u01(r.z));
+                float u0, u1, u2;
+                if constexpr (INJ) { u0 = rin[h_slots_cb_cmd]; u1 = rin[h_slots_cb_cmd + 1]; u2 = rin[h_slots_cb_cmd + 2]; }
+                else { const U4 r = philox(0x40000000u + (unsigned)h_slots_cb_cmd); u0 = u01(r.x); u1 = u01(r.y); u2 = u01(r.z); }
+                const float nc = resample(cmdv, u0, u1, u2);
                 cmdv = need ? nc : cmdv;
             }
         }
@@ -2154,9 +2227,11 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const int pi_ = h_push_interval;
             if (pi_ > 0 && (p.counter % pi_) == 0) {   // genesis_simulator.py:150-158; lanes 0 / 1 evaluate the two draws' blocks side by side
                 const int slot = h_slots_push + (L.is1 ? 1 : 0);
-                const U4 r = philox((unsigned)(slot >> 2));
+                float up;
+                if constexpr (INJ) up = rin[slot];
+                else { const U4 r = philox((unsigned)(slot >> 2)); up = u01(pick(r, slot & 3)); }
                 const float m = h_max_push_vel_xy;
-                const float pv = (m + m) * u01(pick(r, slot & 3)) - m;
+                const float pv = (m + m) * up - m;
                 const bool xy = L.c < 2;
                 vw = xy ? vw + pv : vw;
                 o_push = xy ? pv : o_push;
@@ -2306,11 +2381,14 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
 
         STAMP(7);
         // ---- Philox calls A and B (every step; see the head of this block) ----
-        const U4 rA = philox(0x80000000u + (L.is0 ? (unsigned)(2 * leg) : (L.is1 ? (unsigned)(2 * leg) + 1u
-                                           : (L.is2 ? (unsigned)(2 * LEGS + 2 + leg) : (unsigned)(3 * LEGS + 2 + leg)))));
+        U4 rA = {0u, 0u, 0u, 0u}, rB = rA;
         const bool coin_lane = el == 7;
-        const U4 rB = philox_e(coin_lane ? 0xFFFFFFFFu : e_lo, coin_lane ? 0xFFFFFFFFu : e_hi,
-                               el == 0 ? 0x80000000u + (unsigned)(2 * LEGS) : (coin_lane ? (unsigned)(h_slots_task_reset >> 2) : 0x80000000u + 0x200u + (unsigned)(el - 1)));
+        if constexpr (!INJ) {
+            rA = philox(0x80000000u + (L.is0 ? (unsigned)(2 * leg) : (L.is1 ? (unsigned)(2 * leg) + 1u
+                                       : (L.is2 ? (unsigned)(2 * LEGS + 2 + leg) : (unsigned)(3 * LEGS + 2 + leg)))));
+            rB = philox_e(coin_lane ? 0xFFFFFFFFu : e_lo, coin_lane ? 0xFFFFFFFFu : e_hi,
+                          el == 0 ? 0x80000000u + (unsigned)(2 * LEGS) : (coin_lane ? (unsigned)(h_slots_task_reset >> 2) : 0x80000000u + 0x200u + (unsigned)(el - 1)));
+        }
         const float ax = u01(rA.x), ay = u01(rA.y), az = u01(rA.z), aw = u01(rA.w);
         const float bx = u01(rB.x), by = u01(rB.y), bz = u01(rB.z), bw = u01(rB.w);
         // ---- reset_idx (legged_robot.py:94-148, tron1_pf_ee.py:193-256, 277-310) + simulator.reset_idx (genesis_simulator.py:62-82) ----
@@ -2319,20 +2397,29 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             // env_step_body's eu[]: 0-2 commands, 3 friction, 4-6 CoM, 7 mass, 8-10 root lin vel, 12-14 root ang vel, 16-18 joint
             // armature / friction / damping, 19-20 gait phase offsets, 21 terrain level)
             auto bundle_c = [&](int src) { return L.sel4(fetch8(bx, src), fetch8(by, src), fetch8(bz, src), fetch8(bw, src)); };
-            const float v0 = bundle_c(1), v1 = bundle_c(2), v2 = bundle_c(3), v3_ = bundle_c(4), v4 = bundle_c(5);
-            const float u_gt = fetch8(bx, 6), u_tl = fetch8(by, 6);                               // uniforms 20, 21
-            const float u_coin = fetch8(u01(pick(rB, h_slots_task_reset & 3)), 7);                // tron1_pf_ee.py:204-210: one coin for the whole job
+            float v0 = bundle_c(1), v1 = bundle_c(2), v2 = bundle_c(3), v3_ = bundle_c(4), v4 = bundle_c(5);
+            float u_gt = fetch8(bx, 6), u_tl = fetch8(by, 6);                                     // uniforms 20, 21
+            float u_coin = fetch8(u01(pick(rB, h_slots_task_reset & 3)), 7);                      // tron1_pf_ee.py:204-210: one coin for the whole job
+            if constexpr (INJ) {   // the same quantities from their slots of the injected row (env_step_body's rs.in paths)
+                v0 = L.is3 ? rin[HOT(slots.dr_friction)] : rin[HOT(slots.reset_cmd) + cj];
+                v1 = L.is3 ? rin[HOT(slots.dr_mass)] : rin[HOT(slots.dr_com) + cj];
+                v2 = rin[HOT(slots.reset_lin_vel) + cj]; v3_ = rin[HOT(slots.reset_ang_vel) + cj];
+                v4 = L.is3 ? rin[h_slots_task_reset + 1] : rin[HOT(slots.dr_joint) + cj];
+                u_gt = rin[h_slots_task_reset + 2]; u_tl = rin[HOT(slots.terrain_level)]; u_coin = rin[h_slots_task_reset];
+            }
             // call C: lane 0 / 1 / 2 of the quad: the leg's `_reset_dofs` / kp / kd blocks, lane 3 of leg 0: the root xy block
             const int sxy = h_slots_reset_root_xy;
-            const U4 rC = philox(L.is0 ? 0x40000000u + (unsigned)(h_slots_reset_dof + d0) : (L.is1 ? 0x40000000u + (unsigned)(h_slots_dr_kp + d0)
-                                       : (L.is2 ? 0x40000000u + (unsigned)(h_slots_dr_kd + d0) : (unsigned)(sxy >> 2))));
+            U4 rC = {0u, 0u, 0u, 0u};
+            if constexpr (!INJ) rC = philox(L.is0 ? 0x40000000u + (unsigned)(h_slots_reset_dof + d0) : (L.is1 ? 0x40000000u + (unsigned)(h_slots_dr_kp + d0)
+                                            : (L.is2 ? 0x40000000u + (unsigned)(h_slots_dr_kd + d0) : (unsigned)(sxy >> 2))));
             const float cx_ = u01(rC.x), cy_ = u01(rC.y), cz_ = u01(rC.z);
-            const float ud = L.sel(bc<0>(cx_), bc<0>(cy_), bc<0>(cz_));                           // element c of lane 0's block
-            const float nkp = h_dr_kp_span * L.sel(bc<1>(cx_), bc<1>(cy_), bc<1>(cz_)) + h_dr_kp_lo;
-            const float nkd = h_dr_kd_span * L.sel(bc<2>(cx_), bc<2>(cy_), bc<2>(cz_)) + h_dr_kd_lo;
+            const float ud_p = L.sel(bc<0>(cx_), bc<0>(cy_), bc<0>(cz_)), kp_p = L.sel(bc<1>(cx_), bc<1>(cy_), bc<1>(cz_)), kd_p = L.sel(bc<2>(cx_), bc<2>(cy_), bc<2>(cz_));
+            const float ud = INJ ? rin[h_slots_reset_dof + d0 + cj] : ud_p;                       // element c of lane 0's block
+            const float nkp = h_dr_kp_span * (INJ ? rin[h_slots_dr_kp + d0 + cj] : kp_p) + h_dr_kp_lo;
+            const float nkd = h_dr_kd_span * (INJ ? rin[h_slots_dr_kd + d0 + cj] : kd_p) + h_dr_kd_lo;
             const float pxy0 = u01(pick(rC, sxy & 3)), pxy1 = u01(pick(rC, (sxy + 1) & 3));      // valid in lane 3 of leg 0
             const float u_x = fetch8(pxy0, 3), u_y = fetch8(pxy1, 3);
-            const float u_xy = L.is0 ? u_x : u_y;
+            const float u_xy = INJ ? rin[sxy + (L.c & 1)] : (L.is0 ? u_x : u_y);
             const bool sit = h_sit_percent > 0.f && u_coin < h_sit_percent;
             // terrain curriculum (legged_robot.py:254-272 + genesis_simulator.py:140-148; skipped on the construction-time reset)
             float norg = origin;
@@ -2449,6 +2536,11 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                     uact = L.sel(bc<2>(ax), bc<2>(ay), bc<2>(az));           // block 2 LEGS + 2 + leg in lane 2
                     const float ck0 = bc<3>(ax), ck1 = bc<3>(ay);            // block 3 LEGS + 2 + leg in lane 3: sin / cos entries
                     uclk = L.is0 ? ck0 : ck1;
+                }
+                if constexpr (INJ) {   // the frame's entries of the injected row (slots.noise + index in the frame)
+                    const int ns_ = HOT(slots.noise);
+                    uq = rin[ns_ + 9 + d0 + cj]; uqd = rin[ns_ + 9 + A + d0 + cj]; ug = rin[ns_ + 3 + cj]; ua = rin[ns_ + 6 + cj];
+                    if (h_noise_act0 != 0.f) { uact = rin[ns_ + 9 + 2 * A + d0 + cj]; uclk = rin[ns_ + 9 + 3 * A + (L.is0 ? 0 : F) + foot_slot]; }
                 }
             }
             auto W = [&](int idx, float v, float u, float ns) {            // an actor-frame entry: noisy into the actor windows, noise-free into the critic frame

@@ -289,3 +289,6 @@ template <int LEGS, bool PRE, unsigned MPH, int PROF, int JPL>
 void lg_launch_quad(dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const KParams &p);
 template <int LEGS, unsigned PH, int PROF, int JPL, bool REPL>
 void lg_launch_env(dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const KParams &p);
+// test instantiations of the component-layout tails: PRE | POST | RESET on injected read-backs and uniforms (lg_quad.h, INJ)
+template <int LEGS, int PROF>
+void lg_launch_quad_inj(dim3 grid, hipStream_t st, const KParams &p);

@@ -244,6 +244,10 @@ class Engine:
         run.  Synchronises."""
         return int(self.buf["nonfinite_count"].item())
 
+    def last_kernel(self):
+        """Launcher instantiation(s) of the latest step (include/lgsim.h lg_last_kernel)."""
+        return self.lib.lg_last_kernel(self.handle).decode()
+
     def profile(self, stride):
         """Time the physics kernel of every `stride`-th step with HIP events (0 = off)."""
         abi.check(self.lib.lg_profile(self.handle, int(stride)), self.lib)

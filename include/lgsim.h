@@ -375,6 +375,10 @@ int lg_obs_set_select(LgHandle h, int32_t set);
  * position of the window inside them is the only observation state the handle keeps besides the copy index). */
 int lg_obs_window_select(LgHandle h, int32_t first_frame);
 int lg_profile(LgHandle h, int32_t stride);
+/* Diagnostic: which kernel instantiation(s) the latest lg_step launched, as the launcher expression(s) of lg_host.hip (e.g.
+ * "(lg_launch_quad<4, true, PR, 1, 3>)" = quad_sim_kernel<LEGS 4, PRE, POST | RESET in the tail, PROF 1, 3 joints per leg>; two launches
+ * are joined by " + ").  bench.py reports it as roofline.kernel; the golden replays assert that they went through the tail they mean to. */
+const char *lg_last_kernel(LgHandle h);
 int lg_profile_read(LgHandle h, float *mean_us, int32_t *samples);
 /* Measurement: the achievable HBM stream rate of THIS device, the denominator bench.py quotes next to the nominal peak (SURVEY 8d:
  * "peak figures must be replaced by a measured stream-copy bandwidth on the box").  Copies `bytes` (a multiple of 16) from src to dst

@@ -75,8 +75,9 @@ def _go2_all_terms_cfg():
     return cfg
 
 
-@pytest.mark.parametrize("task", ["go2", "go2-push", "go2-allterms", "go2-yawcmd", "go2_wtw", "go2_ee", "go2_ts", "go2_cts", "go2_dreamwaq", "tron1_pf_ee", "tron1_pf", "tron1_sf"])
-def test_fused_launch_equals_split_launches(task):
+@pytest.mark.parametrize("task", ["go2", "go2-push", "go2-allterms", "go2-yawcmd", "go2_wtw", "go2_ee", "go2_ts", "go2_cts", "go2_dreamwaq", "tron1_pf_ee", "tron1_pf", "tron1_sf",
+                                  "go2_cat", "go2_wtw-shift", "go2_ee-shift"])
+def test_fused_launch_equals_split_launches(task, monkeypatch):
     """Same state in, one control step through (a) the fused launch -- the instantiation bench.py times,
     quad_sim_kernel<4, true, POST|RESET> with the MDP phases in its tail -- and (b) SIM, then PRE|POST|RESET in
     env_step_kernel<4, PRE|POST|RESET>, the very instantiation the golden replays of tests/test_gpu_mdp.py go through:
@@ -92,6 +93,13 @@ def test_fused_launch_equals_split_launches(task):
     from hcr_genesis_lr_cl_amd.envs import make_env
     N = 256
     start = 480                                                      # crosses the push step (500) for go2_ee
+    want = None
+    if task.endswith("-shift"):      # in-place history shift: outside every profile, so the fused launch runs the GENERIC tail (PROF 0: the
+        task = task[:-6]             # leg-per-lane body as four replicas in the tail of quad_sim_kernel<4, true, POST | RESET, 0>)
+        monkeypatch.setenv("LG_OBS_SLACK", "0")
+        want = "lg_launch_quad<4, true, PR, 0, 3>"
+    if task == "go2_cat":            # two calls in the product too (physics, then the MDP launch: the job-wide CaT flag sits between them)
+        want = "lg_launch_env<LEGS, PR, 0, JPL, false>"
     if task == "go2-push":                                           # go2 again, larger, across its push step (750)
         task, N, start = "go2", 1024, 735
     if task in ("go2-allterms", "go2-yawcmd"):
@@ -123,6 +131,8 @@ def test_fused_launch_equals_split_launches(task):
         e2.common_step_counter = e1.common_step_counter
         act = torch.randn(N, e1.num_actions, generator=g, device="cuda") * (1.0 if t % 5 else 4.0)
         e1.step(act)
+        if want is not None:
+            assert want in e1._engine.last_kernel(), e1._engine.last_kernel()
         e2.common_step_counter += 1
         ca = float(e2.cfg.normalization.clip_actions)
         e2._engine.step(abi.PHASE_SIM, torch.clip(act, -ca, ca), e2.common_step_counter)       # Simulator.step: pre-clipped actions

@@ -3,6 +3,8 @@ read-backs and uniform draws injected) against (a) the golden vectors produced b
 reference's own GO2 class and (b) the numpy oracle at 4096 envs on random inputs.
 Float tolerance 1e-5 abs/rel (f32 sums in a different association order + fused multiply-add);
 integer / boolean outputs exact."""
+import os
+
 import numpy as np
 import pytest
 
@@ -18,6 +20,34 @@ def history_mode(request, monkeypatch):
     compaction every `stack` steps), and the in-place shift."""
     monkeypatch.setenv("LG_OBS_SLACK", request.param)
 
+@pytest.fixture(params=["split", "fused-profile"])
+def tail(request, monkeypatch, history_mode):
+    """Which instantiation of the MDP phases a golden replay goes through:
+      split          env_step_kernel<PRE | POST | RESET> (one leg per lane) -- the generic body;
+      fused-profile  the component-layout tail of the task's profile, i.e. the code the fused launch of env.step() / bench.py runs after its
+                     physics (quad_sim_kernel<.., PROF 1 / 2 / 3 / 4 / 6>), in its INJ instantiation: the sub-steps and the read-back are
+                     replaced by loads of the recorded read-backs, Philox by the recorded uniforms (lg_quad.h).  Needs the sliding history
+                     window (the tails hard-wire it): skipped in the history-shift mode.
+    Every PRE | POST | RESET launch of the test is checked through lg_last_kernel: it ran the instantiation the parameter names."""
+    from hcr_genesis_lr_cl_amd import abi
+    from hcr_genesis_lr_cl_amd.engine import Engine
+    if request.param == "fused-profile":
+        if os.environ.get("LG_OBS_SLACK") == "0":
+            pytest.skip("the component-layout tails need the sliding history window")
+        monkeypatch.setenv("LG_SIM_LAYOUT", "2")
+    seen, orig = [], Engine.step
+
+    def step(self, phases, actions, counter):
+        orig(self, phases, actions, counter)
+        if phases == (abi.PHASE_PRE | abi.PHASE_POST | abi.PHASE_RESET):
+            seen.append(self.last_kernel())
+    monkeypatch.setattr(Engine, "step", step)
+    yield request.param
+    if seen:
+        inj = ["lg_launch_quad_inj" in k for k in seen]
+        assert all(inj) if request.param == "fused-profile" else not any(inj), (request.param, sorted(set(seen)))
+
+
 SIM_KEYS = ("base_pos", "base_quat", "base_lin_vel_w", "base_ang_vel_w", "dof_pos", "dof_vel", "torques",
             "link_contact_forces", "feet_pos", "feet_vel", "last_dof_vel", "last_feet_vel")
 
@@ -32,11 +62,21 @@ def make_engine(N, env_origins=None, cfg_cls=None):
     model = load_model(cfg.asset.name)
     desc, opts, task = builders.make_model_desc(model, cfg), builders.make_sim_options(model, cfg), builders.make_task_cfg(model, cfg)
     eng = Engine(model, desc, opts, task, N, "cuda:0", inject_rand=True)
+    drop_unused_joint_dr(eng, task)
     cr = cfg.commands.ranges
     eng.buf["command_ranges"][:8] = torch.tensor(list(cr.lin_vel_x) + list(cr.lin_vel_y) + list(cr.ang_vel_yaw) + list(cr.heading))
     if env_origins is not None:
         eng.buf["env_origins"].copy_(torch.from_numpy(env_origins))
     return eng, model, cfg, task
+
+
+def drop_unused_joint_dr(eng, task):
+    """What HipSimulator does for a task without per-env joint parameters (simulator.py:310-316): the three (N, 1) arrays are unbound, the
+    kernel takes armature / frictionloss / damping from the model -- and the task fits its profile (lg_host.hip flat_profile ...)."""
+    if not int(task.dr_joint_on):
+        for k in ("joint_armature", "joint_friction", "joint_damping"):
+            eng.buf.pop(k)
+        eng.bind()
 
 
 def put(eng, name, arr):
@@ -106,7 +146,7 @@ class KernelStepper:
                     cmd_range_x=np.array(self.cmd_range_x, np.float32))
 
 
-def test_kernel_reproduces_reference_go2_golden_vectors():
+def test_kernel_reproduces_reference_go2_golden_vectors(tail):
     replay(KernelStepper, lambda t, fx, out: check_against_fixture(t, fx, out, rtol=1e-5, atol=1e-5))
 
 
@@ -186,7 +226,7 @@ class WtwKernelStepper:
                     dr_pd=np.concatenate([get(eng, "kp_scale"), get(eng, "kd_scale")], 1), task_state=get(eng, "task_state"))
 
 
-def test_kernel_reproduces_reference_go2_wtw_golden_vectors():
+def test_kernel_reproduces_reference_go2_wtw_golden_vectors(tail):
     """Env 0 is excluded: the reference couples it to the whole batch through two index-flatten bugs
     (go2_wtw.py:33-34, 455-462) which the kernel does not reproduce (envs/go2_wtw.py docstring)."""
     from tests.test_mdp_oracle import GOLD_WTW, WTW_EXACT, WTW_FLOAT
@@ -242,6 +282,7 @@ class EEKernelStepper:
         model = load_model("go2")
         desc, opts, task = builders.make_model_desc(model, cfg), builders.make_sim_options(model, cfg, terrain), builders.make_task_cfg(model, cfg)
         eng = self.eng = Engine(model, desc, opts, task, N, "cuda:0", inject_rand=True)
+        drop_unused_joint_dr(eng, task)
         eng.set_terrain(terrain.height_field_raw, terrain.env_origins, fx["init_height_points"])
         cr = cfg.commands.ranges
         eng.buf["command_ranges"][:8] = torch.tensor(list(cr.lin_vel_x) + list(cr.lin_vel_y) + list(cr.ang_vel_yaw) + list(cr.heading))
@@ -280,17 +321,19 @@ class EEKernelStepper:
                     cstr_sums=get(eng, "cstr_sums") if "cstr_sums" in eng.buf else None)
 
 
-def test_kernel_reproduces_reference_go2_ee_golden_vectors():
+def test_kernel_reproduces_reference_go2_ee_golden_vectors(tail):
     from tests.test_mdp_oracle import replay_ee, check_ee
     replay_ee(EEKernelStepper, lambda t, fx, out: check_ee(t, fx, out, rtol=1e-5, atol=5e-5))
 
 
 @pytest.mark.parametrize("head", ["go2_ts", "go2_cts", "go2_dreamwaq", "go2_cat"])
-def test_kernel_reproduces_reference_head_golden_vectors(head):
+def test_kernel_reproduces_reference_head_golden_vectors(head, tail):
     """the other Go2-rough heads.  Golden vectors from the reference's own Go2TS / Go2CTS / Go2Dreamwaq classes as
     configured (tests/golden/gen_mdp_fixtures.py gen_head): actor frame, newest frames of the 20-deep actor history and the
     5-deep critic stack (full stacks at the last step), the single-frame auxiliary output, rewards, resets, curricula."""
     from tests.test_mdp_oracle import replay_ee, check_head, head_gold
+    if head == "go2_cat" and tail == "fused-profile":
+        pytest.skip("go2_cat has no component-layout tail: its MDP phases are the leg-per-lane launch in the product too")
     stepper = type("KStepper_" + head, (EEKernelStepper,), {"head": head})
     replay_ee(stepper, lambda t, fx, out: check_head(t, fx, out, rtol=1e-5, atol=5e-5), head_gold(head))
 
@@ -393,6 +436,7 @@ class Tron1KernelStepper:
         model = load_model("tron1_pf")
         desc, opts, task = builders.make_model_desc(model, cfg), builders.make_sim_options(model, cfg, terrain), builders.make_task_cfg(model, cfg)
         eng = self.eng = Engine(model, desc, opts, task, N, "cuda:0", inject_rand=True)
+        drop_unused_joint_dr(eng, task)
         eng.set_terrain(terrain.height_field_raw, terrain.env_origins, fx["init_height_points"])
         cr = cfg.commands.ranges
         eng.buf["command_ranges"][:8] = torch.tensor(list(cr.lin_vel_x) + list(cr.lin_vel_y) + list(cr.ang_vel_yaw) + list(cr.heading))
@@ -428,7 +472,7 @@ class Tron1KernelStepper:
                     task_state=np.concatenate([tsb[:, 0:2], tsb[:, 4:12]], 1), feat_full=get(eng, "obs_buf"), priv_full=get(eng, "priv_obs_buf"))
 
 
-def test_kernel_reproduces_reference_tron1_pf_ee_golden_vectors():
+def test_kernel_reproduces_reference_tron1_pf_ee_golden_vectors(tail):
     """Env 0 excluded for the same reason as in the wtw test (reference index-flatten bugs on the gait clock / indicator)."""
     from tests.test_mdp_oracle import GOLD_TRON1, replay_rough, check_tron1
     replay_rough(GOLD_TRON1, Tron1KernelStepper, lambda t, fx, out: check_tron1(t, fx, out, rtol=1e-5, atol=5e-5, skip_env0=True))
