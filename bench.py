@@ -647,15 +647,11 @@ def main():
                 peak_meas = stream_copy_gbs(dev)
             except Exception as e:      # noqa: BLE001
                 print(f"bench.py: stream copy measurement failed: {e!r}", file=sys.stderr)
-        legs = 2 if args.task.startswith("tron1") else 4
-        if args.task == "go2_cat":
-            layout = "quad_sim_kernel<4,PRE,0> + env_step_kernel<4,POST|RESET> (the job-wide CaT flag separates physics and MDP; timed together)"
-        elif n_local * legs * 4 > 2048 * 64:
-            layout = f"env_step_kernel<{legs},ALL> (leg-per-lane)"
-        elif legs == 4:
-            layout = "quad_sim_kernel<4,PRE,POST|RESET> (component-per-lane physics, MDP phases in its tail)"
-        else:
-            layout = "quad_sim_kernel<2,PRE,0> + env_step_kernel<2,POST|RESET> (component-per-lane physics, then the MDP phases; timed together)"
+        # the kernel instantiation(s) the LAST step really launched (lg_last_kernel: launcher expressions of lg_host.hip):
+        # lg_launch_quad<LEGS, PRE, MDP phases in the tail, PROF, joints per leg> = quad_sim_kernel (one vector component per lane; PROF 1 go2
+        # flat, 2 go2_wtw, 3 go2_ee, 4 observation programs, 6 tron1_pf_ee: component-layout tails; 0 / 5: generic tail), lg_launch_env<LEGS,
+        # phases, PROF, JPL, REPL> = env_step_kernel (one leg per lane); PR = POST | RESET
+        layout = env._engine.last_kernel()
         out = {
             "metric": "env-steps/sec, Go2 flat 12-DOF, 4096 envs @1/2/4/8 MI355X" if args.task == "go2" else f"env-steps/sec, {args.task}",
             "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
