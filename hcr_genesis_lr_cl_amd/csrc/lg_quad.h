@@ -41,9 +41,17 @@ LG_DEV float rot1(float v) { return dpp<QP(1, 2, 0, 3)>(v); }              // la
 LG_DEV float rot2(float v) { return dpp<QP(2, 0, 1, 3)>(v); }              // lane c <- lane (c+2)%3
 LG_DEV float sum3(float t) { return t + rot1(t) + rot2(t); }               // x+y+z in lanes 0..2
 LG_DEV float sum4(float t) { t += dpp<QP(1, 0, 3, 2)>(t); return t + dpp<QP(2, 3, 0, 1)>(t); }
+// lane ^ 4 (the other leg of a biped env: 8 lanes) with two masked DPP moves -- quads 0 / 2 of a row take lane + 4 (row_shl:4, banks 0 and 2),
+// quads 1 / 3 lane - 4 (row_shr:4, banks 1 and 3) -- instead of ds_swizzle: no LDS round trip (~100 cycles exposed wherever the result is
+// needed at once: the sweeps of the contact solve, every reduction of the MDP tail)
+LG_DEV int xor4i(int x) {
+    int t = __builtin_amdgcn_update_dpp(x, x, 0x104, 0xF, 0x5, false);
+    return __builtin_amdgcn_update_dpp(t, x, 0x114, 0xF, 0xA, false);
+}
+LG_DEV float xor4(float v) { return __int_as_float(xor4i(__float_as_int(v))); }
 template <int LEGS> LG_DEV float legsum(float v) {                         // sum over the legs of an env, to all
     if (LEGS == 4) { v += dpp<0x124>(v); v += dpp<0x128>(v); }             // row_ror:4, row_ror:8
-    else if (LEGS == 2) v += __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(v), 0x101F));  // lane ^ 4
+    else if (LEGS == 2) v += xor4(v);
     return v;
 }
 LG_DEV int sum4i_or(int v) {
@@ -53,7 +61,7 @@ LG_DEV int sum4i_or(int v) {
 template <int LEGS> LG_DEV int env_or(int v) {
     v = sum4i_or(v);
     if (LEGS == 4) { v |= __builtin_amdgcn_update_dpp(0, v, 0x124, 0xF, 0xF, true); v |= __builtin_amdgcn_update_dpp(0, v, 0x128, 0xF, 0xF, true); }
-    else if (LEGS == 2) v |= __builtin_amdgcn_ds_swizzle(v, 0x101F);
+    else if (LEGS == 2) v |= xor4i(v);
     return v;
 }
 
@@ -118,14 +126,38 @@ template <int K> LG_DEV float dpp_mac3t(float m0, float m1, float m2, float a, f
     return r;
 }
 LG_DEV float mulv(const QM &m, float v) { return dpp_mac3(m.c0, m.c1, m.c2, v); }
-LG_DEV QM mulmm(const QM &a, const QM &b) {     // a b
-    QM r = {dpp_mac3(a.c0, a.c1, a.c2, b.c0), dpp_mac3(a.c0, a.c1, a.c2, b.c1), dpp_mac3(a.c0, a.c1, a.c2, b.c2)};
+// Whole products in ONE asm block: a single `s_nop 1` in front covers the DPP read-after-write hazard of every source (none is written
+// inside the block), instead of one per three-instruction group (each s_nop is an issue slot of the lone wave: the physics loop had ~190
+// of them per sub-step).  The three accumulators are interleaved, so no instruction waits on the one before it.
+LG_DEV QM mulmm(const QM &a, const QM &b) {     // a b: r.ck = a.c0 b.ck[0] + a.c1 b.ck[1] + a.c2 b.ck[2]
+    QM r;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %6, %3 " LG_QP0 "\n\tv_mul_f32_dpp %1, %7, %3 " LG_QP0 "\n\tv_mul_f32_dpp %2, %8, %3 " LG_QP0 "\n\t"
+        "v_fmac_f32_dpp %0, %6, %4 " LG_QP1 "\n\tv_fmac_f32_dpp %1, %7, %4 " LG_QP1 "\n\tv_fmac_f32_dpp %2, %8, %4 " LG_QP1 "\n\t"
+        "v_fmac_f32_dpp %0, %6, %5 " LG_QP2 "\n\tv_fmac_f32_dpp %1, %7, %5 " LG_QP2 "\n\tv_fmac_f32_dpp %2, %8, %5 " LG_QP2
+        : "=&v"(r.c0), "=&v"(r.c1), "=&v"(r.c2) : "v"(a.c0), "v"(a.c1), "v"(a.c2), "v"(b.c0), "v"(b.c1), "v"(b.c2));
     return r;
 }
-LG_DEV QM mulmmt(const QM &a, const QM &b) {    // a b^T
-    QM r = {dpp_mac3t<0>(a.c0, a.c1, a.c2, b.c0, b.c1, b.c2), dpp_mac3t<1>(a.c0, a.c1, a.c2, b.c0, b.c1, b.c2),
-            dpp_mac3t<2>(a.c0, a.c1, a.c2, b.c0, b.c1, b.c2)};
+LG_DEV QM mulmmt(const QM &a, const QM &b) {    // a b^T: r.ck = a.c0 b.c0[k] + a.c1 b.c1[k] + a.c2 b.c2[k]
+    QM r;
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %6, %3 " LG_QP0 "\n\tv_mul_f32_dpp %1, %6, %3 " LG_QP1 "\n\tv_mul_f32_dpp %2, %6, %3 " LG_QP2 "\n\t"
+        "v_fmac_f32_dpp %0, %7, %4 " LG_QP0 "\n\tv_fmac_f32_dpp %1, %7, %4 " LG_QP1 "\n\tv_fmac_f32_dpp %2, %7, %4 " LG_QP2 "\n\t"
+        "v_fmac_f32_dpp %0, %8, %5 " LG_QP0 "\n\tv_fmac_f32_dpp %1, %8, %5 " LG_QP1 "\n\tv_fmac_f32_dpp %2, %8, %5 " LG_QP2
+        : "=&v"(r.c0), "=&v"(r.c1), "=&v"(r.c2) : "v"(a.c0), "v"(a.c1), "v"(a.c2), "v"(b.c0), "v"(b.c1), "v"(b.c2));
     return r;
+}
+// two independent products a b and c d in one block (inv6: B C^-1 with C^-1 B^T, S^-1 T with Y S^-1)
+LG_DEV void mulmm2(const QM &a, const QM &b, const QM &c, const QM &d, QM &r, QM &q) {
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %9, %6 " LG_QP0 "\n\tv_mul_f32_dpp %1, %10, %6 " LG_QP0 "\n\tv_mul_f32_dpp %2, %11, %6 " LG_QP0 "\n\t"
+        "v_mul_f32_dpp %3, %15, %12 " LG_QP0 "\n\tv_mul_f32_dpp %4, %16, %12 " LG_QP0 "\n\tv_mul_f32_dpp %5, %17, %12 " LG_QP0 "\n\t"
+        "v_fmac_f32_dpp %0, %9, %7 " LG_QP1 "\n\tv_fmac_f32_dpp %1, %10, %7 " LG_QP1 "\n\tv_fmac_f32_dpp %2, %11, %7 " LG_QP1 "\n\t"
+        "v_fmac_f32_dpp %3, %15, %13 " LG_QP1 "\n\tv_fmac_f32_dpp %4, %16, %13 " LG_QP1 "\n\tv_fmac_f32_dpp %5, %17, %13 " LG_QP1 "\n\t"
+        "v_fmac_f32_dpp %0, %9, %8 " LG_QP2 "\n\tv_fmac_f32_dpp %1, %10, %8 " LG_QP2 "\n\tv_fmac_f32_dpp %2, %11, %8 " LG_QP2 "\n\t"
+        "v_fmac_f32_dpp %3, %15, %14 " LG_QP2 "\n\tv_fmac_f32_dpp %4, %16, %14 " LG_QP2 "\n\tv_fmac_f32_dpp %5, %17, %14 " LG_QP2
+        : "=&v"(r.c0), "=&v"(r.c1), "=&v"(r.c2), "=&v"(q.c0), "=&v"(q.c1), "=&v"(q.c2)
+        : "v"(a.c0), "v"(a.c1), "v"(a.c2), "v"(b.c0), "v"(b.c1), "v"(b.c2), "v"(c.c0), "v"(c.c1), "v"(c.c2), "v"(d.c0), "v"(d.c1), "v"(d.c2));
 }
 #else
 LG_DEV float mulv(const QM &m, float v) { return m.c0 * bc<0>(v) + m.c1 * bc<1>(v) + m.c2 * bc<2>(v); }
@@ -143,6 +175,7 @@ LG_DEV QM mulmmt(const QM &a, const QM &b) {    // a b^T
     r.c2 = a.c0 * bc<2>(b.c0) + a.c1 * bc<2>(b.c1) + a.c2 * bc<2>(b.c2);
     return r;
 }
+LG_DEV void mulmm2(const QM &a, const QM &b, const QM &c, const QM &d, QM &r, QM &q) { r = mulmm(a, b); q = mulmm(c, d); }
 #endif
 LG_DEV float multv(const Lane &L, const QM &m, float v) {   // m^T v
     return L.sel(sum3(m.c0 * v), sum3(m.c1 * v), sum3(m.c2 * v));
@@ -185,9 +218,17 @@ LG_DEV QV6 operator*(const QV6 &a, float s) { QV6 r = {a.a * s, a.l * s}; return
 LG_DEV float dot6(const QV6 &a, const QV6 &b) { return sum3(a.a * b.a + a.l * b.l); }
 LG_DEV QV6 muli6(const QI6 &I, const QV6 &v) {
 #ifndef LG_NO_DPP_ASM
-    QV6 r;
-    r.a = dpp_mac3_acc(dpp_mac3(I.A.c0, I.A.c1, I.A.c2, v.a), I.B.c0, I.B.c1, I.B.c2, v.l);
-    r.l = dpp_mac3_acc(dpp_mac3(I.Bt.c0, I.Bt.c1, I.Bt.c2, v.a), I.C.c0, I.C.c1, I.C.c2, v.l);
+    QV6 r;      // rows of (A | B) and of (B^T | C) against [v.a; v.l]: twelve multiply-adds, two interleaved accumulators, one s_nop
+    asm("s_nop 1\n\t"
+        "v_mul_f32_dpp %0, %14, %2 " LG_QP0 "\n\tv_mul_f32_dpp %1, %14, %8 " LG_QP0 "\n\t"
+        "v_fmac_f32_dpp %0, %14, %3 " LG_QP1 "\n\tv_fmac_f32_dpp %1, %14, %9 " LG_QP1 "\n\t"
+        "v_fmac_f32_dpp %0, %14, %4 " LG_QP2 "\n\tv_fmac_f32_dpp %1, %14, %10 " LG_QP2 "\n\t"
+        "v_fmac_f32_dpp %0, %15, %5 " LG_QP0 "\n\tv_fmac_f32_dpp %1, %15, %11 " LG_QP0 "\n\t"
+        "v_fmac_f32_dpp %0, %15, %6 " LG_QP1 "\n\tv_fmac_f32_dpp %1, %15, %12 " LG_QP1 "\n\t"
+        "v_fmac_f32_dpp %0, %15, %7 " LG_QP2 "\n\tv_fmac_f32_dpp %1, %15, %13 " LG_QP2
+        : "=&v"(r.a), "=&v"(r.l)
+        : "v"(I.A.c0), "v"(I.A.c1), "v"(I.A.c2), "v"(I.B.c0), "v"(I.B.c1), "v"(I.B.c2),
+          "v"(I.Bt.c0), "v"(I.Bt.c1), "v"(I.Bt.c2), "v"(I.C.c0), "v"(I.C.c1), "v"(I.C.c2), "v"(v.a), "v"(v.l));
     return r;
 #else
     const float a0 = bc<0>(v.a), a1 = bc<1>(v.a), a2 = bc<2>(v.a), l0 = bc<0>(v.l), l1 = bc<1>(v.l), l2 = bc<2>(v.l);
@@ -219,6 +260,21 @@ LG_DEV QI6 rank1_down(const QI6 &I, const QV6 &U, float dinv) {
 LG_DEV QI6 operator+(const QI6 &a, const QI6 &b) { QI6 r = {a.A + b.A, a.B + b.B, a.Bt + b.Bt, a.C + b.C}; return r; }
 // I - U U^T dinv
 LG_DEV QI6 rank1_down(const QI6 &I, const QV6 &U, float dinv) {
+#ifndef LG_NO_DPP_ASM
+    // entry (c, k) of each block -= u_c dinv u_k: the broadcast of u_k rides on v_fmac_f32_dpp (twelve instructions, one s_nop) instead
+    // of six v_mov_b32_dpp + twelve v_fma
+    const float na = -(U.a * dinv), nl = -(U.l * dinv);
+    QI6 r = I;
+    asm("s_nop 1\n\t"
+        "v_fmac_f32_dpp %0, %12, %14 " LG_QP0 "\n\tv_fmac_f32_dpp %1, %12, %14 " LG_QP1 "\n\tv_fmac_f32_dpp %2, %12, %14 " LG_QP2 "\n\t"
+        "v_fmac_f32_dpp %3, %13, %14 " LG_QP0 "\n\tv_fmac_f32_dpp %4, %13, %14 " LG_QP1 "\n\tv_fmac_f32_dpp %5, %13, %14 " LG_QP2 "\n\t"
+        "v_fmac_f32_dpp %6, %12, %15 " LG_QP0 "\n\tv_fmac_f32_dpp %7, %12, %15 " LG_QP1 "\n\tv_fmac_f32_dpp %8, %12, %15 " LG_QP2 "\n\t"
+        "v_fmac_f32_dpp %9, %13, %15 " LG_QP0 "\n\tv_fmac_f32_dpp %10, %13, %15 " LG_QP1 "\n\tv_fmac_f32_dpp %11, %13, %15 " LG_QP2
+        : "+v"(r.A.c0), "+v"(r.A.c1), "+v"(r.A.c2), "+v"(r.B.c0), "+v"(r.B.c1), "+v"(r.B.c2),
+          "+v"(r.Bt.c0), "+v"(r.Bt.c1), "+v"(r.Bt.c2), "+v"(r.C.c0), "+v"(r.C.c1), "+v"(r.C.c2)
+        : "v"(U.a), "v"(U.l), "v"(na), "v"(nl));
+    return r;
+#else
     const float ua = U.a * dinv, ul = U.l * dinv;
     const float a0 = bc<0>(U.a), a1 = bc<1>(U.a), a2 = bc<2>(U.a), l0 = bc<0>(U.l), l1 = bc<1>(U.l), l2 = bc<2>(U.l);
     QI6 r;
@@ -227,19 +283,21 @@ LG_DEV QI6 rank1_down(const QI6 &I, const QV6 &U, float dinv) {
     r.Bt.c0 = I.Bt.c0 - ul * a0; r.Bt.c1 = I.Bt.c1 - ul * a1; r.Bt.c2 = I.Bt.c2 - ul * a2;
     r.C.c0 = I.C.c0 - ul * l0; r.C.c1 = I.C.c1 - ul * l1; r.C.c2 = I.C.c2 - ul * l2;
     return r;
+#endif
 }
 #endif
 // inverse of an SPD 6x6 by Schur complement on the C block
 LG_DEV QI6 inv6(const Lane &L, const QI6 &N) {
     const QM Ci = inv_sym(L, N.C);
-    const QM T = mulmm(N.B, Ci);            // B C^-1
+    QM T, Y, SiT, YSi;
+    mulmm2(N.B, Ci, Ci, N.Bt, T, Y);        // B C^-1 and C^-1 B^T = T^T, one block
     const QM S = N.A - mulmm(T, N.Bt);      // A - B C^-1 B^T
     const QM Si = inv_sym(L, S);
-    const QM Y = mulmm(Ci, N.Bt);           // C^-1 B^T = T^T
+    mulmm2(Si, T, Y, Si, SiT, YSi);
     QI6 r;
     r.A = Si;
-    r.B = -mulmm(Si, T);
-    r.Bt = -mulmm(Y, Si);
+    r.B = -SiT;
+    r.Bt = -YSi;
     r.C = Ci - mulmm(Y, r.B);
     return r;
 }
@@ -2251,7 +2309,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         int fail = 0;
 #pragma unroll
         for (int k = 0; k < 4; k++) fail |= (((tmask >> (l0 + k)) & 1u) && n2[k] > 100.0f) ? 1 : 0;
-        fail |= __builtin_amdgcn_ds_swizzle(fail, 0x101F);                       // the other leg (lane ^ 4)
+        fail |= xor4i(fail);                                                     // the other leg (lane ^ 4)
         fail |= ((tmask & 1u) && nb2 > 100.0f) ? 1 : 0;
         fail |= pgz > h_max_projected_gravity ? 1 : 0;
         if (guard_bad) failb = LG_FAIL_NONFINITE;   // a re-seated env ends its episode here (lgsim.h)
@@ -2343,8 +2401,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             add(LG_R_FEET_CONTACT_STAND_STILL, (cnt == (float)LEGS ? 1.f : 0.f) * (cmd_xyz < 0.1f ? 1.f : 0.f));
         }
         if (RON(LG_R_FEET_DISTANCE)) {                                                                                           // tron1_pf_ee.py:458-463
-            const float ox = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(fpx), 0x101F));
-            const float oy = __int_as_float(__builtin_amdgcn_ds_swizzle(__float_as_int(fpy), 0x101F));
+            const float ox = xor4(fpx), oy = xor4(fpy);
             const float dxy = sqrtf((fpx - ox) * (fpx - ox) + (fpy - oy) * (fpy - oy));
             add(LG_R_FEET_DISTANCE, fmaxf(0.f, h_foot_distance_threshold - dxy));
         }
