@@ -252,6 +252,8 @@ def load_lib():
     lib.lg_philox.restype = C.c_int
     lib.lg_stream_copy.argtypes = [C.c_void_p, C.c_void_p, i64, i32, C.c_void_p, C.POINTER(C.c_float)]
     lib.lg_stream_copy.restype = C.c_int
+    lib.lg_terrain_generate.argtypes = [C.c_void_p, i32, C.c_void_p, C.c_void_p, C.c_void_p, i32, i32, i32, i32, i32, i32, C.c_double, C.c_void_p, C.c_void_p]
+    lib.lg_terrain_generate.restype = C.c_int
     lib.lg_rollout_record.argtypes = [i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, f32, C.c_void_p, C.c_void_p,
                                       C.POINTER(LgRowCopy), i32, C.c_void_p]
     lib.lg_rollout_gae.argtypes = [i32, i32, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, f32, f32, C.c_void_p, C.c_void_p,
@@ -269,10 +271,17 @@ def load_lib():
 
 
 EXPORTS = ["lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step",
-           "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_obs_set_select", "lg_obs_window_select", "lg_profile", "lg_profile_read", "lg_philox", "lg_stream_copy", "lg_last_kernel", "lg_last_error",
+           "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_obs_set_select", "lg_obs_window_select", "lg_profile", "lg_profile_read", "lg_philox", "lg_stream_copy", "lg_terrain_generate", "lg_last_kernel", "lg_last_error",
            "lg_abi_version"]
 ROLLOUT_EXPORTS = ["lg_rollout_record", "lg_rollout_gae"]          # include/lgrollout.h
 ROLLOUT_MAX_COPIES = 8
+
+
+TILE_SLOPE, TILE_UNIFORM, TILE_STAIRS, TILE_OBSTACLES = 0, 1, 2, 3
+
+
+class LgTerrainTile(C.Structure):
+    _fields_ = [("kind", i32), ("row", i32), ("col", i32), ("ip", i32 * 5), ("aux_off", i32)]
 
 
 class LgRowCopy(C.Structure):

@@ -508,6 +508,102 @@ extern "C" int lg_stream_copy(const void *src, void *dst, int64_t bytes, int32_t
     return 0;
 }
 
+// ---- heightfield generation (include/lgsim.h lg_terrain_generate) ---------------------------------------------------------------------
+// One thread per pixel of a tile.  Everything float is float64 with the reference's (numpy / FITPACK) operation order and NO contraction
+// into fused multiply-adds (__dmul_rn / __dadd_rn / __ddiv_rn): the grid has to come out sample for sample.
+__global__ __launch_bounds__(256) void terrain_tile_kernel(const LgTerrainTile *__restrict__ tiles, const double *__restrict__ aux,
+                                                           const int32_t *__restrict__ iaux, int16_t *__restrict__ hf, int cols, int W, int border) {
+    const LgTerrainTile T = tiles[blockIdx.y];
+    const int pix = blockIdx.x * blockDim.x + threadIdx.x;
+    if (pix >= W * W) return;
+    const int x = pix / W, y = pix % W;
+    int v = 0;
+    if (T.kind == LG_TILE_SLOPE) {
+        // (peak * ramp_x * ramp_y).astype(int16) inside the edge, then clip to [min(ref, 0), max(ref, 0)] (terrain_utils.py:160-181)
+        const int peak = T.ip[0], edge = T.ip[1], half = T.ip[2], c = W / 2;
+        auto val = [&](int px, int py) {
+            if (px < edge || px >= W - edge || py < edge || py >= W - edge) return 0;
+            const double rx = __ddiv_rn((double)(c - abs(c - px)), (double)c), ry = __ddiv_rn((double)(c - abs(c - py)), (double)c);
+            return (int)(int16_t)__dmul_rn(__dmul_rn((double)peak, rx), ry);
+        };
+        const int ref = val(W / 2 - half, W / 2 - half);
+        v = min(max(val(x, y), min(ref, 0)), max(ref, 0));
+    } else if (T.kind == LG_TILE_STAIRS) {
+        // nested squares [r w, W - r w)^2 at height r h while the square is wider than the platform (terrain_utils.py:361-371)
+        const int w = T.ip[0], h = T.ip[1], plat = T.ip[2];
+        int rings = 0;
+        for (int lo = 0, hi = W; hi - lo > plat; lo += w, hi -= w) rings++;
+        const int d = min(min(x, W - 1 - x), min(y, W - 1 - y));
+        v = rings > 0 ? min(d / w, rings - 1) * h : 0;
+    } else if (T.kind == LG_TILE_OBSTACLES) {
+        const int n = T.ip[0], plat = T.ip[1];
+        const int32_t *r = iaux + T.aux_off;
+        for (int k = 0; k < n; k++)          // later rectangles overwrite earlier ones
+            if (x >= r[5 * k] && x < r[5 * k] + r[5 * k + 2] && y >= r[5 * k + 1] && y < r[5 * k + 1] + r[5 * k + 3]) v = r[5 * k + 4];
+        const int a = (W - plat) / 2, b = (W + plat) / 2;
+        if (x >= a && x < b && y >= a && y < b) v = 0;
+    } else if (T.kind == LG_TILE_UNIFORM) {
+        // np.rint(RectBivariateSpline(kx = ky = 1)(xs, ys)) inside the edge: FITPACK fpbisp / fpbspl for degree 1
+        const int edge = T.ip[0], nx = T.ip[1], ny = T.ip[2], mx = T.ip[3], my = T.ip[4];
+        const int i = x - edge, j = y - edge;
+        if (i >= 0 && i < mx && j >= 0 && j < my) {
+            const double *tx = aux + T.aux_off, *ty = tx + nx, *cf = ty + ny, *xs = cf + (nx - 2) * (ny - 2), *ys = xs + mx;
+            auto basis = [](const double *t, int n, double arg, int &l, double &h1, double &h2) {
+                const int k1 = 2, nk1 = n - k1;                       // fpbisp: clamp, then the knot interval (1-based l: t(l) <= arg < t(l+1))
+                const double tb = t[k1 - 1], te = t[nk1];
+                if (arg < tb) arg = tb;
+                if (arg > te) arg = te;
+                l = k1;
+                while (!(arg < t[l]) && l != nk1) l++;                // t(l1) with l1 = l + 1 is t[l] in 0-based terms
+                const double f = __ddiv_rn(1.0, __dadd_rn(t[l], -t[l - 1]));      // fpbspl, k = 1
+                h1 = __dmul_rn(f, __dadd_rn(t[l], -arg));
+                h2 = __dmul_rn(f, __dadd_rn(arg, -t[l - 1]));
+            };
+            int lx, ly;
+            double wx1, wx2, wy1, wy2;
+            basis(tx, nx, xs[i], lx, wx1, wx2);
+            basis(ty, ny, ys[j], ly, wy1, wy2);
+            const int nky1 = ny - 2;
+            int l1 = (lx - 2) * nky1 + (ly - 2);
+            double sp = 0.0;
+            sp = __dadd_rn(sp, __dmul_rn(__dmul_rn(cf[l1], wx1), wy1));
+            sp = __dadd_rn(sp, __dmul_rn(__dmul_rn(cf[l1 + 1], wx1), wy2));
+            l1 += nky1;
+            sp = __dadd_rn(sp, __dmul_rn(__dmul_rn(cf[l1], wx2), wy1));
+            sp = __dadd_rn(sp, __dmul_rn(__dmul_rn(cf[l1 + 1], wx2), wy2));
+            v = (int)(int16_t)rint(sp);                               // np.rint: half to even
+        }
+    }
+    hf[(size_t)(border + T.row * W + x) * cols + border + T.col * W + y] = (int16_t)v;
+}
+
+__global__ __launch_bounds__(256) void terrain_origin_kernel(const LgTerrainTile *__restrict__ tiles, const int16_t *__restrict__ hf, int cols, int W,
+                                                             int border, int o1, int o2, double vscale, double *__restrict__ origin_z) {
+    __shared__ int smax[256];
+    const LgTerrainTile T = tiles[blockIdx.x];
+    const int n = o2 - o1;
+    int m = -32768;
+    for (int k = threadIdx.x; k < n * n; k += blockDim.x)
+        m = max(m, (int)hf[(size_t)(border + T.row * W + o1 + k / n) * cols + border + T.col * W + o1 + k % n]);
+    smax[threadIdx.x] = m;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) { if ((int)threadIdx.x < s) smax[threadIdx.x] = max(smax[threadIdx.x], smax[threadIdx.x + s]); __syncthreads(); }
+    if (threadIdx.x == 0) origin_z[blockIdx.x] = __dmul_rn((double)smax[0], vscale);
+}
+
+extern "C" int lg_terrain_generate(const LgTerrainTile *tiles, int32_t n_tiles, const double *aux, const int32_t *iaux, int16_t *hf, int32_t rows,
+                                   int32_t cols, int32_t tile_px, int32_t border_px, int32_t o1, int32_t o2, double vertical_scale, double *origin_z,
+                                   void *stream) {
+    if (!tiles || !hf || !origin_z || n_tiles < 1 || tile_px < 1 || rows < 2 || cols < 2 || o1 < 0 || o2 <= o1 || o2 > tile_px)
+        return fail("lg_terrain_generate: bad argument");
+    hipStream_t st = (hipStream_t)stream;
+    HIPCHK(hipMemsetAsync(hf, 0, (size_t)rows * cols * sizeof(int16_t), st));
+    hipLaunchKernelGGL(terrain_tile_kernel, dim3((tile_px * tile_px + 255) / 256, n_tiles), dim3(256), 0, st, tiles, aux, iaux, hf, cols, tile_px, border_px);
+    hipLaunchKernelGGL(terrain_origin_kernel, dim3(n_tiles), dim3(256), 0, st, tiles, hf, cols, tile_px, border_px, o1, o2, vertical_scale, origin_z);
+    HIPCHK(hipGetLastError());
+    return 0;
+}
+
 __global__ void philox_kat_kernel(U4 c, unsigned k0, unsigned k1, unsigned *out) {
     const U4 r = philox4x32_10(c, k0, k1);
     out[0] = r.x; out[1] = r.y; out[2] = r.z; out[3] = r.w;

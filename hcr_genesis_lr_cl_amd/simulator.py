@@ -148,7 +148,9 @@ class HipSimulator:
             pass
         elif mesh_type == "heightfield":
             from .terrain import Terrain
-            self._terrain = Terrain(self._cfg.terrain)
+            # the heightfield is generated on the device (terrain.py: one init-time kernel; LG_TERRAIN_HOST=1 keeps the numpy path)
+            import os
+            self._terrain = Terrain(self._cfg.terrain, device=None if os.environ.get("LG_TERRAIN_HOST") == "1" else self._device)
         elif mesh_type == "trimesh":
             raise NotImplementedError("Trimesh terrain is not supported by this backend, use heightfield")
         else:
@@ -180,7 +182,10 @@ class HipSimulator:
         self._engine = Engine(m, self._desc, self._opts, self._task, self._num_envs, self._device,
                               inject_rand=self._inject_rand)
         if self._terrain is not None:          # genesis_simulator.py:765-778 + height sample grid :496-507
-            self._height_samples = torch.tensor(self._terrain.heightsamples).view(self._terrain.tot_rows, self._terrain.tot_cols).to(self._device)
+            if self._terrain.heightsamples_dev is not None:
+                self._height_samples = self._terrain.heightsamples_dev
+            else:
+                self._height_samples = torch.tensor(self._terrain.heightsamples).view(self._terrain.tot_rows, self._terrain.tot_cols).to(self._device)
             hx = torch.tensor(cfg.terrain.measured_points_x)
             hy = torch.tensor(cfg.terrain.measured_points_y)
             gx, gy = torch.meshgrid(hx, hy, indexing="ij")

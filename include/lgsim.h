@@ -385,6 +385,28 @@ int lg_profile_read(LgHandle h, float *mean_us, int32_t *samples);
  * `iters` times with a float4 grid-stride kernel on `stream`, timed with HIP events after one untimed pass; *gbs = (read + write)
  * bytes per second / 1e9.  src / dst: device pointers, 16-byte aligned, not overlapping. */
 int lg_stream_copy(const void *src, void *dst, int64_t bytes, int32_t iters, void *stream, float *gbs);
+/* ---- heightfield generation on the device (legged_gym/utils/terrain.py:37-203, terrain_utils.py:34-372).
+ * One tile of the terrain map.  The host side (hcr_genesis_lr_cl_amd/terrain.py) walks the tiles in the reference's order, takes the
+ * numpy draws the reference would take (np.random.choice call order) and describes each tile here; the kernel then evaluates every pixel
+ * of every tile: integers for the stairs and the obstacles, the reference's float64 arithmetic for the slopes, and FITPACK's own evaluation
+ * recurrences (fpbspl / fpbisp, kx = ky = 1) for the up-sampled random-uniform tiles, whose spline knots and coefficients the host fitted.
+ * Result: the int16 grid of the reference sample for sample (tests/golden/terrain_*.npz). */
+#define LG_TILE_SLOPE 0      /* terrain_utils.py:128-181  ip: peak, edge, half platform; */
+#define LG_TILE_UNIFORM 1    /* terrain_utils.py:34-96    ip: edge, nx (knots), ny, n eval x, n eval y; aux: tx | ty | c | x | y (doubles) */
+#define LG_TILE_STAIRS 2     /* terrain_utils.py:330-372  ip: step width px, step height (int16 units, signed), platform px */
+#define LG_TILE_OBSTACLES 3  /* terrain_utils.py:204-258  ip: n rectangles, platform px; iaux: (i0, j0, w, l, height) per rectangle, in draw order */
+typedef struct LgTerrainTile {
+    int32_t kind, row, col;  /* tile (row, col) of the map: rows = levels (x), cols = types (y) */
+    int32_t ip[5];
+    int32_t aux_off;         /* first double of this tile in `aux` / first int in `iaux` */
+} LgTerrainTile;
+/* Fill the (rows x cols) int16 heightfield `hf` (device, zeroed here: the border stays flat) and the per-tile origin heights
+ * `origin_z` (n_tiles doubles, device: max over the central 2 m x 2 m times vertical_scale, terrain.py:197-202).  tiles / aux / iaux: device
+ * copies of the descriptor table and of the injected arrays.  tile_px: pixels per tile edge; border_px: border width; o1, o2: pixel range of
+ * the origin window. */
+int lg_terrain_generate(const LgTerrainTile *tiles, int32_t n_tiles, const double *aux, const int32_t *iaux, int16_t *hf, int32_t rows,
+                        int32_t cols, int32_t tile_px, int32_t border_px, int32_t o1, int32_t o2, double vertical_scale, double *origin_z,
+                        void *stream);
 /* Diagnostic: one Philox4x32-10 block computed on the device by the kernel's own generator (known-answer tests). */
 int lg_philox(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
 const char *lg_last_error(void);
