@@ -417,10 +417,19 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
     }
     const int pi = (ph & LG_PHASE_SIM) ? prof_begin(h, st) : -1;
     switch (ph) {
-    case LG_PHASE_ALL:
-        if constexpr (JPL == 3) { if (flat_profile(h)) { LG_LAUNCH(pi, (lg_launch_env<LEGS, LG_PHASE_ALL, 1, 3, false>), grid); break; } }   // large go2 batches: same FLAT constants
+    case LG_PHASE_ALL: {
+        // LG_SPLIT_ALL=1 (developer switch): PRE | SIM and POST | RESET as two launches instead of the whole-step kernel, whose 480-512
+        // registers per lane spill a few dwords to scratch (tools/register_table.py)
+        const char *sp = getenv("LG_SPLIT_ALL");
+        if (sp && atoi(sp) != 0) {
+            LG_LAUNCH_FIRST(pi, (lg_launch_env<LEGS, LG_PHASE_PRE | LG_PHASE_SIM, 0, JPL, false>), grid);
+            LG_LAUNCH_LAST(pi, (lg_launch_env<LEGS, PR, 0, JPL, false>), grid);
+            break;
+        }
+        if constexpr (JPL == 3 && LEGS == 4) { if (flat_profile(h)) { LG_LAUNCH(pi, (lg_launch_env<4, LG_PHASE_ALL, 1, 3, false>), grid); break; } }   // large go2 batches: same FLAT constants
         LG_LAUNCH(pi, (lg_launch_env<LEGS, LG_PHASE_ALL, 0, JPL, false>), grid);
         break;
+    }
     case LG_PHASE_SIM: LG_LAUNCH(pi, (lg_launch_env<LEGS, LG_PHASE_SIM, 0, JPL, false>), grid); break;
     case LG_PHASE_PRE | LG_PHASE_POST | LG_PHASE_RESET: LG_LAUNCH_PLAIN((lg_launch_env<LEGS, LG_PHASE_PRE | PR, 0, JPL, false>), grid); break;
     case LG_PHASE_PRE | LG_PHASE_SIM | LG_PHASE_POST: LG_LAUNCH(pi, (lg_launch_env<LEGS, LG_PHASE_PRE | LG_PHASE_SIM | LG_PHASE_POST, 0, JPL, false>), grid); break;

@@ -58,7 +58,7 @@ QUAD(2, true, 12u, 0, 3) QUAD(2, true, 12u, 5, 3) QUAD(2, true, 12u, 6, 3)
 #elif LG_GROUP == 9    // whole step, quadruped (large batches)
 ENV(4, 15u, 0, 3, false) ENV(4, 15u, 1, 3, false)
 #elif LG_GROUP == 10    // whole step, biped
-ENV(2, 15u, 0, 3, false) ENV(2, 15u, 1, 3, false) ENV(2, 15u, 0, 4, false)
+ENV(2, 15u, 0, 3, false) ENV(2, 15u, 0, 4, false)
 #elif LG_GROUP == 11   // MDP phases behind a physics launch, quadruped
 ENV(4, 12u, 0, 3, false) ENV(4, 12u, 0, 3, true) ENV(4, 13u, 0, 3, false)
 #elif LG_GROUP == 12   // ... biped
