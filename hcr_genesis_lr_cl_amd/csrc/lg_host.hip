@@ -373,6 +373,7 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
             const char *bf = getenv("LG_BIPED_FUSE");
             fuse = pre && rest == PR && !h->task.cat_enable && (bf ? atoi(bf) != 0 : true);
             const char *bt = getenv("LG_BIPED_TAIL");    // 0: the leg-per-lane MDP body in the tail even where the component-layout tail applies
+            // PROF 6: workgroups of two waves per group of 8 envs (lg_quad.h DUO: both run the physics, then split the tail)
             if (fuse && hfb && biped_profile(h) && !(bt && atoi(bt) == 0)) LG_LAUNCH(pi, (lg_launch_quad<2, true, PR, 6, 3>), qgrid);
             else if (fuse && hfb) LG_LAUNCH(pi, (lg_launch_quad<2, true, PR, 5, 3>), qgrid);
             else if (fuse) LG_LAUNCH(pi, (lg_launch_quad<2, true, PR, 0, 3>), qgrid);

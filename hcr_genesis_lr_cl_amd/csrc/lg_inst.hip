@@ -14,13 +14,14 @@
 
 template <int LEGS, bool PRE, unsigned MPH, int PROF, int JPL>
 void lg_launch_quad(dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const KParams &p) {
-    if (e0 || e1) hipExtLaunchKernelGGL((quad_sim_kernel<LEGS, PRE, MPH, PROF, JPL>), grid, dim3(BLOCK), 0, st, e0, e1, 0, p);
-    else hipLaunchKernelGGL((quad_sim_kernel<LEGS, PRE, MPH, PROF, JPL>), grid, dim3(BLOCK), 0, st, p);
+    const dim3 block(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET) ? 2 * BLOCK : BLOCK);   // PROF 6: two waves per group of envs (lg_quad.h DUO)
+    if (e0 || e1) hipExtLaunchKernelGGL((quad_sim_kernel<LEGS, PRE, MPH, PROF, JPL>), grid, block, 0, st, e0, e1, 0, p);
+    else hipLaunchKernelGGL((quad_sim_kernel<LEGS, PRE, MPH, PROF, JPL>), grid, block, 0, st, p);
 }
 #define QUAD(...) template void lg_launch_quad<__VA_ARGS__>(dim3, hipStream_t, hipEvent_t, hipEvent_t, const KParams &);
 template <int LEGS, int PROF>
 void lg_launch_quad_inj(dim3 grid, hipStream_t st, const KParams &p) {
-    hipLaunchKernelGGL((quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET, PROF, 3, true>), grid, dim3(BLOCK), 0, st, p);
+    hipLaunchKernelGGL((quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET, PROF, 3, true>), grid, dim3(PROF == 6 ? 2 * BLOCK : BLOCK), 0, st, p);
 }
 #define QUAD_INJ(...) template void lg_launch_quad_inj<__VA_ARGS__>(dim3, hipStream_t, const KParams &);
 #else

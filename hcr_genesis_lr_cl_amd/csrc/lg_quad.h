@@ -68,7 +68,7 @@ template <int LEGS> LG_DEV int env_or(int v) {
 // 16 bytes of the kernel argument segment per lane (lane i: bytes [16 i, 16 i + 16), clamped to `n16` chunks)
 LG_DEV uint4 kernarg_lane(int n16) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    return reinterpret_cast<const uint4 *>(__builtin_amdgcn_kernarg_segment_ptr())[min((int)threadIdx.x, n16 - 1)];
+    return reinterpret_cast<const uint4 *>(__builtin_amdgcn_kernarg_segment_ptr())[min((int)(threadIdx.x & 63u), n16 - 1)];
 #else
     (void)n16;
     return make_uint4(0u, 0u, 0u, 0u);
@@ -428,9 +428,10 @@ template <int LEGS, bool DO_PRE, unsigned MPH, int PROF = 0, int JPL = 3, bool I
 #ifdef LG_PK_F32   // one wave per SIMD by design: let the allocator use the accumulation registers instead of spilling the 64-bit tuples
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1))) void quad_sim_kernel(KParams p) {
 #else
-__global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
+__global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET) ? 2 * BLOCK : BLOCK) void quad_sim_kernel(KParams p) {
 #endif
     using namespace q4;
+    const unsigned tl_ = threadIdx.x & 63u;   // lane of the wave (a workgroup is one wave, two for the DUO tail below)
     static_assert(JPL == 3 || (JPL == 4 && LEGS == 2 && MPH == 0 && PROF == 0), "four-joint legs: biped physics only");
     static_assert(!INJ || (DO_PRE && MPH == (LG_PHASE_POST | LG_PHASE_RESET) && (PROF == 1 || PROF == 2 || PROF == 3 || PROF == 4 || PROF == 6)),
                   "injected read-backs: the component-layout tails only");
@@ -458,14 +459,14 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     __shared__ int sHot[256 + 2 * BLOCK];
     int hv0, hv1, hv2, hv3;
     {
-        const int GAS *hp = KPTR(const int GAS *, offsetof(KParams, H)) + (threadIdx.x & 63);
+        const int GAS *hp = KPTR(const int GAS *, offsetof(KParams, H)) + (tl_ & 63);
         hv0 = hp[0]; hv1 = hp[64]; hv2 = hp[128]; hv3 = hp[192];
     }
     uint4 stg0, stg1, stg2, stg3;
     {
         typedef unsigned int u4v __attribute__((ext_vector_type(4)));
         const u4v GAS *src = reinterpret_cast<const u4v GAS *>(Mg);
-        const u4v a0 = src[threadIdx.x], a1 = src[threadIdx.x + BLOCK], a2 = src[threadIdx.x + 2 * BLOCK], a3 = src[threadIdx.x + 3 * BLOCK];
+        const u4v a0 = src[tl_], a1 = src[tl_ + BLOCK], a2 = src[tl_ + 2 * BLOCK], a3 = src[tl_ + 3 * BLOCK];
         stg0 = make_uint4(a0.x, a0.y, a0.z, a0.w); stg1 = make_uint4(a1.x, a1.y, a1.z, a1.w);
         stg2 = make_uint4(a2.x, a2.y, a2.z, a2.w); stg3 = make_uint4(a3.x, a3.y, a3.z, a3.w);
     }
@@ -473,8 +474,16 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     unsigned long long _stamp0 = 0; (void)_stamp0;
     STAMP(0);
     STAMPB(4096);
+    // DUO (the tron1_pf_ee tail, PROF 6): a workgroup of TWO waves per group of 8 envs.  4096 biped envs are 512 waves on 1024 SIMDs; with
+    // two, both waves run the same physics on the same envs (role 0 owns its stores) and then SPLIT the MDP tail -- role 0: rewards,
+    // episode sums, the noisy actor frames; role 1: the critic frames, labels, pushes, reset / task state -- so the serial tail of the
+    // wave that ends the launch is about half as long.  Being one workgroup the two are resident together whatever else runs on the
+    // chip; barriers order their accesses to the shared state: every start-of-kernel load of both has returned before either stores
+    // (below), and role 0's read-back stores are out before role 1's reset stores to the same arrays.
+    constexpr bool DUO = PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET);
     const int wg = lg_wg();   // XCD-aware (lg_kernel.h)
-    const int tid = wg * BLOCK + threadIdx.x;
+    const int role = DUO ? (int)(threadIdx.x >> 6) : 0;
+    const int tid = wg * BLOCK + tl_;
     Lane L;
     L.c = tid & 3; L.is0 = L.c == 0; L.is1 = L.c == 1; L.is2 = L.c == 2; L.is3 = L.c == 3;
     L.d0 = L.is0 ? 1.f : 0.f; L.d1 = L.is1 ? 1.f : 0.f; L.d2 = L.is2 ? 1.f : 0.f;
@@ -483,8 +492,9 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     const int quad = tid >> 2, leg = quad % LEGS;
     int e = quad / LEGS;
     const int N = KINT(B.n_envs);
-    const bool live = e < N;
-    if (!live) e = N - 1;
+    const bool alive = e < N;                 // this lane's env exists
+    const bool live = alive && role == 0;     // ... and this wave owns its physics / state stores
+    if (!alive) e = N - 1;
     const bool st = live && !L.is3;           // this lane stores vector components
     const bool stj = JPL == 4 ? live : st;    // ... joint values
     const bool lead = st && leg == 0;         // ... and the per-env ones
@@ -551,10 +561,10 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     if (k_joint_armature) { dr_arm = k_joint_armature[e]; dr_jf = k_joint_friction[e]; dr_jd = k_joint_damping[e]; }
     const float origin = k_env_origins ? k_env_origins[3 * e + cj] : 0.f;
     int crv = 0;
-    if (MPH != 0) crv = reinterpret_cast<const int GAS *>(k_command_ranges)[min((int)threadIdx.x, LG_CMD_RANGE_FLOATS - 1)];
+    if (MPH != 0) crv = reinterpret_cast<const int GAS *>(k_command_ranges)[min((int)tl_, LG_CMD_RANGE_FLOATS - 1)];
     int prw = 0;   // observation programs for the MDP tail (lg_kernel.h PRG_I / PRG_F)
     if ((MPH & LG_PHASE_RESET) != 0 && (PROF == 4 || ((PROF == 0 || PROF == 5) && KINT(k.obs_layout) == LG_OBS_PROGRAM))) {
-        const int tl = (int)threadIdx.x;
+        const int tl = (int)tl_;
         prw = reinterpret_cast<const int GAS *>(tl < 26 ? &kT->priv_prog : &kT->labels_prog)[tl < 26 ? tl : min(tl - 26, 25)];
     }
     // MDP working set of the wave's 16 legs, fetched by lanes 0..15 in this same burst and parked in LDS: the MDP tail
@@ -624,9 +634,9 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         const int32_t GAS *tl = KB(const int32_t GAS *, terrain_levels), *tt = KB(const int32_t GAS *, terrain_types);
         if (tl) { w_lvl = tl[e]; w_type = tt[e]; }
     }
-    if (MPH != 0 && !CTAIL && threadIdx.x < 16) {
+    if (MPH != 0 && !CTAIL && tl_ < 16) {
         const LgTaskCfg GAS *T = kT;
-        const int lt = wg * 16 + (int)threadIdx.x, legL = lt % LEGS, dL = 3 * legL;
+        const int lt = wg * 16 + (int)tl_, legL = lt % LEGS, dL = 3 * legL;
         const int eL = min(lt / LEGS, N - 1);
         const int flL = legL == 0 ? KINT(k.m_foot_link[0]) : (legL == 1 ? KINT(k.m_foot_link[1]) : (legL == 2 ? KINT(k.m_foot_link[2]) : KINT(k.m_foot_link[3])));
         int fsL = 0;
@@ -653,20 +663,21 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     }
 
     asm volatile("" ::: "memory");
-    sHot[threadIdx.x] = hv0; sHot[threadIdx.x + 64] = hv1; sHot[threadIdx.x + 128] = hv2; sHot[threadIdx.x + 192] = hv3;
+    sHot[tl_] = hv0; sHot[tl_ + 64] = hv1; sHot[tl_ + 128] = hv2; sHot[tl_ + 192] = hv3;
     if (MPH != 0) {
-        sHot[threadIdx.x + 256] = crv;
-        sHot[threadIdx.x + 256 + BLOCK] = prw;
-        if (!CTAIL && threadIdx.x < 16) {
+        sHot[tl_ + 256] = crv;
+        sHot[tl_ + 256 + BLOCK] = prw;
+        if (!CTAIL && tl_ < 16) {
             const unsigned rm = p.k.reward_mask;
-            const bool leadL = (wg * 16 + threadIdx.x) % LEGS == 0;
+            const bool leadL = (wg * 16 + tl_) % LEGS == 0;
 #pragma unroll
-            for (int k = 0; k < LG_R_COUNT; k++) sStF[k * 16 + threadIdx.x] = (leadL && ((rm >> k) & 1u)) ? wsv[k] : 0.f;
+            for (int k = 0; k < LG_R_COUNT; k++) sStF[k * 16 + tl_] = (leadL && ((rm >> k) & 1u)) ? wsv[k] : 0.f;
 #pragma unroll
-            for (int k = LG_R_COUNT; k < NST - 1; k++) sStF[k * 16 + threadIdx.x] = wsv[k];
+            for (int k = LG_R_COUNT; k < NST - 1; k++) sStF[k * 16 + tl_] = wsv[k];
         }
     }
-    sMraw[threadIdx.x] = stg0; sMraw[threadIdx.x + BLOCK] = stg1; sMraw[threadIdx.x + 2 * BLOCK] = stg2; sMraw[threadIdx.x + 3 * BLOCK] = stg3;
+    sMraw[tl_] = stg0; sMraw[tl_ + BLOCK] = stg1; sMraw[tl_ + 2 * BLOCK] = stg2; sMraw[tl_ + 3 * BLOCK] = stg3;
+    if (DUO) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): both waves hold everything they read before anything of the step is stored
     __syncthreads();
     STAMP(23);
 
@@ -1158,7 +1169,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
     // becomes `s_waitcnt vmcnt(k)` with k = the stores issued since on the shortest path, i.e. a drain of most of those stores.
     __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0); expcnt / lgkmcnt untouched
     if (!PLANE && p.k.cat_enable) {   // go2_cat's job-wide "some joint faster than 4 rad/s" flag (LG_CR_ANY_FAST)
-        if (__builtin_amdgcn_ballot_w64(stj && fabsf(qd) > 4.0f) != 0ull && threadIdx.x == 0) B.command_ranges[LG_CR_ANY_FAST + (int)(p.counter & 1)] = 1.0f;
+        if (__builtin_amdgcn_ballot_w64(stj && fabsf(qd) > 4.0f) != 0ull && tl_ == 0) B.command_ranges[LG_CR_ANY_FAST + (int)(p.counter & 1)] = 1.0f;
     }
     // ---------------- read-back (genesis_simulator.py:35-60) ---------------------------------------
     int guard_bad = 0;
@@ -1351,6 +1362,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         if (L.is0 && leg == 0 && (mask & 1u)) B.link_contact_states[(size_t)e * nst] = fb > 1.f ? 1.f : 0.f;
     }
 
+    if (DUO) __syncthreads();   // role 0's read-back stores are issued; role 1's tail may now store into the same arrays (resets)
     STAMP(22);
     STAMPB(8192);
     // ---------------- MDP phases in the same launch, go2-flat and go2_wtw profiles: component layout, all 64 lanes ------------
@@ -1479,7 +1491,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         auto philox = [&](unsigned c3) { const U4 c = {e_lo, e_hi, rstep, c3}; return philox4x32_10(c, k0, k1); };
         auto pick = [](const U4 &r, int k) { return k == 0 ? r.x : (k == 1 ? r.y : (k == 2 ? r.z : r.w)); };
         auto anyl = [](bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; };
-        auto lane_of_row = [&](int l16) { return (int)((threadIdx.x & 48u) | (unsigned)l16) << 2; };   // byte address for ds_bpermute
+        auto lane_of_row = [&](int l16) { return (int)((tl_ & 48u) | (unsigned)l16) << 2; };   // byte address for ds_bpermute
         auto fetch = [&](float v, int l16) { return __int_as_float(__builtin_amdgcn_ds_bpermute(lane_of_row(l16), __float_as_int(v))); };
         auto jsum = [&](float v) { return bc<0>(legsum<LEGS>(sum3(v))); };       // over the env's joints (value in joint lanes), to all lanes
         auto vnorm2 = [&](float v) { return bc<0>(sum3(v * v)); };               // |v|^2 of a component-layout vector, to the quad
@@ -2242,10 +2254,12 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         auto pick = [](const U4 &r, int k) { return k == 0 ? r.x : (k == 1 ? r.y : (k == 2 ? r.z : r.w)); };
         auto anyl = [](bool b) { return __builtin_amdgcn_ballot_w64(b) != 0ull; };
         // lane l8 (0..7) of this env, to every lane of the env
-        auto fetch8 = [&](float v, int l8) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)((threadIdx.x & 56u) | (unsigned)l8) << 2, __float_as_int(v))); };
+        auto fetch8 = [&](float v, int l8) { return __int_as_float(__builtin_amdgcn_ds_bpermute((int)((tl_ & 56u) | (unsigned)l8) << 2, __float_as_int(v))); };
         auto jsum = [&](float v) { return bc<0>(legsum<LEGS>(sum3(v))); };       // over the env's joints (value in joint lanes), to all lanes
         auto vnorm2 = [&](float v) { return bc<0>(sum3(v * v)); };               // |v|^2 of a component-layout vector, to the quad
         const int el = ei;                                                       // lane of the env: 4 leg + c
+        const bool A_ = role == 0, B_ = role == 1;                               // this wave's share of the tail (wave-uniform)
+        const bool liveB = alive && B_, stB = liveB && !L.is3, sv = alive && !L.is3;
 
         float cmdv = m_cmd, air = m_air;
         float es[4] = {b_es[0], b_es[1], b_es[2], b_es[3]};
@@ -2293,7 +2307,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 const bool xy = L.c < 2;
                 vw = xy ? vw + pv : vw;
                 o_push = xy ? pv : o_push;
-                if (live && leg == 0 && xy) { B.rand_push_vels[3 * e + L.c] = pv; B.base_lin_vel_w[3 * e + L.c] = vw; }
+                if (liveB && leg == 0 && xy) { B.rand_push_vels[3 * e + L.c] = pv; B.base_lin_vel_w[3 * e + L.c] = vw; }   // role 1: in program order with its reset stores
             }
         }
         const float cmd0 = bc<0>(cmdv), cmd1 = bc<1>(cmdv), cmd2 = bc<2>(cmdv);
@@ -2356,6 +2370,13 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             for (int i = 0; i < HQ; i++) acc += (hk0 + i * kstride < P) ? pzv - hq[i] : 0.f;
             mean_height = legsum<LEGS>(sum4(acc)) / (float)P;
         }
+        if (B_ && RON(LG_R_BIPED_PERIODIC_GAIT)) {   // role 1 writes the critic frame's gait block: the force indicator of the reward term below
+            const float two_pi = 6.283185307179586f;
+            float ph = phi + theta;
+            ph = (ph - floorf(ph)) * two_pi;
+            expC = (ph >= 0.f && ph < h_b_swing * two_pi) ? -1.f : 0.f;
+        }
+        if (A_) {
         if (RON(LG_R_ACTION_RATE)) { const float d = last_act - act; add(LG_R_ACTION_RATE, jsum(d * d)); }                     // :495-497
         if (RON(LG_R_ACTION_SMOOTHNESS)) { const float d = act - 2.f * last_act + llast_act; add(LG_R_ACTION_SMOOTHNESS, jsum(d * d)); }   // :499-503
         if (RON(LG_R_ANG_VEL_XY)) { const float bx = bc<0>(bav), by = bc<1>(bav); add(LG_R_ANG_VEL_XY, bx * bx + by * by); }    // :462-464
@@ -2430,6 +2451,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         }
         if (h_only_positive_rewards) total = fmaxf(total, 0.f);                                                               // :161-162
         if (RON(LG_R_TERMINATION)) add(LG_R_TERMINATION, (reset && !time_out) ? 1.f : 0.f);                                      // :163-168
+        }
         {   // gait clock (tron1_pf_ee.py:28-35)
             gait_time += cdt;
             if (gait_time >= gait_period - cdt / 2.f) gait_time = 0.f;
@@ -2441,8 +2463,8 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         U4 rA = {0u, 0u, 0u, 0u}, rB = rA;
         const bool coin_lane = el == 7;
         if constexpr (!INJ) {
-            rA = philox(0x80000000u + (L.is0 ? (unsigned)(2 * leg) : (L.is1 ? (unsigned)(2 * leg) + 1u
-                                       : (L.is2 ? (unsigned)(2 * LEGS + 2 + leg) : (unsigned)(3 * LEGS + 2 + leg)))));
+            if (A_) rA = philox(0x80000000u + (L.is0 ? (unsigned)(2 * leg) : (L.is1 ? (unsigned)(2 * leg) + 1u     // observation noise: the actor frames are role 0's
+                                               : (L.is2 ? (unsigned)(2 * LEGS + 2 + leg) : (unsigned)(3 * LEGS + 2 + leg)))));
             rB = philox_e(coin_lane ? 0xFFFFFFFFu : e_lo, coin_lane ? 0xFFFFFFFFu : e_hi,
                           el == 0 ? 0x80000000u + (unsigned)(2 * LEGS) : (coin_lane ? (unsigned)(h_slots_task_reset >> 2) : 0x80000000u + 0x200u + (unsigned)(el - 1)));
         }
@@ -2520,7 +2542,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const QM Rr = quat_rows(L, quat);
             const float npg = -L.sel(bc<2>(Rr.c0), bc<2>(Rr.c1), bc<2>(Rr.c2));
             if (reset) { blv = vw; bav = ww; pg = npg; }
-            if (reset && st) {
+            if (reset && stB) {
                 B.dof_pos[ja] = q; B.dof_vel[ja] = 0.f; B.last_dof_vel[ja] = 0.f;
                 B.actions[ja] = 0.f; B.last_actions[ja] = 0.f; B.llast_actions[ja] = 0.f;
                 if (h_dr_pd_on) { B.kp_scale[ja] = o_kp; B.kd_scale[ja] = o_kd; }
@@ -2537,7 +2559,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                     jp[e] = o_jnt;
                 }
             }
-            if (reset && live && leg == 0) {
+            if (reset && liveB && leg == 0) {
                 B.base_quat[4 * e + L.c] = quat;
                 if (L.is3) {
                     if (h_dr_friction_on) B.friction_values[e] = o_fric;
@@ -2573,13 +2595,14 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const unsigned ip4 = ((unsigned)e * (unsigned)prow + (unsigned)(p.obs_win * PF + (PST - 1) * PF)) * 4u;
             const unsigned il4 = (unsigned)e * (unsigned)h_num_labels * 4u;
             auto SO = [](float *base, unsigned off, float v) { *reinterpret_cast<float *>(reinterpret_cast<char *>(base) + off) = v; };
+            // role 0 blanks the actor rows, role 1 the (four times longer) critic rows
             if (anyl(reset)) {                         // legged_robot_ee.py: the histories of a reset env restart from zeros
-                blank_histories(__builtin_amdgcn_ballot_w64(reset && live && el == 0), e, B.obs_buf + (size_t)cs * N * orow + (size_t)p.obs_win * FR, orow, (ST - 1) * FR,
-                                B.priv_obs_buf + (size_t)cs * N * prow + (size_t)p.obs_win * PF, prow, (PST - 1) * PF);
+                blank_histories(__builtin_amdgcn_ballot_w64(reset && alive && el == 0), e, B.obs_buf + (size_t)cs * N * orow + (size_t)p.obs_win * FR, orow,
+                                A_ ? (ST - 1) * FR : 0, B.priv_obs_buf + (size_t)cs * N * prow + (size_t)p.obs_win * PF, prow, B_ ? (PST - 1) * PF : 0);
             }
             if (two && anyl(!reset && w_dirty != 0)) {
-                blank_histories(__builtin_amdgcn_ballot_w64(!reset && w_dirty != 0 && live && el == 0), e, B.obs_buf + (size_t)cs * N * orow + (size_t)p.obs_win * FR, orow,
-                                (ST - 2) * FR, B.priv_obs_buf + (size_t)cs * N * prow + (size_t)p.obs_win * PF, prow, (PST - 2) * PF);
+                blank_histories(__builtin_amdgcn_ballot_w64(!reset && w_dirty != 0 && alive && el == 0), e, B.obs_buf + (size_t)cs * N * orow + (size_t)p.obs_win * FR, orow,
+                                A_ ? (ST - 2) * FR : 0, B.priv_obs_buf + (size_t)cs * N * prow + (size_t)p.obs_win * PF, prow, B_ ? (PST - 2) * PF : 0);
             }
             const bool w2o = two && ST > 1, w2p = two && PST > 1;
             float uq = 0.5f, uqd = 0.5f, uact = 0.5f, uclk = 0.5f, ug = 0.5f, ua = 0.5f;
@@ -2604,8 +2627,8 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 const float cl = clampf(v, -co, co);
                 const float nv = clampf(nz ? v + (2.f * u - 1.f) * ns : v, -co, co);
                 const unsigned o4 = io4 + 4u * (unsigned)idx, p4 = ip4 + 4u * (unsigned)idx;
-                SO(ob_c, o4, nv); if (w2o) SO(ob_x, o4, nv);
-                SO(pb_c, p4, cl); if (w2p) SO(pb_x, p4, cl);
+                if (A_) { SO(ob_c, o4, nv); if (w2o) SO(ob_x, o4, nv); }
+                else { SO(pb_c, p4, cl); if (w2p) SO(pb_x, p4, cl); }
             };
             auto WP = [&](int idx, float v) { const float cl = clampf(v, -co, co); const unsigned p4 = ip4 + 4u * (unsigned)idx; SO(pb_c, p4, cl); if (w2p) SO(pb_x, p4, cl); };
             auto WL = [&](int idx, float v) { SO(lb_c, il4 + 4u * (unsigned)idx, v); };
@@ -2623,26 +2646,30 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
             const int oDR = FR, oG = FR + 7 + 2 * A + 3, oK = oG + F, oH = oK + K, oN = oH + P, oR = oN + 3 * F;
             const float clr = clampf(fpz - f_hmax - h_foot_height_offset, -1.f, 1.f);
             const float nrm = L.sel(f_n3[0], f_n3[1], f_n3[2]);
-            if (st) {
+            if (sv) {
                 W(9 + d0 + cj, (q - q0) * h_obs_scale_dof_pos, uq, m_nq);
                 W(9 + A + d0 + cj, qd * h_obs_scale_dof_vel, uqd, m_nqd);
                 W(9 + 2 * A + d0 + cj, act, uact, b_nact);
                 if (L.c < 2) W(9 + 3 * A + (L.is0 ? 0 : F) + foot_slot, L.is0 ? sn : csn, uclk, L.is0 ? b_nclk0 : b_nclk1);
+                if (leg == 0) {
+                    W(cj, cmdv * (L.is2 ? h_obs_scale_ang_vel : h_obs_scale_lin_vel), 0.5f, 0.f);
+                    W(3 + cj, pg, ug, L.sel(h_noise_lead_0, h_noise_lead_1, h_noise_lead_2));
+                    W(6 + cj, bav * h_obs_scale_ang_vel, ua, L.sel(h_noise_lead_3, h_noise_lead_4, h_noise_lead_5));
+                }
+            }
+            if (stB) {
                 WP(oDR + 7 + d0 + cj, o_kp - h_kp_offset);
                 WP(oDR + 7 + A + d0 + cj, o_kd - h_kd_offset);
                 WP(oN + 3 * foot_slot + cj, nrm);
                 WL(3 + K + F + 3 * foot_slot + cj, nrm);
                 if (L.is2) { WP(oG + foot_slot, expC); WL(3 + K + foot_slot, clr); }
                 if (leg == 0) {
-                    W(cj, cmdv * (L.is2 ? h_obs_scale_ang_vel : h_obs_scale_lin_vel), 0.5f, 0.f);
-                    W(3 + cj, pg, ug, L.sel(h_noise_lead_0, h_noise_lead_1, h_noise_lead_2));
-                    W(6 + cj, bav * h_obs_scale_ang_vel, ua, L.sel(h_noise_lead_3, h_noise_lead_4, h_noise_lead_5));
                     WP(oDR + 2 + cj, o_com);
                     WP(oDR + 7 + 2 * A + cj, o_jnt);
                     WL(cj, blv * h_obs_scale_lin_vel);
                 }
             }
-            if (live) {
+            if (liveB) {
                 if (leg == 1) WP(oDR + (L.c < 2 ? L.c : 3 + L.c), env4);                 // friction, mass | push x, y at oDR + 5, 6
                 if (chas) { WP(oK + cidx, csv); WL(3 + cidx, csv); }
                 if (leg == 0 && L.is3 && (smask & 1u)) { const float cb = nb2 > 1.f ? 1.f : 0.f; WP(oK, cb); WL(3, cb); }
@@ -2664,26 +2691,27 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
                 if (leg == 0 && L.c < 3) ts[L.c] = L.sel(gait_time, phi, gait_period);
                 if (leg == 0 && L.is0 && B.obs_dirty) B.obs_dirty[e] = reset ? 1 : 0;
             }
-            if (st) {
+            if (stB) {
                 B.llast_actions[ja] = reset ? 0.f : last_act;
                 B.last_actions[ja] = act;
             }
         }
         STAMP(10);
         // ---- persistent MDP state ----
-        if (live) {
+        if (live) {        // role 0: what the reward terms produced
             const unsigned es4 = ((unsigned)el * (unsigned)N + (unsigned)e) * 4u;      // (term, N) rows: uniform base + 32-bit offset per lane
 #pragma unroll
             for (int k = 0; k < 4; k++)
                 if (el + 8 * k < LG_R_COUNT && ((rmask >> (el + 8 * k)) & 1u))
                     *reinterpret_cast<float *>(reinterpret_cast<char *>(B.episode_sums + (size_t)8 * k * N) + es4) = es[k];
             if (L.is0) { B.feet_air_time[e * F + foot_slot] = air; B.last_contacts[e * F + foot_slot] = (uint8_t)last_contact; }
-            if (leg == 0) {
-                B.commands[4 * e + L.c] = cmdv;
-                if (L.is0) {
-                    B.episode_length_buf[e] = ep_len; B.fail_buf[e] = (long long)failb;
-                    B.reset_buf[e] = reset ? 1 : 0; B.time_out_buf[e] = time_out ? 1 : 0; B.rew_buf[e] = total;
-                }
+            if (leg == 0 && L.is0) B.rew_buf[e] = total;
+        }
+        if (liveB && leg == 0) {      // role 1: commands, counters, flags
+            B.commands[4 * e + L.c] = cmdv;
+            if (L.is0) {
+                B.episode_length_buf[e] = ep_len; B.fail_buf[e] = (long long)failb;
+                B.reset_buf[e] = reset ? 1 : 0; B.time_out_buf[e] = time_out ? 1 : 0;
             }
         }
         STAMP(11);
@@ -2695,7 +2723,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         // above, so those stores drain in the background instead of being waited for.
         __shared__ float sX[NX * 16];
         {
-            const int qi = (int)threadIdx.x >> 2;
+            const int qi = (int)tl_ >> 2;
             auto XW = [&](int k, float v) { if (!L.is3) sX[(k + L.c) * 16 + qi] = v; };
             XW(XA, act); XW(XLA, last_act); XW(XLLA, llast_act); XW(XQ, q); XW(XQD, qd); XW(XLQD, qd_start); XW(XTQ, torque);
             XW(XFL, f_link[0]); XW(XFL + 3, f_link[1]); XW(XFL + 6, f_link[2]); XW(XFL + 9, f_link[3]);
@@ -2712,7 +2740,7 @@ __global__ __launch_bounds__(BLOCK) void quad_sim_kernel(KParams p) {
         // the wave's 64 lanes run the leg-per-lane body as FOUR replicas of its 16 leg-lanes (lane = 16 replica + leg-lane): every replica
         // computes the same values, replica 0 owns the state stores, and the observation section deals its stores over the replicas
         // (the four destinations of an actor-frame entry, the two of a critic entry; blanking with 64 lanes)
-        env_step_body<LEGS, MPH, true, (PROF == 5 ? 0 : PROF)>(p, sMraw, sHot, sStF, sX, wg * 16 + ((int)threadIdx.x & 15), (int)threadIdx.x & 15);
+        env_step_body<LEGS, MPH, true, (PROF == 5 ? 0 : PROF)>(p, sMraw, sHot, sStF, sX, wg * 16 + ((int)tl_ & 15), (int)tl_ & 15);
     }
     STAMPB(12288);
 }
