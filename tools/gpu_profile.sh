@@ -25,14 +25,19 @@ done
 cp profiles/hbm_traffic.json profiles/sq_counters.json gpurun_out/ 2>/dev/null || true
 echo "== bench lines (read the PMC summaries just written)"
 for T in $TASKS; do
-  EXTRA=$([ $T = go2 ] && echo "--ppo-rollout 30" || echo "--no-cpu-baseline")
+  EXTRA=$([ $T = go2 ] && echo "--ppo-rollout 30" || ([ $T = go2_ee ] || [ $T = tron1_pf_ee ]) && echo "--no-cpu-baseline --ppo-rollout 10" || echo "--no-cpu-baseline")
   python bench.py --task $T $EXTRA > gpurun_out/${TAG}_bench_$T.json 2> gpurun_out/${TAG}_bench_$T.err || { echo "bench failed for $T"; continue; }
   python -c "import json;d=json.load(open('gpurun_out/${TAG}_bench_$T.json'));r=d['roofline'];print('$T', round(d['value']/1e6,2),'M env-steps/s', round(r['launch_us'],2),'us frac',round(r['frac'],4),'traffic',r['traffic'],'valu',(r['valu'] or {}).get('frac'))"
 done
 echo "== rocprofv3 kernel stats of the headline command"
-rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats --output-format csv -- python3 bench.py --steps 1000 --no-cpu-baseline > gpurun_out/bench_prof.json 2> gpurun_out/prof_stats.err
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats --output-format csv -- python3 bench.py --steps 1000 --no-cpu-baseline --no-stream-copy > gpurun_out/bench_prof.json 2> gpurun_out/prof_stats.err
 S=$(find gpurun_out/prof_stats -name "*kernel_stats.csv" | head -1)
 head -8 "$S" > gpurun_out/${TAG}_kernel_stats.csv
+echo "== the driver's command (20 steps, 5 warm-up), plain and under rocprofv3"
+python bench.py --steps 20 --warmup 5 > gpurun_out/${TAG}_bench_go2_driver_cmd.json 2> gpurun_out/${TAG}_bench_go2_driver_cmd.err || echo "driver-cmd bench failed"
+rocprofv3 --kernel-trace --stats -d gpurun_out/prof_stats_drv --output-format csv -- python3 bench.py --steps 20 --warmup 5 --no-cpu-baseline --no-stream-copy > /dev/null 2> gpurun_out/prof_stats_drv.err
+S=$(find gpurun_out/prof_stats_drv -name "*kernel_stats.csv" | head -1)
+head -6 "$S" > gpurun_out/${TAG}_kernel_stats_driver_cmd.csv
 cp profiles/hbm_traffic.json profiles/sq_counters.json gpurun_out/ 2>/dev/null || true
 head -4 gpurun_out/${TAG}_kernel_stats.csv | cut -c1-220
 echo "copy gpurun_out/${TAG}_* + hbm_traffic.json + sq_counters.json into profiles/ (tracked)"

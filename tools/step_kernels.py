@@ -1,14 +1,15 @@
 """Kernel-name prefixes (as rocprofv3 prints them, trailing template arguments left open) of one control step of each task at
 4096 envs per GPU.  First entry = the launch that happens exactly once per step."""
 _QUAD_FUSED = ["quad_sim_kernel<4, true, 12u,", "obs_compact_kernel"]
-_BIPED = ["quad_sim_kernel<2, true, 0u,", "env_step_kernel<2, 12u", "obs_compact_kernel"]
+_BIPED = ["quad_sim_kernel<2, true, 12u,", "obs_compact_kernel"]                                   # one launch since round 3
+_BIPED_2 = ["quad_sim_kernel<2, true, 0u,", "env_step_kernel<2, 12u", "obs_compact_kernel"]          # four-joint legs: physics, then the MDP launch
 STEP_KERNELS = {
     "go2": ["quad_sim_kernel<4, true, 12u,"],
     "go2_wtw": _QUAD_FUSED, "go2_ee": _QUAD_FUSED, "tron1_pf_ee": _BIPED,
     # not BASELINE configs
     "go2_ts": _QUAD_FUSED, "go2_cts": _QUAD_FUSED, "go2_dreamwaq": _QUAD_FUSED, "tron1_pf": _BIPED,
     "go2_cat": ["quad_sim_kernel<4, true, 0u,", "env_step_kernel<4, 12u", "obs_compact_kernel"],
-    "tron1_sf": _BIPED,
+    "tron1_sf": _BIPED_2,
 }
 
 
