@@ -2,7 +2,12 @@
 
 The library is 20 translation units: lg_host.hip (C ABI), lg_rollout.hip and lg_inst.hip compiled once per kernel-instantiation group
 (-DLG_GROUP=0..17).  They are compiled in parallel into csrc/obj/ and linked; an object is reused while the sources it depends on and
-the flags are unchanged (content hash), so an edit of lg_quad.h rebuilds the ten component-per-lane groups only."""
+the flags are unchanged (content hash), so an edit of lg_quad.h rebuilds the ten component-per-lane groups only.
+
+The kernel groups go through the compiler's ASSEMBLY: hipcc -S (device) -> dpp_hazard_pass.fix (the s_nop each DPP read needs, no
+more: the inline-asm products of lg_quad.h otherwise pay a two-slot nop per block) -> assembler -> lld -> offload bundle -> host
+compile with that bundle.  These are the steps `hipcc -c` runs itself (hipcc -###), with the pass in the middle; the rewritten text is
+re-checked and a finding fails the build.  LG_NO_DPP_PASS=1 compiles the groups with plain `hipcc -c` (every marked nop stays)."""
 import hashlib
 import json
 import os
@@ -16,6 +21,8 @@ INC = os.path.join(HERE, "..", "include")
 # LG_BUILD_OUT: a developer variant (other flags, e.g. -DLG_DBG_STAMPS) next to the product library; load it with LG_LIB=<path>
 OUT = os.environ.get("LG_BUILD_OUT") or os.path.join(CSRC, "liblgsim.so")
 OBJ = os.path.join(CSRC, "obj" if "LG_BUILD_OUT" not in os.environ else "obj_" + os.path.splitext(os.path.basename(OUT))[0])
+LLVM_BIN = os.environ.get("LG_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
+DPP_PASS = os.environ.get("LG_NO_DPP_PASS", "0") != "1"
 N_GROUPS = 18
 QUAD_GROUPS = list(range(0, 9)) + [17]          # lg_inst.hip: groups that include lg_quad.h
 COMMON = ["lg_shared.h", "lg_math.h", os.path.join(INC, "lgsim.h")]
@@ -31,7 +38,7 @@ def units():
     """(object name, source, extra defines, dependencies) of every translation unit."""
     u = [("lg_host", "lg_host.hip", [], COMMON), ("lg_rollout", "lg_rollout.hip", [], [os.path.join(INC, "lgrollout.h")])]
     for g in range(N_GROUPS):
-        deps = COMMON + ["lg_kernel.h"] + (["lg_quad.h"] if g in QUAD_GROUPS else [])
+        deps = COMMON + ["lg_kernel.h"] + (["lg_quad.h"] if g in QUAD_GROUPS else []) + ([os.path.join(HERE, "dpp_hazard_pass.py")] if DPP_PASS else [])
         u.append((f"lg_inst_{g}", "lg_inst.hip", [f"-DLG_GROUP={g}"], deps))
     return u
 
@@ -45,6 +52,8 @@ def source_hash():
     h = hashlib.sha256()
     files = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith((".hip", ".h")))
     files += sorted(os.path.join(INC, f) for f in os.listdir(INC) if f.endswith(".h"))
+    if DPP_PASS:
+        files.append(os.path.join(HERE, "dpp_hazard_pass.py"))     # it rewrites the kernels' instruction stream
     for f in files:
         h.update(os.path.basename(f).encode())
         with open(f, "rb") as fh:
@@ -53,7 +62,7 @@ def source_hash():
 
 
 def _unit_key(src, defs, deps, flags):
-    h = hashlib.sha256(" ".join(flags + defs).encode())
+    h = hashlib.sha256(" ".join(flags + defs + (["dpp-pass"] if DPP_PASS else [])).encode())
     for f in [src] + list(deps):
         with open(_path(f), "rb") as fh:
             h.update(fh.read())
@@ -80,13 +89,15 @@ def _compile_all(hipcc, flags, force, jobs, verbose):
         objs.append(obj)
         old = open(keyf).read() if os.path.exists(keyf) and os.path.exists(obj) else ""
         if force or old != key:
-            todo.append((name, [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", *flags, *defs, "-c", _path(src), "-o", obj], keyf, key))
+            base = [hipcc, "--offload-arch=gfx950", "-O3", "-fPIC", "-std=c++17", *flags, *defs]
+            cmd = [*base, "-c", _path(src), "-o", obj]
+            todo.append((name, ("pass", base, _path(src), obj) if DPP_PASS and name.startswith("lg_inst_") else cmd, keyf, key))
 
     def run(t):
         name, cmd, keyf, key = t
         if os.path.exists(keyf):
             os.remove(keyf)
-        r = subprocess.run(cmd, capture_output=True, text=True)
+        r = _compile_through_pass(name, *cmd[1:]) if cmd[0] == "pass" else subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode == 0:
             with open(keyf, "w") as f:
                 f.write(key)
@@ -99,6 +110,60 @@ def _compile_all(hipcc, flags, force, jobs, verbose):
             if r.returncode != 0 and not err:
                 err = f"[{name}] " + r.stderr
     return objs, err
+
+
+class _Result:
+    def __init__(self, returncode, stderr):
+        self.returncode, self.stderr = returncode, stderr
+
+
+def _compile_through_pass(name, base, src, obj):
+    """hipcc -S (device) -> dpp_hazard_pass -> assembler -> lld -> offload bundle -> host compile embedding the bundle (module doc)."""
+    sys.path.insert(0, HERE)
+    import dpp_hazard_pass
+    stem = os.path.join(OBJ, name)
+    steps = [[*base, "--cuda-device-only", "-S", "-o", stem + ".s", src]]
+    r = subprocess.run(steps[0], capture_output=True, text=True)
+    if r.returncode != 0:
+        return r
+    with open(stem + ".s") as f:
+        text, stats = dpp_hazard_pass.fix(f.read())
+    left = dpp_hazard_pass.check(text)
+    if left:
+        return _Result(1, f"dpp_hazard_pass: {len(left)} unresolved DPP hazard(s), first: {left[0]}")
+    with open(stem + ".fix.s", "w") as f:
+        f.write(text)
+    with open(stem + ".pass.json", "w") as f:
+        json.dump(stats, f)
+    for cmd in ([os.path.join(LLVM_BIN, "clang"), "-x", "assembler", "-target", "amdgcn-amd-amdhsa", "-mcpu=gfx950", "-c", stem + ".fix.s", "-o", stem + ".dev.o"],
+                [os.path.join(LLVM_BIN, "lld"), "-flavor", "gnu", "-m", "elf64_amdgpu", "--no-undefined", "-shared", stem + ".dev.o", "-o", stem + ".co"],
+                [os.path.join(LLVM_BIN, "clang-offload-bundler"), "-type=o", "-bundle-align=4096",
+                 "-targets=host-x86_64-unknown-linux-gnu,hipv4-amdgcn-amd-amdhsa--gfx950", "-input=/dev/null", "-input=" + stem + ".co", "-output=" + stem + ".hipfb"],
+                [*base, "--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", stem + ".hipfb", "-c", src, "-o", obj]):
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0:
+            return _Result(r.returncode, " ".join(cmd[:3]) + " ...: " + r.stderr)
+    for ext in (".s", ".dev.o", ".co", ".hipfb"):      # .fix.s stays next to the object: it is what tools/isa_loop_stats.py reads
+        try:
+            os.remove(stem + ext)
+        except OSError:
+            pass
+    return _Result(0, "")
+
+
+def pass_stats():
+    """Sum of the hazard pass's counters over the kernel groups of the last build (None when it did not run)."""
+    tot = None
+    for g in range(N_GROUPS):
+        try:
+            with open(os.path.join(OBJ, f"lg_inst_{g}.pass.json")) as f:
+                st = json.load(f)
+        except (OSError, ValueError):
+            continue
+        tot = tot or {}
+        for k, v in st.items():
+            tot[k] = tot.get(k, 0) + v
+    return tot
 
 
 def build(force=False, verbose=False, allow_fallback=None, jobs=None):
@@ -134,7 +199,8 @@ def build(force=False, verbose=False, allow_fallback=None, jobs=None):
                 json.dump({"flags": ["--offload-arch=gfx950", "-O3", *flags], "fallback": fell,
                            "primary_flags": EXTRA_FLAGS, "primary_error": first_err[-1500:] if fell else "",
                            "hipcc": next((l for l in ver if "HIP version" in l), ver[0] if ver else ""),
-                           "source_hash": source_hash(), "translation_units": len(objs)}, f, indent=1)
+                           "source_hash": source_hash(), "translation_units": len(objs),
+                           "dpp_hazard_pass": pass_stats() if DPP_PASS else None}, f, indent=1)
             done = True
             break
         first_err = first_err or err

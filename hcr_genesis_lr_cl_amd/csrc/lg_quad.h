@@ -76,6 +76,7 @@ LG_DEV uint4 kernarg_lane(int n16) {
 }
 
 struct QM { float c0, c1, c2; };       // 3x3: this lane's row
+typedef float f2 __attribute__((ext_vector_type(2)));   // <2 x float>: v_pk_fma_f32 / v_pk_mul_f32 / v_pk_add_f32 on an aligned register pair
 struct QV6 { float a, l; };            // spatial vector [angular; linear], one component of each
 struct QI6 { QM A, B, Bt, C; };        // [A B; B^T C]: rows c of (A|B) and of (B^T|C)
 
@@ -98,30 +99,35 @@ LG_DEV float cross(float a, float b) { return rot1(a * rot1(b) - rot1(a) * b); }
 // write hazard of every source in it (2 wait states; the hazard recogniser does not look inside inline asm); inside a group
 // the DPP sources are never written.  LG_NO_DPP_ASM selects the plain C++ forms (same arithmetic, same order).
 #ifndef LG_NO_DPP_ASM
+// The marker lets hcr_genesis_lr_cl_amd/dpp_hazard_pass.py (run by build.py on the compiler's assembly) drop the nop wherever the
+// sources of the block turn out to be old enough in the instruction stream the compiler actually produced, and keep or shorten it
+// where they are not -- an `s_nop 1` is two issue slots of a lone wave (~8.6 cycles), and most blocks do not need it.  Compiled without
+// the pass (tools, plain hipcc) the nops simply stay.
+#define LG_SNOP "s_nop 1 ; lg-dpp-hazard\n\t"
 #define LG_QP0 "quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf"
 #define LG_QP1 "quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf"
 #define LG_QP2 "quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
 // r = m0 * v[0] + m1 * v[1] + m2 * v[2]   (v: component layout, broadcast inside the quad)
 LG_DEV float dpp_mac3(float m0, float m1, float m2, float v) {
     float r;
-    asm("s_nop 1\n\tv_mul_f32_dpp %0, %4, %1 " LG_QP0 "\n\tv_fmac_f32_dpp %0, %4, %2 " LG_QP1 "\n\tv_fmac_f32_dpp %0, %4, %3 " LG_QP2
+    asm(LG_SNOP "v_mul_f32_dpp %0, %4, %1 " LG_QP0 "\n\tv_fmac_f32_dpp %0, %4, %2 " LG_QP1 "\n\tv_fmac_f32_dpp %0, %4, %3 " LG_QP2
         : "=&v"(r) : "v"(m0), "v"(m1), "v"(m2), "v"(v));
     return r;
 }
 // r += m0 * v[0] + m1 * v[1] + m2 * v[2]
 LG_DEV float dpp_mac3_acc(float r, float m0, float m1, float m2, float v) {
-    asm("s_nop 1\n\tv_fmac_f32_dpp %0, %4, %1 " LG_QP0 "\n\tv_fmac_f32_dpp %0, %4, %2 " LG_QP1 "\n\tv_fmac_f32_dpp %0, %4, %3 " LG_QP2
+    asm(LG_SNOP "v_fmac_f32_dpp %0, %4, %1 " LG_QP0 "\n\tv_fmac_f32_dpp %0, %4, %2 " LG_QP1 "\n\tv_fmac_f32_dpp %0, %4, %3 " LG_QP2
         : "+v"(r) : "v"(m0), "v"(m1), "v"(m2), "v"(v));
     return r;
 }
 // r = m0 * a[K] + m1 * b[K] + m2 * c[K]   (one fixed lane K of three different vectors: rows of a transposed operand)
 template <int K> LG_DEV float dpp_mac3t(float m0, float m1, float m2, float a, float b, float c) {
     float r;
-    if (K == 0) asm("s_nop 1\n\tv_mul_f32_dpp %0, %4, %1 " LG_QP0 "\n\tv_fmac_f32_dpp %0, %5, %2 " LG_QP0 "\n\tv_fmac_f32_dpp %0, %6, %3 " LG_QP0
+    if (K == 0) asm(LG_SNOP "v_mul_f32_dpp %0, %4, %1 " LG_QP0 "\n\tv_fmac_f32_dpp %0, %5, %2 " LG_QP0 "\n\tv_fmac_f32_dpp %0, %6, %3 " LG_QP0
                     : "=&v"(r) : "v"(m0), "v"(m1), "v"(m2), "v"(a), "v"(b), "v"(c));
-    else if (K == 1) asm("s_nop 1\n\tv_mul_f32_dpp %0, %4, %1 " LG_QP1 "\n\tv_fmac_f32_dpp %0, %5, %2 " LG_QP1 "\n\tv_fmac_f32_dpp %0, %6, %3 " LG_QP1
+    else if (K == 1) asm(LG_SNOP "v_mul_f32_dpp %0, %4, %1 " LG_QP1 "\n\tv_fmac_f32_dpp %0, %5, %2 " LG_QP1 "\n\tv_fmac_f32_dpp %0, %6, %3 " LG_QP1
                          : "=&v"(r) : "v"(m0), "v"(m1), "v"(m2), "v"(a), "v"(b), "v"(c));
-    else asm("s_nop 1\n\tv_mul_f32_dpp %0, %4, %1 " LG_QP2 "\n\tv_fmac_f32_dpp %0, %5, %2 " LG_QP2 "\n\tv_fmac_f32_dpp %0, %6, %3 " LG_QP2
+    else asm(LG_SNOP "v_mul_f32_dpp %0, %4, %1 " LG_QP2 "\n\tv_fmac_f32_dpp %0, %5, %2 " LG_QP2 "\n\tv_fmac_f32_dpp %0, %6, %3 " LG_QP2
              : "=&v"(r) : "v"(m0), "v"(m1), "v"(m2), "v"(a), "v"(b), "v"(c));
     return r;
 }
@@ -131,7 +137,7 @@ LG_DEV float mulv(const QM &m, float v) { return dpp_mac3(m.c0, m.c1, m.c2, v); 
 // of them per sub-step).  The three accumulators are interleaved, so no instruction waits on the one before it.
 LG_DEV QM mulmm(const QM &a, const QM &b) {     // a b: r.ck = a.c0 b.ck[0] + a.c1 b.ck[1] + a.c2 b.ck[2]
     QM r;
-    asm("s_nop 1\n\t"
+    asm(LG_SNOP
         "v_mul_f32_dpp %0, %6, %3 " LG_QP0 "\n\tv_mul_f32_dpp %1, %7, %3 " LG_QP0 "\n\tv_mul_f32_dpp %2, %8, %3 " LG_QP0 "\n\t"
         "v_fmac_f32_dpp %0, %6, %4 " LG_QP1 "\n\tv_fmac_f32_dpp %1, %7, %4 " LG_QP1 "\n\tv_fmac_f32_dpp %2, %8, %4 " LG_QP1 "\n\t"
         "v_fmac_f32_dpp %0, %6, %5 " LG_QP2 "\n\tv_fmac_f32_dpp %1, %7, %5 " LG_QP2 "\n\tv_fmac_f32_dpp %2, %8, %5 " LG_QP2
@@ -140,7 +146,7 @@ LG_DEV QM mulmm(const QM &a, const QM &b) {     // a b: r.ck = a.c0 b.ck[0] + a.
 }
 LG_DEV QM mulmmt(const QM &a, const QM &b) {    // a b^T: r.ck = a.c0 b.c0[k] + a.c1 b.c1[k] + a.c2 b.c2[k]
     QM r;
-    asm("s_nop 1\n\t"
+    asm(LG_SNOP
         "v_mul_f32_dpp %0, %6, %3 " LG_QP0 "\n\tv_mul_f32_dpp %1, %6, %3 " LG_QP1 "\n\tv_mul_f32_dpp %2, %6, %3 " LG_QP2 "\n\t"
         "v_fmac_f32_dpp %0, %7, %4 " LG_QP0 "\n\tv_fmac_f32_dpp %1, %7, %4 " LG_QP1 "\n\tv_fmac_f32_dpp %2, %7, %4 " LG_QP2 "\n\t"
         "v_fmac_f32_dpp %0, %8, %5 " LG_QP0 "\n\tv_fmac_f32_dpp %1, %8, %5 " LG_QP1 "\n\tv_fmac_f32_dpp %2, %8, %5 " LG_QP2
@@ -149,7 +155,7 @@ LG_DEV QM mulmmt(const QM &a, const QM &b) {    // a b^T: r.ck = a.c0 b.c0[k] + 
 }
 // two independent products a b and c d in one block (inv6: B C^-1 with C^-1 B^T, S^-1 T with Y S^-1)
 LG_DEV void mulmm2(const QM &a, const QM &b, const QM &c, const QM &d, QM &r, QM &q) {
-    asm("s_nop 1\n\t"
+    asm(LG_SNOP
         "v_mul_f32_dpp %0, %9, %6 " LG_QP0 "\n\tv_mul_f32_dpp %1, %10, %6 " LG_QP0 "\n\tv_mul_f32_dpp %2, %11, %6 " LG_QP0 "\n\t"
         "v_mul_f32_dpp %3, %15, %12 " LG_QP0 "\n\tv_mul_f32_dpp %4, %16, %12 " LG_QP0 "\n\tv_mul_f32_dpp %5, %17, %12 " LG_QP0 "\n\t"
         "v_fmac_f32_dpp %0, %9, %7 " LG_QP1 "\n\tv_fmac_f32_dpp %1, %10, %7 " LG_QP1 "\n\tv_fmac_f32_dpp %2, %11, %7 " LG_QP1 "\n\t"
@@ -206,7 +212,6 @@ LG_DEV QM inv_sym(const Lane &L, const QM &m) {
 // packed FP32 (<2 x float>: v_pk_add_f32 / v_pk_mul_f32 / v_pk_fma_f32).  Measured slower -- the pairs cost v_mov_b32 to form and 64-bit
 // tuples to allocate -- and the iterative-ilp build of it crashes clang's register allocator.
 #ifdef LG_PK_F32
-typedef float f2 __attribute__((ext_vector_type(2)));
 LG_DEV QV6 operator+(const QV6 &a, const QV6 &b) { const f2 r = f2{a.a, a.l} + f2{b.a, b.l}; QV6 o = {r.x, r.y}; return o; }
 LG_DEV QV6 operator-(const QV6 &a, const QV6 &b) { const f2 r = f2{a.a, a.l} - f2{b.a, b.l}; QV6 o = {r.x, r.y}; return o; }
 LG_DEV QV6 operator*(const QV6 &a, float s) { const f2 r = f2{a.a, a.l} * f2{s, s}; QV6 o = {r.x, r.y}; return o; }
@@ -219,7 +224,7 @@ LG_DEV float dot6(const QV6 &a, const QV6 &b) { return sum3(a.a * b.a + a.l * b.
 LG_DEV QV6 muli6(const QI6 &I, const QV6 &v) {
 #ifndef LG_NO_DPP_ASM
     QV6 r;      // rows of (A | B) and of (B^T | C) against [v.a; v.l]: twelve multiply-adds, two interleaved accumulators, one s_nop
-    asm("s_nop 1\n\t"
+    asm(LG_SNOP
         "v_mul_f32_dpp %0, %14, %2 " LG_QP0 "\n\tv_mul_f32_dpp %1, %14, %8 " LG_QP0 "\n\t"
         "v_fmac_f32_dpp %0, %14, %3 " LG_QP1 "\n\tv_fmac_f32_dpp %1, %14, %9 " LG_QP1 "\n\t"
         "v_fmac_f32_dpp %0, %14, %4 " LG_QP2 "\n\tv_fmac_f32_dpp %1, %14, %10 " LG_QP2 "\n\t"
@@ -265,7 +270,7 @@ LG_DEV QI6 rank1_down(const QI6 &I, const QV6 &U, float dinv) {
     // of six v_mov_b32_dpp + twelve v_fma
     const float na = -(U.a * dinv), nl = -(U.l * dinv);
     QI6 r = I;
-    asm("s_nop 1\n\t"
+    asm(LG_SNOP
         "v_fmac_f32_dpp %0, %12, %14 " LG_QP0 "\n\tv_fmac_f32_dpp %1, %12, %14 " LG_QP1 "\n\tv_fmac_f32_dpp %2, %12, %14 " LG_QP2 "\n\t"
         "v_fmac_f32_dpp %3, %13, %14 " LG_QP0 "\n\tv_fmac_f32_dpp %4, %13, %14 " LG_QP1 "\n\tv_fmac_f32_dpp %5, %13, %14 " LG_QP2 "\n\t"
         "v_fmac_f32_dpp %6, %12, %15 " LG_QP0 "\n\tv_fmac_f32_dpp %7, %12, %15 " LG_QP1 "\n\tv_fmac_f32_dpp %8, %12, %15 " LG_QP2 "\n\t"
@@ -888,10 +893,45 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
                 m[0] += cy * fz - cz * fy; m[1] += cz * fx - cx * fz; m[2] += cx * fy - cy * fx;
                 f[0] += fx; f[1] += fy; f[2] += fz;
             };
-            auto reduce = [&](const float (&m)[3], const float (&f)[3], QV6 &acc) {
-                acc.a += L.sel(sum4(m[0]), sum4(m[1]), sum4(m[2]));
-                acc.l += L.sel(sum4(f[0]), sum4(f[1]), sum4(f[2]));
+            // TWO spheres per lane at once, one in each half of a packed-f32 pair (v_pk_fma_f32 & co.): a lone wave issues a packed
+            // instruction at the price of a plain one (tools/ubench/pk_issue.hip: 5.1 vs 5.3 cycles), and this law is plain per-lane
+            // arithmetic -- no DPP operand anywhere -- so the pair costs about what one sphere does.  Same statements as `force`, half by half.
+            struct BodyS2 { f2 x0, x1, x2, y0, y1, y2, Px, Py, wx, wy, wz, vx, vy, vz; };
+            auto pair_bodies = [&](const BodyS a, const BodyS b) {
+                BodyS2 g = {f2{a.x0, b.x0}, f2{a.x1, b.x1}, f2{a.x2, b.x2}, f2{a.y0, b.y0}, f2{a.y1, b.y1}, f2{a.y2, b.y2}, f2{a.Px, b.Px}, f2{a.Py, b.Py},
+                            f2{a.wx, b.wx}, f2{a.wy, b.wy}, f2{a.wz, b.wz}, f2{a.vx, b.vx}, f2{a.vy, b.vy}, f2{a.vz, b.vz}};
+                return g;
             };
+            struct Acc2 { f2 mx, my, mz, fx, fy, fz; };
+            auto force2 = [&](int k0, int k1, const Hit t0, const Hit t1, const BodyS2 &g, Acc2 &acc) {
+                const f2 sxx = {sx[k0], sx[k1]}, syy = {sy[k0], sy[k1]}, szz = {sz[k0], sz[k1]}, rad = {srad[k0], srad[k1]};
+                f2 rx = {t0.rx, t1.rx}, ry = {t0.ry, t1.ry};
+                const f2 rz = {t0.rz, t1.rz}, nx = {t0.nx, t1.nx}, ny = {t0.ny, t1.ny}, nz = {t0.nz, t1.nz}, depth = {t0.depth, t1.depth};
+                if (!hfmode) {
+                    rx = g.Px + g.x0 * sxx + g.x1 * syy + g.x2 * szz;
+                    ry = g.Py + g.y0 * sxx + g.y1 * syy + g.y2 * szz;
+                }
+                const f2 vx = g.vx + (g.wy * rz - g.wz * ry), vy = g.vy + (g.wz * rx - g.wx * rz), vz = g.vz + (g.wx * ry - g.wy * rx);
+                const f2 vn = vx * nx + vy * ny + vz * nz;
+                const f2 den = {sden[k0], sden[k1]}, idw = {sidw[k0], sidw[k1]};
+                const f2 fn = (kc * depth - kappa * vn) * den;
+                const f2 tx = vx - nx * vn, ty = vy - ny * vn, tz = vz - nz * vn;
+                const f2 s2 = tx * tx + ty * ty + tz * tz;
+                const f2 mf = mu * fn;
+                const bool a0 = t0.on && fn.x > 0.f, a1 = t1.on && fn.y > 0.f;
+                // no force: normal and tangential magnitudes both zero (the products below then are)
+                const f2 fa = {a0 ? fn.x : 0.f, a1 ? fn.y : 0.f};
+                const f2 gg = {a0 && s2.x > 1e-18f ? fminf(idw.x, mf.x * rsqrtf(s2.x)) : 0.f, a1 && s2.y > 1e-18f ? fminf(idw.y, mf.y * rsqrtf(s2.y)) : 0.f};
+                const f2 fx = nx * fa - tx * gg, fy = ny * fa - ty * gg, fz = nz * fa - tz * gg;
+                const f2 cx = rx - nx * rad, cy = ry - ny * rad, cz = rz - nz * rad;
+                acc.mx += cy * fz - cz * fy; acc.my += cz * fx - cx * fz; acc.mz += cx * fy - cy * fx;
+                acc.fx += fx; acc.fy += fy; acc.fz += fz;
+            };
+            auto reduce6 = [&](float mx, float my, float mz, float fx, float fy, float fz, QV6 &acc) {
+                acc.a += L.sel(sum4(mx), sum4(my), sum4(mz));
+                acc.l += L.sel(sum4(fx), sum4(fy), sum4(fz));
+            };
+            auto reduce = [&](const float (&m)[3], const float (&f)[3], QV6 &acc) { reduce6(m[0], m[1], m[2], f[0], f[1], f[2], acc); };
             // one slot of a body; the force branch runs only if some sphere of the slot touches somewhere in the wave
             auto slot = [&](int k, const Hit &t, const QM &R, float P, const QV6 &V, QV6 &acc) {
                 if (__builtin_amdgcn_ballot_w64(t.on) != 0ull) {
@@ -913,8 +953,24 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
                 terrain<HFC>(TR, px + bc<0>(rf), py + bc<1>(rf), ft_h, ft_nx, ft_ny, ft_nz);
             }
             slot(4, tb, Rb, 0.f, V0, extb);
+#ifndef LG_NO_PK_SPHERES
+            {   // hip and thigh slots: as a packed pair when both are live somewhere in the wave, on their own otherwise
+                const bool on0 = __builtin_amdgcn_ballot_w64(ta.on) != 0ull, on1 = __builtin_amdgcn_ballot_w64(tc.on) != 0ull;
+                if (on0 && on1) {
+                    const f2 z2 = {0.f, 0.f};
+                    Acc2 a2 = {z2, z2, z2, z2, z2, z2};
+                    force2(0, 1, ta, tc, pair_bodies(gather(K[0].R, K[0].P, K[0].V), gather(K[1].R, K[1].P, K[1].V)), a2);
+                    reduce6(a2.mx.x, a2.my.x, a2.mz.x, a2.fx.x, a2.fy.x, a2.fz.x, ext[0]);
+                    reduce6(a2.mx.y, a2.my.y, a2.mz.y, a2.fx.y, a2.fy.y, a2.fz.y, ext[1]);
+                } else {
+                    slot(0, ta, K[0].R, K[0].P, K[0].V, ext[0]);
+                    slot(1, tc, K[1].R, K[1].P, K[1].V, ext[1]);
+                }
+            }
+#else
             slot(0, ta, K[0].R, K[0].P, K[0].V, ext[0]);
             slot(1, tc, K[1].R, K[1].P, K[1].V, ext[1]);
+#endif
             if constexpr (JPL == 4) {
                 slot(2, td, K[2].R, K[2].P, K[2].V, ext[2]);
                 // the sole corners: penetration / approach velocity relative to the sole centre's while that one is in the ground
@@ -944,11 +1000,18 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             } else {   // the calf's two slots share one gather and one reduction
                 const Hit t2 = td, t3 = te;
                 if (__builtin_amdgcn_ballot_w64(t2.on || t3.on) != 0ull) {
-                    float m[3] = {0.f, 0.f, 0.f}, f[3] = {0.f, 0.f, 0.f};
                     const BodyS g = gather(K[2].R, K[2].P, K[2].V);
+#ifndef LG_NO_PK_SPHERES
+                    const f2 z2 = {0.f, 0.f};
+                    Acc2 a2 = {z2, z2, z2, z2, z2, z2};
+                    force2(2, 3, t2, t3, pair_bodies(g, g), a2);
+                    reduce6(a2.mx.x + a2.mx.y, a2.my.x + a2.my.y, a2.mz.x + a2.mz.y, a2.fx.x + a2.fx.y, a2.fy.x + a2.fy.y, a2.fz.x + a2.fz.y, ext[2]);
+#else
+                    float m[3] = {0.f, 0.f, 0.f}, f[3] = {0.f, 0.f, 0.f};
                     force(2, t2, g, m, f);
                     force(3, t3, g, m, f);
                     reduce(m, f, ext[2]);
+#endif
                 }
             }
         }
