@@ -112,6 +112,9 @@ def _compile_all(hipcc, flags, force, jobs, verbose):
     return objs, err
 
 
+_PASS_FALLBACK = False      # set by build(allow_fallback=True)
+
+
 class _Result:
     def __init__(self, returncode, stderr):
         self.returncode, self.stderr = returncode, stderr
@@ -142,7 +145,14 @@ def _compile_through_pass(name, base, src, obj):
                 [*base, "--cuda-host-only", "-Xclang", "-fcuda-include-gpubinary", "-Xclang", stem + ".hipfb", "-c", src, "-o", obj]):
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
-            return _Result(r.returncode, " ".join(cmd[:3]) + " ...: " + r.stderr)
+            err = " ".join(cmd[:3]) + " ...: " + r.stderr
+            if not _PASS_FALLBACK:
+                return _Result(r.returncode, err)
+            # the driver hook may not fail on tooling around the compiler: plain `hipcc -c` (every marked nop stays), on record
+            print(f"build.py: {name}: assembly pipeline failed, compiled with plain hipcc -c instead: {err[-300:]}", file=sys.stderr)
+            with open(stem + ".pass.json", "w") as f:
+                json.dump({"pipeline_failed": 1}, f)
+            return subprocess.run([*base, "-c", src, "-o", obj], capture_output=True, text=True)
     for ext in (".s", ".dev.o", ".co", ".hipfb"):      # .fix.s stays next to the object: it is what tools/isa_loop_stats.py reads
         try:
             os.remove(stem + ext)
@@ -179,6 +189,8 @@ def build(force=False, verbose=False, allow_fallback=None, jobs=None):
     hipcc = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
     if allow_fallback is None:
         allow_fallback = os.environ.get("LG_ALLOW_FLAG_FALLBACK", "0") == "1"
+    global _PASS_FALLBACK
+    _PASS_FALLBACK = bool(allow_fallback)
     if jobs is None:
         jobs = int(os.environ.get("LG_BUILD_JOBS", str(min(8, os.cpu_count() or 1))))
     attempts = [EXTRA_FLAGS]

@@ -92,7 +92,6 @@ struct Lane {
 // with only the is0 lanes in EXEC, so the read from lane 3 returns 0 (bound_ctrl).  Cross-lane values are therefore always formed in
 // their own statements (or as arguments of L.sel / L.sel4, which are evaluated before the call) and selected afterwards.
 LG_DEV float dot3(float a, float b) { return sum3(a * b); }
-LG_DEV float cross(float a, float b) { return rot1(a * rot1(b) - rot1(a) * b); }
 // The quad broadcast of an operand rides ON the multiply-add (v_mul_f32_dpp / v_fmac_f32_dpp with quad_perm:[k,k,k,k] on src0).
 // LLVM folds a DPP mov into v_mul / v_add but not into v_fmac, leaving one v_mov_b32_dpp per multiply-add (~20 % of the physics
 // loop's issue slots); these helpers spell the sequences out.  One `s_nop 1` in front of a group covers the DPP read-after-VALU-
@@ -104,6 +103,8 @@ LG_DEV float cross(float a, float b) { return rot1(a * rot1(b) - rot1(a) * b); }
 // where they are not -- an `s_nop 1` is two issue slots of a lone wave (~8.6 cycles), and most blocks do not need it.  Compiled without
 // the pass (tools, plain hipcc) the nops simply stay.
 #define LG_SNOP "s_nop 1 ; lg-dpp-hazard\n\t"
+#define LG_QPR1 "quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf"
+#define LG_QPR2 "quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf"
 #define LG_QP0 "quad_perm:[0,0,0,0] row_mask:0xf bank_mask:0xf"
 #define LG_QP1 "quad_perm:[1,1,1,1] row_mask:0xf bank_mask:0xf"
 #define LG_QP2 "quad_perm:[2,2,2,2] row_mask:0xf bank_mask:0xf"
@@ -183,6 +184,28 @@ LG_DEV QM mulmmt(const QM &a, const QM &b) {    // a b^T
 }
 LG_DEV void mulmm2(const QM &a, const QM &b, const QM &c, const QM &d, QM &r, QM &q) { r = mulmm(a, b); q = mulmm(c, d); }
 #endif
+// Cross products.  (a x b)_c = a_{c+1} b_{c+2} - a_{c+2} b_{c+1} = rot1(a) rot2(b) - rot2(a) rot1(b): with ONE operand given by its two quad
+// rotations (QR, two v_mov_b32_dpp, shared by every product that operand enters) the other rides through DPP on a multiply and a
+// multiply-add -- two instructions per product, and no rotation of the RESULT: the older form rot1(a rot1(b) - rot1(a) b) was three
+// plus a DPP read of the value just computed, i.e. two wait states in front of whatever consumed it (~50 products per sub-step).
+struct QR { float r1, r2; };                                               // rot1(v), rot2(v)
+LG_DEV QR rots(float v) { QR r = {rot1(v), rot2(v)}; return r; }
+#ifndef LG_NO_DPP_ASM
+LG_DEV float cross(float a, const QR &b) {      // a x b, b by its rotations
+    float r;
+    asm(LG_SNOP "v_mul_f32_dpp %0, %1, %2 " LG_QPR1 "\n\tv_fmac_f32_dpp %0, %1, -%3 " LG_QPR2 : "=&v"(r) : "v"(a), "v"(b.r2), "v"(b.r1));
+    return r;
+}
+LG_DEV float cross(const QR &a, float b) {      // a x b, a by its rotations
+    float r;
+    asm(LG_SNOP "v_mul_f32_dpp %0, %1, %2 " LG_QPR2 "\n\tv_fmac_f32_dpp %0, %1, -%3 " LG_QPR1 : "=&v"(r) : "v"(b), "v"(a.r1), "v"(a.r2));
+    return r;
+}
+#else
+LG_DEV float cross(float a, const QR &b) { return rot1(a) * b.r2 - rot2(a) * b.r1; }
+LG_DEV float cross(const QR &a, float b) { return a.r1 * rot2(b) - a.r2 * rot1(b); }
+#endif
+LG_DEV float cross(float a, float b) { return cross(a, rots(b)); }
 LG_DEV float multv(const Lane &L, const QM &m, float v) {   // m^T v
     return L.sel(sum3(m.c0 * v), sum3(m.c1 * v), sum3(m.c2 * v));
 }
@@ -351,7 +374,7 @@ template <int AK> LG_DEV void joint_rot(const Lane &L, const QM &Rp, float ax, f
 }
 
 struct QJoint { QV6 S, U, c; float dinv, u; };
-struct QKin { QM R; float P; QV6 V; };
+struct QKin { QM R; float P; QV6 V; QR Wr; };   // Wr: the rotations of V.a (cross products)
 struct Terr { int rows, cols; float border, ihs, vscale; const int16_t *hf; };
 
 // terrain height and unit normal at world (x, y) -- scalar form, any lane
@@ -819,12 +842,14 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
                 else if (j == 2) joint_rot<QUAD_AXES[2]>(L, Rp, Lax[j], cq, sq, K[j].R, s);
                 else joint_rot<QUAD_AXES[3]>(L, Rp, Lax[j], cq, sq, K[j].R, s);
                 J[j].S.a = s;
-                J[j].S.l = cross(K[j].P, s);
+                const QR sr = rots(s);           // the joint axis enters three products, the body's angular velocity six (here and in pass 2)
+                J[j].S.l = cross(K[j].P, sr);
                 const float qdj = bcj(qd, j);
                 K[j].V.a = Vp.a + s * qdj;
                 K[j].V.l = Vp.l + J[j].S.l * qdj;
-                J[j].c.a = cross(K[j].V.a, s) * qdj;
-                J[j].c.l = (cross(K[j].V.a, J[j].S.l) + cross(K[j].V.l, s)) * qdj;
+                K[j].Wr = rots(K[j].V.a);
+                J[j].c.a = cross(K[j].V.a, sr) * qdj;
+                J[j].c.l = (cross(K[j].Wr, J[j].S.l) + cross(K[j].V.l, sr)) * qdj;
                 Rp = K[j].R; Pp = K[j].P; Vp = K[j].V;
             }
         }
@@ -1032,13 +1057,14 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             const float m = Lm[j];
             const float cw = K[j].P + mulv(K[j].R, Lcom[j]);
             const QM Icw = mulmmt(mulmm(K[j].R, LIc[j]), K[j].R);
-            const float vc = K[j].V.l + cross(K[j].V.a, cw);
+            const QR cwr = rots(cw);
+            const float vc = K[j].V.l + cross(K[j].Wr, cw);
             const float Pm = vc * m;
-            const float Lmo = mulv(Icw, K[j].V.a) + cross(cw, Pm);
+            const float Lmo = mulv(Icw, K[j].V.a) + cross(cwr, Pm);
             const float fg = gravc * m;
             QV6 pb;
-            pb.a = cross(K[j].V.a, Lmo) + cross(K[j].V.l, Pm) - cross(cw, fg) - ext[j].a;
-            pb.l = cross(K[j].V.a, Pm) - fg - ext[j].l;
+            pb.a = cross(K[j].Wr, Lmo) + cross(K[j].V.l, Pm) - cross(cwr, fg) - ext[j].a;
+            pb.l = cross(K[j].Wr, Pm) - fg - ext[j].l;
             const QI6 Ib = rigid(L, m, cw, Icw);
             if (j == JPL - 1) { IA = Ib; pacc = pb; }
             else { IA = IA + Ib; pacc = pacc + pb; }
@@ -1064,12 +1090,13 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             const float cw = mulv(Rb, com0);
             const QM Icw = mulmmt(mulmm(Rb, I0), Rb);
             IA0 = IA0 + rigid(L, mass0, cw, Icw);
-            const float vc = vw + cross(ww, cw);
+            const QR wr = rots(ww), cwr = rots(cw);
+            const float vc = vw + cross(wr, cw);
             const float Pm = vc * mass0;
-            const float Lmo = mulv(Icw, ww) + cross(cw, Pm);
+            const float Lmo = mulv(Icw, ww) + cross(cwr, Pm);
             const float fg = gravc * mass0;
-            p0.a += cross(ww, Lmo) + cross(vw, Pm) - cross(cw, fg);
-            p0.l += cross(ww, Pm) - fg;
+            p0.a += cross(wr, Lmo) + cross(vw, Pm) - cross(cwr, fg);
+            p0.l += cross(wr, Pm) - fg;
         }
         const QI6 Inv = inv6(L, IA0);
         QV6 a0 = muli6(Inv, QV6{-p0.a, -p0.l});
@@ -1103,7 +1130,8 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
                 const float t1 = t * rsqrtf(dot3(t, t));
                 const bool tilt = nz < 0.999999f;
                 ct1 = tilt ? t1 : ct1;
-                ct2 = tilt ? cross(cn, t1) : ct2;
+                const float t2 = cross(cn, t1);      // formed outside the conditional (cross-lane reads: see the note at the top)
+                ct2 = tilt ? t2 : ct2;
             }
         }
         float lim_e = 0.f, lim_s = 0.f, lim_T = 0.f;
@@ -1121,17 +1149,18 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             E.c1 = L.sel(bc<1>(cn), bc<1>(ct1), bc<1>(ct2));
             E.c2 = L.sel(bc<2>(cn), bc<2>(ct1), bc<2>(ct2));
             const QM ET = {cn, ct1, ct2};
+            const QR cpr = rots(cp);          // the contact point enters every product below
             if (w_refresh) {      // dt * W, contact frame, rows
                 float du[JPL], dq;
                 const float axs[3] = {cn, ct1, ct2};
                 float col[3];
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
-                    const QV6 fsp = {cross(cp, axs[k]), axs[k]};
+                    const QV6 fsp = {cross(cpr, axs[k]), axs[k]};
                     const QV6 dp = resp_up(J, fsp, 0.f, du);
                     const QV6 ab = muli6(Inv, QV6{-dp.a, -dp.l});
                     const QV6 ac = resp_down(L, J, ab, du, dq);
-                    const float ra = ac.l + cross(ac.a, cp);
+                    const float ra = ac.l + cross(ac.a, cpr);
                     col[k] = dt * mulv(E, ra);
                 }
                 Ac_keep.c0 = col[0]; Ac_keep.c1 = col[1]; Ac_keep.c2 = col[2];
@@ -1139,8 +1168,8 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             const QM Ac = Ac_keep;
             float vfree;
             {
-                const float vpt = K[JPL - 1].V.l + cross(K[JPL - 1].V.a, cp);
-                const float apt = a_calf.l + cross(a_calf.a, cp) + cross(K[JPL - 1].V.a, vpt);
+                const float vpt = K[JPL - 1].V.l + cross(K[JPL - 1].V.a, cpr);
+                const float apt = a_calf.l + cross(a_calf.a, cpr) + cross(K[JPL - 1].Wr, vpt);
                 vfree = mulv(E, vpt + apt * dt);
             }
             if (sub == 0) STAMP(18);
@@ -1184,13 +1213,13 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
                 }
                 // exact response of the whole robot to the current force set
                 const float fw = mulv(ET, fc);
-                const QV6 fsp = {cross(cp, fw), fw};
+                const QV6 fsp = {cross(cpr, fw), fw};
                 float du[JPL];
                 QV6 dp = resp_up(J, fsp, tl, du);
                 dp.a = legsum<LEGS>(dp.a); dp.l = legsum<LEGS>(dp.l);
                 da0 = muli6(Inv, QV6{-dp.a, -dp.l});
                 const QV6 ac = resp_down(L, J, da0, du, dqdd);
-                const float ra = ac.l + cross(ac.a, cp);
+                const float ra = ac.l + cross(ac.a, cpr);
                 resp_c = mulv(E, ra);
             }
             if (JPL == 4) f_link[3] += mulv(ET, fc);   // the foot is the last body's own link: on top of its sole corners
@@ -1218,7 +1247,8 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             const float d = L.is3 ? 0.f : ww * sc;              // vector part of the step quaternion; scalar part chh
             const float qw_b = bc<3>(quat);
             const float dv = sum4(d * quat);                    // d . q_v  (lane 3 contributes 0)
-            const float nq = chh * quat + (L.is3 ? -dv : qw_b * d + cross(d, quat));
+            const float dxq = cross(d, quat);                   // outside the conditional (cross-lane reads)
+            const float nq = chh * quat + (L.is3 ? -dv : qw_b * d + dxq);
             quat = nq * rsqrtf(sum4(nq * nq));
         }
         if (sub == 0) STAMP(20);

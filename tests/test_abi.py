@@ -93,3 +93,5 @@ def test_build_used_primary_flags():
     info = json.load(open(build.SIDECAR))
     assert info["fallback"] is False, info.get("primary_error", "")[-500:]
     assert all(f in info["flags"] for f in build.EXTRA_FLAGS)
+    st = info.get("dpp_hazard_pass")
+    assert st and not st.get("pipeline_failed"), f"a kernel group fell back to plain hipcc -c (no hazard pass): {st}"
