@@ -276,6 +276,9 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
         p.k.obs_layout = hot.obs_layout; p.k.o_n_height_points = hot.o_n_height_points;
         p.k.reward_mask = (unsigned)hot.reward_mask; p.k.clip_actions = hot.clip_actions;
         p.k.cat_enable = h->task.cat_enable;
+        p.k.seed_lo = (unsigned)(hot.seed & 0xFFFFFFFFull); p.k.seed_hi = (unsigned)(hot.seed >> 32);
+        p.k.gid0_lo = (unsigned)((unsigned long long)hot.env_id_offset & 0xFFFFFFFFull); p.k.gid0_hi = (unsigned)((unsigned long long)hot.env_id_offset >> 32);
+        p.k.slots_reset_dof = hot.slots.reset_dof;
         p.k.joint_axis[3] = -1;
         for (int j = 0; j < JPL; j++) {
             int code = -2;

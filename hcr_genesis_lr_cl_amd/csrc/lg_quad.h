@@ -690,6 +690,19 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
         wsv[c2++] = __int_as_float(((MPH & LG_PHASE_RESET) && k_obs_dirty) ? (int)k_obs_dirty[eL] : 0);
     }
 
+    // The every-step Philox call of the component-layout tails (observation noise / reset draws, below), issued HERE: its counter and key
+    // are kernel arguments and lane arithmetic, so its ~800 cycles run while the burst above is in flight instead of in the serial tail.
+    // (go2 on the plane only: in the larger tails the four words held across the sub-steps cost more -- go2_wtw +0.4, go2_ee +0.3, go2_ts +0.7 us --
+    // than the hidden call saves)
+    constexpr bool PHILOX_EARLY = FLAT && QTAIL && !INJ;
+    U4 rall_pre = {0u, 0u, 0u, 0u};
+    if constexpr (PHILOX_EARLY) {
+        const unsigned long long gid = (((unsigned long long)KINT(k.gid0_hi) << 32) | (unsigned)KINT(k.gid0_lo)) + (unsigned long long)(long long)e;
+        const U4 c = {(unsigned)(gid & 0xFFFFFFFFull), (unsigned)(gid >> 32), (unsigned)KINT(counter),
+                      L.is0 ? 0x80000000u + (unsigned)(2 * leg) : (L.is1 ? 0x80000000u + (unsigned)(2 * leg) + 1u
+                      : (L.is2 ? 0x40000000u + (unsigned)(KINT(k.slots_reset_dof) + d0) : 0x80000000u + 0x200u + (unsigned)leg))};
+        rall_pre = philox4x32_10(c, (unsigned)KINT(k.seed_lo), (unsigned)KINT(k.seed_hi));
+    }
     asm volatile("" ::: "memory");
     sHot[tl_] = hv0; sHot[tl_ + 64] = hv1; sHot[tl_ + 128] = hv2; sHot[tl_ + 192] = hv3;
     if (MPH != 0) {
@@ -906,6 +919,21 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
                 }
                 const float fn = (kc * t.depth - kappa * vn) * den;
                 float fx = 0.f, fy = 0.f, fz = 0.f;
+                if (!hfmode && !(JPL == 4 && sole)) {
+                    // the plane: n = e_z, so v_n = v_z, the tangential velocity is (vx, vy, 0) and the contact point sits straight below the centre
+                    // -- the general statements with the zeros and ones multiplied out (a compiler may not drop x * 0)
+                    float gg = 0.f;
+                    if (t.on && fn > 0.f) {
+                        const float s2 = vx * vx + vy * vy;
+                        gg = s2 > 1e-18f ? fminf(idw, mu * fn * rsqrtf(s2)) : 0.f;
+                        fz = fn;
+                    }
+                    fx = -vx * gg; fy = -vy * gg;
+                    const float cz = t.rz - srad[k];
+                    m[0] += t.ry * fz - cz * fy; m[1] += cz * fx - t.rx * fz; m[2] += t.rx * fy - t.ry * fx;
+                    f[0] += fx; f[1] += fy; f[2] += fz;
+                    return;
+                }
                 if (t.on && fn > 0.f) {
                     const float vnf = vx * t.nx + vy * t.ny + vz * t.nz;
                     const float tx = vx - t.nx * vnf, ty = vy - t.ny * vnf, tz = vz - t.nz * vnf;
@@ -937,8 +965,21 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
                     ry = g.Py + g.y0 * sxx + g.y1 * syy + g.y2 * szz;
                 }
                 const f2 vx = g.vx + (g.wy * rz - g.wz * ry), vy = g.vy + (g.wz * rx - g.wx * rz), vz = g.vz + (g.wx * ry - g.wy * rx);
-                const f2 vn = vx * nx + vy * ny + vz * nz;
                 const f2 den = {sden[k0], sden[k1]}, idw = {sidw[k0], sidw[k1]};
+                if (!hfmode) {   // the plane (see `force`)
+                    const f2 fn = (kc * depth - kappa * vz) * den;
+                    const f2 s2 = vx * vx + vy * vy;
+                    const f2 mf = mu * fn;
+                    const bool a0 = t0.on && fn.x > 0.f, a1 = t1.on && fn.y > 0.f;
+                    const f2 fz = {a0 ? fn.x : 0.f, a1 ? fn.y : 0.f};
+                    const f2 gg = {a0 && s2.x > 1e-18f ? fminf(idw.x, mf.x * rsqrtf(s2.x)) : 0.f, a1 && s2.y > 1e-18f ? fminf(idw.y, mf.y * rsqrtf(s2.y)) : 0.f};
+                    const f2 fx = -vx * gg, fy = -vy * gg;
+                    const f2 cz = rz - rad;
+                    acc.mx += ry * fz - cz * fy; acc.my += cz * fx - rx * fz; acc.mz += rx * fy - ry * fx;
+                    acc.fx += fx; acc.fy += fy; acc.fz += fz;
+                    return;
+                }
+                const f2 vn = vx * nx + vy * ny + vz * nz;
                 const f2 fn = (kc * depth - kappa * vn) * den;
                 const f2 tx = vx - nx * vn, ty = vy - ny * vn, tz = vz - nz * vn;
                 const f2 s2 = tx * tx + ty * ty + tz * tz;
@@ -1798,9 +1839,10 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
         // leg's `_reset_dofs` block, lane 3: the env-level reset block 0x200 + leg.  A launch ends with its slowest wave, and that is
         // always one with a reset in it: with the reset draws inside the call every wave makes anyway, a reset costs no Philox call
         // (a call is ~800 cycles of quarter-rate multiplies).
-        U4 rall = {0u, 0u, 0u, 0u};
-        if constexpr (!INJ) rall = philox(L.is0 ? 0x80000000u + (unsigned)(2 * leg) : (L.is1 ? 0x80000000u + (unsigned)(2 * leg) + 1u
-                                          : (L.is2 ? 0x40000000u + (unsigned)(h_slots_reset_dof + d0) : 0x80000000u + 0x200u + (unsigned)leg)));
+        U4 rall = rall_pre;         // go2 on the plane: evaluated under the start-of-kernel load burst (same counter, same key: see there)
+        if constexpr (!INJ && !PHILOX_EARLY)
+            rall = philox(L.is0 ? 0x80000000u + (unsigned)(2 * leg) : (L.is1 ? 0x80000000u + (unsigned)(2 * leg) + 1u
+                          : (L.is2 ? 0x40000000u + (unsigned)(h_slots_reset_dof + d0) : 0x80000000u + 0x200u + (unsigned)leg)));
         const float rux = u01(rall.x), ruy = u01(rall.y), ruz = u01(rall.z), ruw = u01(rall.w);
         const float ud_p = L.sel(bc<2>(rux), bc<2>(ruy), bc<2>(ruz));                        // element c of lane 2's block
         const float ud = INJ ? rin[h_slots_reset_dof + d0 + cj] : ud_p;

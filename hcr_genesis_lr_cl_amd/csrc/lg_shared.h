@@ -276,6 +276,9 @@ struct KParams {
     struct { int m_n_links, m_foot_link[4], obs_layout, o_n_height_points; unsigned reward_mask; float clip_actions;
              int cat_enable;      // LgTaskCfg.cat_enable: tested on every step, so not behind a memory round trip
              int joint_axis[4];   // per joint index: 0/1/2 if that joint's axis is +-e_x/e_y/e_z on every leg, else -1 (lg_quad.h joint_rot)
+             // what the every-step Philox call of the component-layout tails is keyed on: with these in the kernarg the call is issued
+             // UNDER the start-of-kernel load burst (its ~800 cycles of quarter-rate multiplies need nothing from memory)
+             unsigned seed_lo, seed_hi, gid0_lo, gid0_hi; int slots_reset_dof;
     } k;
     int obs_win;         // first frame of the observation window this launch writes (sliding history, LgTaskCfg.obs_slack)
     int obs_set;         // copy of obs_buf / priv_obs_buf / labels_buf this launch writes (LgTaskCfg.obs_sets)
