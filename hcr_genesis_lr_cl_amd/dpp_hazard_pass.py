@@ -7,6 +7,12 @@ products of csrc/lg_quad.h (v_mul_f32_dpp / v_fmac_f32_dpp sequences) are inline
 needed or not.  One wave per SIMD hides nothing: an `s_nop 1` is two issue slots, ~8.6 cycles (tools/ubench/pk_issue.hip), and the
 physics loop had 50 of them per sub-step -- 1.0 us of the 25.6 us go2 step.
 
+Only the DPP-routed operand (src0) is subject to the rule: the accumulator of a v_fmac_f32_dpp chain is written and re-read in
+consecutive slots throughout lg_quad.h's blocks, and the physics matches the CPU oracle.  The compiler pads for every VGPR operand of a
+DPP instruction; where that padding stands in front of a plain f32 / mov DPP instruction and nothing nearby has wait-state rules of its
+own (_blocks_relaxing: SGPR / VCC / EXEC writers, transcendentals, partial-register writes, memory, ...), it is dropped too
+(`_relax_compiler_nops`: 44 of the loop's remaining wait states, another 0.4 us).
+
 This pass removes those marked nops (`s_nop 1 ; lg-dpp-hazard`) and then walks every function: for EVERY `*_dpp` instruction -- the
 compiler's and the asm blocks' alike -- it measures the wait states since the last VALU write of the DPP source register over all
 paths that reach the instruction (branch targets resolved; an unknown predecessor counts as a write), and inserts exactly the `s_nop`
@@ -174,10 +180,64 @@ def _analyse(items):
     return labels, branches
 
 
-def fix(text):
-    """-> (new text, stats).  Removes the marked nops, then inserts the minimal s_nop in front of every DPP read that needs one."""
+_PLAIN_DPP = ("v_mov_b32_dpp", "v_add_f32_dpp", "v_sub_f32_dpp", "v_subrev_f32_dpp", "v_mul_f32_dpp", "v_fmac_f32_dpp", "v_max_f32_dpp", "v_min_f32_dpp")
+_TRANS = ("v_rcp", "v_rsq", "v_sqrt", "v_sin", "v_cos", "v_exp", "v_log")
+RELAX_WINDOW = 6
+
+
+def _blocks_relaxing(it):
+    """True for anything in front of a compiler nop that could be the reason for it other than the DPP rule, or whose own consumers count
+    wait states across it: VALU writes of SGPR / VCC / EXEC (lane selects, v_div_fmas, VMEM / VALU reads of that SGPR: up to 5 wait states),
+    transcendental and partial-register (op_sel, SDWA, packed) results (forwarding hazards, 1 wait state), stores (their data registers
+    may not be overwritten in the next slot), hardware-register accesses, and any instruction this pass does not know."""
+    mn = it.mn
+    if mn.startswith("v_"):
+        if mn.startswith(("v_cmp", "v_readlane", "v_readfirstlane", "v_writelane", "v_div_", "v_mad_u64", "v_mad_i64", "v_mfma", "v_accvgpr", "v_permlane") + _TRANS):
+            return True
+        if "_co_" in mn or "_pk_" in mn or "sdwa" in mn or "op_sel" in it.text or "16" in mn:
+            return True
+        if it.ops and it.ops[0].split()[0].startswith(("s", "vcc", "exec", "a", "m0")):
+            return True
+        return False
+    if mn in ("s_nop", "s_mov_b32", "s_mov_b64", "s_and_b64", "s_or_b64", "s_andn2_b64", "s_xor_b64", "s_add_i32", "s_sub_i32", "s_cmp_eq_u32", "s_cmp_lg_u32",
+              "s_cselect_b32", "s_cselect_b64", "s_lshl_b32", "s_and_b32", "s_or_b32", "s_cmp_lt_i32", "s_cmp_ge_u32", "s_cmp_lg_u64", "s_mul_i32"):
+        return False
+    return True            # memory, branches, waitcnt, setreg, message, ... : leave the nop alone
+
+
+def _relax_compiler_nops(lines, stats):
+    """The compiler pads a DPP instruction when ANY of its VGPR operands was written in the two slots before; the hardware rule concerns the
+    DPP-routed source only (the accumulators of lg_quad.h's blocks are written and re-read back to back).  Drop a compiler s_nop that stands
+    directly in front of a plain f32 / mov DPP instruction when nothing in the RELAX_WINDOW instructions before it is of a kind that could
+    need wait states for another reason (_blocks_relaxing) and no label lies in between; the main loop of fix() then re-inserts whatever
+    the DPP source itself needs."""
+    drop = set()
+    for items in _parse(lines):
+        for k, it in enumerate(items):
+            if not (isinstance(it, Inst) and it.mn == "s_nop" and not it.marked and MARK not in it.text):
+                continue
+            nxt = items[k + 1] if k + 1 < len(items) else None
+            if not (isinstance(nxt, Inst) and nxt.mn in _PLAIN_DPP):
+                continue
+            ok, j, seen = True, k, 0
+            while seen < RELAX_WINDOW:
+                j -= 1
+                if j < 0 or isinstance(items[j], tuple) or _blocks_relaxing(items[j]):
+                    ok = False
+                    break
+                seen += 1
+            if ok:
+                drop.add(it.line)
+                stats["compiler_nops_relaxed"] += 1
+                stats["compiler_wait_states_relaxed"] += it.wait_states
+    return [raw for i, raw in enumerate(lines) if i not in drop]
+
+
+def fix(text, relax=True):
+    """-> (new text, stats).  Removes the marked nops (and, `relax`, the compiler's over-wide padding in front of plain DPP instructions),
+    then inserts the minimal s_nop in front of every DPP read that needs one."""
     lines = text.split("\n")
-    stats = {"marked": 0, "kept_or_inserted": 0, "wait_states_inserted": 0, "dpp": 0, "functions": 0}
+    stats = {"marked": 0, "kept_or_inserted": 0, "wait_states_inserted": 0, "dpp": 0, "functions": 0, "compiler_nops_relaxed": 0, "compiler_wait_states_relaxed": 0}
     # 1. drop the marked nops
     keep = []
     for raw in lines:
@@ -187,6 +247,8 @@ def fix(text):
             continue
         keep.append(raw)
     lines = keep
+    if relax:
+        lines = _relax_compiler_nops(lines, stats)
     # 2. insert what is missing, function by function, top to bottom (an insertion only lengthens later distances)
     funcs = _parse(lines)
     stats["functions"] = len(funcs)

@@ -82,6 +82,43 @@ def test_unmarked_nops_are_left_alone_and_counted():
     assert nops(out) == ["s_nop 0", "s_nop 0"]   # the compiler's one wait state stays, the missing one is added
 
 
+FILL = ["v_add_f32_e32 v20, v1, v2", "v_add_f32_e32 v21, v1, v2", "v_add_f32_e32 v22, v1, v2", "v_add_f32_e32 v23, v1, v2", "v_add_f32_e32 v24, v1, v2",
+        "v_add_f32_e32 v25, v1, v2"]
+
+
+def test_compiler_padding_for_a_plain_operand_is_dropped():
+    # the compiler's s_nop 1 is there because v60 (PLAIN operand of the DPP add) was just written; the DPP source v59 is old
+    src = kernel(FILL + ["v_mul_f32_e32 v59, v1, v2", "v_add_f32_e32 v30, v1, v2", "v_add_f32_e32 v60, v1, v2", "s_nop 1",
+                         "v_add_f32_dpp v61, v59, v60 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf bound_ctrl:1", "s_endpgm"])
+    out, st = P.fix(src)
+    assert nops(out) == [] and st["compiler_nops_relaxed"] == 1 and st["compiler_wait_states_relaxed"] == 2
+    assert nops(P.fix(src, relax=False)[0]) == ["s_nop 1"]
+
+
+def test_compiler_padding_comes_back_when_the_dpp_source_needs_it():
+    src = kernel(FILL + ["v_mul_f32_e32 v59, v1, v2", "s_nop 1", "v_add_f32_dpp v61, v59, v60 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf bound_ctrl:1", "s_endpgm"])
+    out, st = P.fix(src)
+    assert nops(out) == ["s_nop 1"] and st["compiler_nops_relaxed"] == 1 and st["kept_or_inserted"] == 1
+
+
+@pytest.mark.parametrize("blocker", ["v_cmp_lt_f32_e32 vcc, v1, v2", "v_rcp_f32_e32 v40, v1", "v_readlane_b32 s6, v18, 0", "global_store_dword v1, v2, s[0:1]",
+                                     "v_pk_fma_f32 v[40:41], v[0:1], v[2:3], v[6:7]", "s_waitcnt vmcnt(0)", "v_add_co_u32_e32 v40, vcc, v1, v2"])
+def test_compiler_padding_is_left_alone_next_to_anything_with_rules_of_its_own(blocker):
+    src = kernel(FILL + [blocker, "v_add_f32_e32 v30, v1, v2", "v_add_f32_e32 v60, v1, v2", "s_nop 1",
+                         "v_add_f32_dpp v61, v59, v60 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf bound_ctrl:1", "s_endpgm"])
+    out, st = P.fix(src)
+    assert nops(out) == ["s_nop 1"] and st["compiler_nops_relaxed"] == 0
+
+
+def test_compiler_padding_is_left_alone_behind_a_label_and_in_front_of_other_instructions():
+    src = kernel(FILL[:3] + [".LBB0_4:"] + FILL[:3] + ["s_nop 1", "v_add_f32_dpp v61, v59, v60 quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf bound_ctrl:1", "s_endpgm"])
+    assert nops(P.fix(src)[0]) == ["s_nop 1"]
+    src = kernel(FILL + ["s_nop 0", "v_cndmask_b32_dpp v61, v59, v60, vcc quad_perm:[2,0,1,3] row_mask:0xf bank_mask:0xf", "s_endpgm"])
+    assert nops(P.fix(src)[0]) == ["s_nop 0"]
+    src = kernel(FILL + ["s_nop 0", "v_mul_f32_e32 v61, v59, v60", "s_endpgm"])
+    assert nops(P.fix(src)[0]) == ["s_nop 0"]
+
+
 def test_the_built_library_went_through_the_pass():
     side = os.path.join(ROOT, "hcr_genesis_lr_cl_amd", "csrc", "liblgsim.build.json")
     if not os.path.exists(side):
