@@ -1192,19 +1192,29 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             const QM ET = {cn, ct1, ct2};
             const QR cpr = rots(cp);          // the contact point enters every product below
             if (w_refresh) {      // dt * W, contact frame, rows
-                float du[JPL], dq;
+                // W_rk = f_r . (acceleration the robot answers f_k with), f_k the unit force along contact axis k at the contact point.  The
+                // articulated-body passes are an L D L^T factorisation of the inverse inertia, so with the UPWARD pass of each unit force
+                // alone (joint residuals du_j, force left at the base p) W = sum_j du_j du_j^T / D_j + P^T IA0^-1 P: no downward passes, no
+                // point accelerations -- the three resp_down chains were the longest dependent stretch of this section.  (Checked against the
+                // two-pass form on random chains to 1e-16 in double; the oracle and the leg-per-lane kernel keep the two-pass form.)
                 const float axs[3] = {cn, ct1, ct2};
-                float col[3];
+                float du[3][JPL];
+                QV6 pk[3], qk[3];
 #pragma unroll
                 for (int k = 0; k < 3; k++) {
                     const QV6 fsp = {cross(cpr, axs[k]), axs[k]};
-                    const QV6 dp = resp_up(J, fsp, 0.f, du);
-                    const QV6 ab = muli6(Inv, QV6{-dp.a, -dp.l});
-                    const QV6 ac = resp_down(L, J, ab, du, dq);
-                    const float ra = ac.l + cross(ac.a, cpr);
-                    col[k] = dt * mulv(E, ra);
+                    pk[k] = resp_up(J, fsp, 0.f, du[k]);
+                    qk[k] = muli6(Inv, pk[k]);
                 }
-                Ac_keep.c0 = col[0]; Ac_keep.c1 = col[1]; Ac_keep.c2 = col[2];
+                const float D00 = dot6(pk[0], qk[0]), D01 = dot6(pk[0], qk[1]), D02 = dot6(pk[0], qk[2]);
+                const float D11 = dot6(pk[1], qk[1]), D12 = dot6(pk[1], qk[2]), D22 = dot6(pk[2], qk[2]);
+                float col[3] = {L.sel(D00, D01, D02), L.sel(D01, D11, D12), L.sel(D02, D12, D22)};   // row r in lane r; symmetric by construction
+#pragma unroll
+                for (int j = 0; j < JPL; j++) {
+                    const float us = L.sel(du[0][j], du[1][j], du[2][j]) * J[j].dinv;
+                    col[0] += us * du[0][j]; col[1] += us * du[1][j]; col[2] += us * du[2][j];
+                }
+                Ac_keep.c0 = dt * col[0]; Ac_keep.c1 = dt * col[1]; Ac_keep.c2 = dt * col[2];
             }
             const QM Ac = Ac_keep;
             float vfree;
