@@ -1,8 +1,8 @@
 """Builds csrc/liblgsim.so with hipcc for gfx950 (in-tree, so it travels to the GPU box).
 
-The library is 20 translation units: lg_host.hip (C ABI), lg_rollout.hip and lg_inst.hip compiled once per kernel-instantiation group
-(-DLG_GROUP=0..17).  They are compiled in parallel into csrc/obj/ and linked; an object is reused while the sources it depends on and
-the flags are unchanged (content hash), so an edit of lg_quad.h rebuilds the ten component-per-lane groups only.
+The library is 22 translation units: lg_host.hip (C ABI), lg_rollout.hip and lg_inst.hip compiled once per kernel-instantiation group
+(-DLG_GROUP=0..19).  They are compiled in parallel into csrc/obj/ and linked; an object is reused while the sources it depends on and
+the flags are unchanged (content hash), so an edit of lg_quad.h rebuilds the twelve component-per-lane groups only.
 
 The kernel groups go through the compiler's ASSEMBLY: hipcc -S (device) -> dpp_hazard_pass.fix (the s_nop each DPP read needs, no
 more: the inline-asm products of lg_quad.h otherwise pay a two-slot nop per block) -> assembler -> lld -> offload bundle -> host
@@ -23,8 +23,8 @@ OUT = os.environ.get("LG_BUILD_OUT") or os.path.join(CSRC, "liblgsim.so")
 OBJ = os.path.join(CSRC, "obj" if "LG_BUILD_OUT" not in os.environ else "obj_" + os.path.splitext(os.path.basename(OUT))[0])
 LLVM_BIN = os.environ.get("LG_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 DPP_PASS = os.environ.get("LG_NO_DPP_PASS", "0") != "1"
-N_GROUPS = 18
-QUAD_GROUPS = list(range(0, 9)) + [17]          # lg_inst.hip: groups that include lg_quad.h
+N_GROUPS = 20
+QUAD_GROUPS = list(range(0, 9)) + list(range(17, 20))   # lg_inst.hip: groups that include lg_quad.h
 COMMON = ["lg_shared.h", "lg_math.h", os.path.join(INC, "lgsim.h")]
 # -fno-slp-vectorize: packing scalars into v_pk_* costs more v_mov / AGPR shuffles than it saves here.
 # iterative-ilp scheduling: the kernels run one wave per SIMD, so occupancy is irrelevant and the scheduler should fill DPP /

@@ -364,8 +364,11 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
         const bool hfb = h->hf != nullptr && h->opts.terrain_rows > 0;
         if constexpr (LEGS == 4) {
             fuse = pre && rest != 0;
-            if (fuse && rest == PR && flat_profile(h)) LG_LAUNCH(pi, (lg_launch_quad<4, true, PR, 1, 3>), qgrid);
-            else if (fuse && rest == PR && wtw_profile(h)) LG_LAUNCH(pi, (lg_launch_quad<4, true, PR, 2, 3>), qgrid);
+            // rs(P): the task's reward set is the default one of profile P -> the instantiation that has it as a constant (lg_quad.h RS)
+            const char *rse = getenv("LG_REWARD_SET_CONST");
+            auto rs = [&](int prof) { return (unsigned)h->hot.reward_mask == lg_default_reward_mask(prof) && !(rse && atoi(rse) == 0); };
+            if (fuse && rest == PR && flat_profile(h)) { if (rs(1)) LG_LAUNCH(pi, (lg_launch_quad_rs<4, 1, false>), qgrid); else LG_LAUNCH(pi, (lg_launch_quad<4, true, PR, 1, 3>), qgrid); }
+            else if (fuse && rest == PR && wtw_profile(h)) { if (rs(2)) LG_LAUNCH(pi, (lg_launch_quad_rs<4, 2, false>), qgrid); else LG_LAUNCH(pi, (lg_launch_quad<4, true, PR, 2, 3>), qgrid); }
             else if (fuse && rest == PR && rough_profile(h) == 3) LG_LAUNCH(pi, (lg_launch_quad<4, true, PR, 3, 3>), qgrid);
             else if (fuse && rest == PR && rough_profile(h) == 4) LG_LAUNCH(pi, (lg_launch_quad<4, true, PR, 4, 3>), qgrid);
             else if (fuse && rest == PR) LG_LAUNCH(pi, (lg_launch_quad<4, true, PR, 0, 3>), qgrid);
@@ -408,11 +411,17 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
         bool done = true;
         if constexpr (LEGS == 4) {
             const int rp = rough_profile(h, true);
-            if (flat_profile(h, true)) { h->last_kernel = "(lg_launch_quad_inj<4, 1>)"; lg_launch_quad_inj<4, 1>(qgrid, st, p); }
-            else if (wtw_profile(h, true)) { h->last_kernel = "(lg_launch_quad_inj<4, 2>)"; lg_launch_quad_inj<4, 2>(qgrid, st, p); }
+            // the same choice of instantiation as the whole-step launch: constant reward set where the task's is the profile's default
+            const char *rse = getenv("LG_REWARD_SET_CONST");
+            auto rs = [&](int prof) { return (unsigned)h->hot.reward_mask == lg_default_reward_mask(prof) && !(rse && atoi(rse) == 0); };
+#define LG_INJ(L_, P_) do { if (rs(P_)) { h->last_kernel = "(lg_launch_quad_inj<" #L_ ", " #P_ ">, reward set constant)"; lg_launch_quad_rs<L_, P_, true>(qgrid, st, nullptr, nullptr, p); } \
+                            else { h->last_kernel = "(lg_launch_quad_inj<" #L_ ", " #P_ ">)"; lg_launch_quad_inj<L_, P_>(qgrid, st, p); } } while (0)
+            if (flat_profile(h, true)) LG_INJ(4, 1);
+            else if (wtw_profile(h, true)) LG_INJ(4, 2);
             else if (rp == 3) { h->last_kernel = "(lg_launch_quad_inj<4, 3>)"; lg_launch_quad_inj<4, 3>(qgrid, st, p); }
             else if (rp == 4) { h->last_kernel = "(lg_launch_quad_inj<4, 4>)"; lg_launch_quad_inj<4, 4>(qgrid, st, p); }
             else done = false;
+#undef LG_INJ
         } else {
             if (biped_profile(h, true)) { h->last_kernel = "(lg_launch_quad_inj<2, 6>)"; lg_launch_quad_inj<2, 6>(qgrid, st, p); }
             else done = false;

@@ -1,15 +1,15 @@
 // lg_inst.hip -- the kernel instantiations of the library, compiled once per GROUP (hipcc -DLG_GROUP=g ... -c, the groups in parallel;
 // hcr_genesis_lr_cl_amd/build.py).  One translation unit holding all of them took over three minutes to build; a group is a
-// handful of kernels that share template parameters.  Groups 0-8 and 17 hold the component-per-lane kernels (lg_quad.h), groups 9-16 the
+// handful of kernels that share template parameters.  Groups 0-8 and 17-19 hold the component-per-lane kernels (lg_quad.h), groups 9-16 the
 // leg-per-lane ones (lg_kernel.h) and do not include lg_quad.h, so an edit there leaves their objects valid.
 //
 // The host side (lg_host.hip) calls the launchers declared in lg_shared.h; every instantiation it names must appear in exactly
 // one group below (a missing one is a link error, not a run-time surprise).
 #ifndef LG_GROUP
-#error "compile with -DLG_GROUP=<0..17> (hcr_genesis_lr_cl_amd/build.py)"
+#error "compile with -DLG_GROUP=<0..19> (hcr_genesis_lr_cl_amd/build.py)"
 #endif
 #include "lg_kernel.h"
-#if LG_GROUP < 9 || LG_GROUP == 17
+#if LG_GROUP < 9 || LG_GROUP >= 17
 #include "lg_quad.h"
 
 template <int LEGS, bool PRE, unsigned MPH, int PROF, int JPL>
@@ -24,6 +24,14 @@ void lg_launch_quad_inj(dim3 grid, hipStream_t st, const KParams &p) {
     hipLaunchKernelGGL((quad_sim_kernel<LEGS, true, LG_PHASE_POST | LG_PHASE_RESET, PROF, 3, true>), grid, dim3(PROF == 6 ? 2 * BLOCK : BLOCK), 0, st, p);
 }
 #define QUAD_INJ(...) template void lg_launch_quad_inj<__VA_ARGS__>(dim3, hipStream_t, const KParams &);
+template <int LEGS, int PROF, bool INJ>
+void lg_launch_quad_rs(dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const KParams &p) {
+    constexpr unsigned PR = LG_PHASE_POST | LG_PHASE_RESET;
+    const dim3 block(PROF == 6 ? 2 * BLOCK : BLOCK);
+    if (e0 || e1) hipExtLaunchKernelGGL((quad_sim_kernel<LEGS, true, PR, PROF, 3, INJ, true>), grid, block, 0, st, e0, e1, 0, p);
+    else hipLaunchKernelGGL((quad_sim_kernel<LEGS, true, PR, PROF, 3, INJ, true>), grid, block, 0, st, p);
+}
+#define QUAD_RS(...) template void lg_launch_quad_rs<__VA_ARGS__>(dim3, hipStream_t, hipEvent_t, hipEvent_t, const KParams &);
 #else
 template <int LEGS, unsigned PH, int PROF, int JPL, bool REPL>
 void lg_launch_env(dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const KParams &p) {
@@ -74,6 +82,11 @@ ENV_PHASES(2, 3)
 ENV_PHASES(2, 4)
 #elif LG_GROUP == 17   // the component-layout tails on injected read-backs and uniforms (golden replays through the benchmarked tails)
 QUAD_INJ(4, 1) QUAD_INJ(4, 2) QUAD_INJ(4, 3) QUAD_INJ(4, 4) QUAD_INJ(2, 6)
+// ---- the whole step / the golden-replay form with the profile's default reward set as a compile-time constant (lg_quad.h RS) ----
+#elif LG_GROUP == 18   // go2 (the headline kernel of the default task), go2_wtw
+QUAD_RS(4, 1, false) QUAD_RS(4, 2, false)
+#elif LG_GROUP == 19   // ... on injected read-backs (golden replays)
+QUAD_RS(4, 1, true) QUAD_RS(4, 2, true)
 #else
 #error "LG_GROUP out of range"
 #endif

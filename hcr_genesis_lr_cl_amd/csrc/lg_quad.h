@@ -452,7 +452,11 @@ LG_DEV void blank_histories(unsigned long long rm, int e, float *obs, size_t oro
 // component-layout tails themselves -- the sub-step loop and the read-back are skipped, what they would have left in registers (twists,
 // torques, contact forces, feet, terrain samples) is loaded from the bound buffers the test filled with the reference's recorded values,
 // and every uniform comes from LgBuffers.rand_in instead of Philox.  The MDP statements are the very ones the product instantiation runs.
-template <int LEGS, bool DO_PRE, unsigned MPH, int PROF = 0, int JPL = 3, bool INJ = false>
+// RS (host-checked: the task's reward set IS its profile's default, lg_host.hip rs_mask): the set of active reward terms is a compile-time
+// constant.  The terms are evaluated behind one scalar test each -- thirty-two branches that cut the reward section into as many basic
+// blocks, each term's reduction over the env's lanes (four dependent DPP adds with their wait states) alone in its own; with the set known
+// the unused terms are gone and the others interleave (go2: -0.5 us).  Any other set of terms runs the RS = false instantiation.
+template <int LEGS, bool DO_PRE, unsigned MPH, int PROF = 0, int JPL = 3, bool INJ = false, bool RS = false>
 #ifdef LG_PK_F32   // one wave per SIMD by design: let the allocator use the accumulation registers instead of spilling the 64-bit tuples
 __global__ __launch_bounds__(BLOCK) __attribute__((amdgpu_waves_per_eu(1, 1))) void quad_sim_kernel(KParams p) {
 #else
@@ -464,6 +468,8 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
     static_assert(!INJ || (DO_PRE && MPH == (LG_PHASE_POST | LG_PHASE_RESET) && (PROF == 1 || PROF == 2 || PROF == 3 || PROF == 4 || PROF == 6)),
                   "injected read-backs: the component-layout tails only");
     constexpr bool FLAT = PROF == 1, PLANE = PROF == 1 || PROF == 2;   // host-checked task profiles (lg_kernel.h flat_profile / wtw_profile)
+    constexpr unsigned RS_MASK = lg_default_reward_mask(PROF);
+    static_assert(!RS || RS_MASK != 0u, "RS: the profile has a default reward set");
     constexpr int A = JPL * LEGS;
     // The kernel argument block (KParams, ~800 B of pointers) through ONE vector load: lane i holds bytes [16 i, 16 i + 16).
     // Fetched with scalar loads it arrives as a dozen dependent dwordx16 chunks (SGPR pressure), each a device-memory round
@@ -1196,7 +1202,7 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
                 // articulated-body passes are an L D L^T factorisation of the inverse inertia, so with the UPWARD pass of each unit force
                 // alone (joint residuals du_j, force left at the base p) W = sum_j du_j du_j^T / D_j + P^T IA0^-1 P: no downward passes, no
                 // point accelerations -- the three resp_down chains were the longest dependent stretch of this section.  (Checked against the
-                // two-pass form on random chains to 1e-16 in double; the oracle and the leg-per-lane kernel keep the two-pass form.)
+                // two-pass form on random chains to 1e-16 in double; the CPU oracle and the leg-per-lane kernel keep the two-pass form.)
                 const float axs[3] = {cn, ct1, ct2};
                 float du[3][JPL];
                 QV6 pk[3], qk[3];
@@ -1622,7 +1628,7 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
         const auto h_kd_offset = EQ ? HOT(kd_offset) : 0.f;
         asm volatile("" ::: "memory");
         const float cdt = h_control_dt;
-        const unsigned rmask = (unsigned)p.k.reward_mask;
+        const unsigned rmask = RS ? RS_MASK : (unsigned)p.k.reward_mask;
         const bool heading = h_heading_command != 0;
         unsigned k0, k1, e_lo, e_hi;
         {
@@ -2384,7 +2390,7 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
         const auto h_yaw_clip_1 = HOT(yaw_clip[1]);
         asm volatile("" ::: "memory");
         const float cdt = h_control_dt;
-        const unsigned rmask = (unsigned)p.k.reward_mask;
+        const unsigned rmask = RS ? RS_MASK : (unsigned)p.k.reward_mask;
         const bool heading = h_heading_command != 0;
         unsigned k0, k1, e_lo, e_hi;
         {

@@ -8,7 +8,7 @@ needed or not.  One wave per SIMD hides nothing: an `s_nop 1` is two issue slots
 physics loop had 50 of them per sub-step -- 1.0 us of the 25.6 us go2 step.
 
 Only the DPP-routed operand (src0) is subject to the rule: the accumulator of a v_fmac_f32_dpp chain is written and re-read in
-consecutive slots throughout lg_quad.h's blocks, and the physics matches the CPU oracle.  The compiler pads for every VGPR operand of a
+consecutive slots throughout lg_quad.h's blocks, and the physics matches its f64 CPU restatement.  The compiler pads for every VGPR operand of a
 DPP instruction; where that padding stands in front of a plain f32 / mov DPP instruction and nothing nearby has wait-state rules of its
 own (_blocks_relaxing: SGPR / VCC / EXEC writers, transcendentals, partial-register writes, memory, ...), it is dropped too
 (`_relax_compiler_nops`: 44 of the loop's remaining wait states, another 0.4 us).

@@ -612,3 +612,41 @@ def test_baseline_config_full_size_properties(task, n_local, n_global, offset):
         return outs
     a, b = run(), run()
     assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
+
+
+@pytest.mark.parametrize("task", ["go2", "go2_wtw"])
+def test_constant_reward_set_instantiation_equals_the_general_one(task, monkeypatch):
+    """A task whose reward set is its profile's default runs the instantiation that has the set as a compile-time constant (lg_quad.h RS,
+    lg_host.hip); LG_REWARD_SET_CONST=0 sends the same task through the general instantiation.  Both step from the same state every step
+    (the two are separate compilations of the same statements: floating-point contraction may differ in the last bits, and a rollout
+    left alone would amplify that)."""
+    import os
+    import torch
+    from hcr_genesis_lr_cl_amd.envs import make_env
+    N, T = 256, 60
+    e1, _ = make_env(task, N)
+    e2, _ = make_env(task, N)
+    e1.reset(); e2.reset()
+    g = torch.Generator(device="cuda"); g.manual_seed(11)
+    e1.episode_length_buf[:] = torch.randint(0, 900, (N,), generator=g, device="cuda", dtype=torch.int32)
+    e1.common_step_counter = e2.common_step_counter = 480
+    n_reset = 0
+    for t in range(T):
+        for k in e1._engine.buf.keys():
+            e2._engine.buf.raw(k).copy_(e1._engine.buf.raw(k))
+        e2.common_step_counter = e1.common_step_counter
+        act = torch.randn(N, e1.num_actions, generator=g, device="cuda")
+        monkeypatch.delenv("LG_REWARD_SET_CONST", raising=False)
+        e1.step(act)
+        assert "lg_launch_quad_rs" in e1._engine.last_kernel(), e1._engine.last_kernel()
+        monkeypatch.setenv("LG_REWARD_SET_CONST", "0")
+        e2.step(act)
+        assert "lg_launch_quad_rs" not in e2._engine.last_kernel() and "lg_launch_quad<4" in e2._engine.last_kernel(), e2._engine.last_kernel()
+        torch.cuda.synchronize()
+        assert torch.equal(e1.reset_buf, e2.reset_buf), t
+        torch.testing.assert_close(e1.rew_buf, e2.rew_buf, rtol=2e-5, atol=2e-6)
+        for k in ("episode_sums", "obs_buf", "dof_pos", "dof_vel", "base_pos", "commands", "feet_air_time"):
+            a, b = e1._engine.buf[k], e2._engine.buf[k]
+            torch.testing.assert_close(a, b, rtol=2e-4, atol=2e-4, msg=lambda m, k=k, t=t: f"{k} @ {t}: {m}")
+        n_reset += int(e1.reset_buf.sum())
+    assert n_reset > 0

@@ -4,7 +4,7 @@
 set -e
 D=${ISA_DIR:-/tmp/isa}
 mkdir -p $D
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp -DLG_GROUP=${LG_GROUP:-0} "$@" \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fno-slp-vectorize -mllvm -amdgpu-sched-strategy=iterative-ilp -DLG_GROUP=${LG_GROUP:-18} "$@" \
     -S --cuda-device-only -o $D/g.s $(dirname $0)/../hcr_genesis_lr_cl_amd/csrc/lg_inst.hip 2>/dev/null
 python3 - $D/g.s <<'PY'
 import re, sys

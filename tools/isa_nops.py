@@ -2,7 +2,7 @@
 usage: python tools/isa_nops.py [group] [kernel-name-prefix]"""
 import re, sys, os
 from collections import Counter
-g = sys.argv[1] if len(sys.argv) > 1 else "0"
+g = sys.argv[1] if len(sys.argv) > 1 else "18"
 pref = sys.argv[2] if len(sys.argv) > 2 else "_Z15quad_sim_kernel"
 lines = open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", "hcr_genesis_lr_cl_amd", "csrc", "obj", f"lg_inst_{g}.fix.s")).read().splitlines()
 start = next(i for i, l in enumerate(lines) if l.startswith(pref) and l.rstrip().endswith(":") or re.match(re.escape(pref) + r".*:", l))
