@@ -373,6 +373,10 @@ template <int AK> LG_DEV void joint_rot(const Lane &L, const QM &Rp, float ax, f
     }
 }
 
+// store / load at base + a 32-bit BYTE offset (base wave-uniform: the saddr form of global_store / global_load)
+template <class T> LG_DEV void stq(T *base, unsigned off, T v) { *reinterpret_cast<T *>(reinterpret_cast<char *>(base) + off) = v; }
+template <class T> LG_DEV T ldq(const T *base, unsigned off) { return *reinterpret_cast<const T *>(reinterpret_cast<const char *>(base) + off); }
+
 struct QJoint { QV6 S, U, c; float dinv, u; };
 struct QKin { QM R; float P; QV6 V; QR Wr; };   // Wr: the rotations of V.a (cross products)
 struct Terr { int rows, cols; float border, ihs, vscale; const int16_t *hf; };
@@ -730,9 +734,9 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
 
     // ---------------- prologue stores ---------------------------------------------------------------
     if (DO_PRE && stj) {
-        B.llast_actions[ja] = llast_act;
-        B.last_actions[ja] = last_act;
-        B.actions[ja] = act;
+        stq(B.llast_actions, 4u * (unsigned)ja, llast_act);
+        stq(B.last_actions, 4u * (unsigned)ja, last_act);
+        stq(B.actions, 4u * (unsigned)ja, act);
     }
     float last_foot_v = snap_fv, qd_start = qd;   // kept for the MDP tail (dof_acc, foot_acc)
     // injected read-backs (INJ): what the physics of this step left behind, as the test put it into the buffers
@@ -746,10 +750,10 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
         inj_fp = B.feet_pos[(e * F + foot_slot) * 3 + cj];
         inj_pg = B.projected_gravity[3 * e + cj]; inj_eul = B.base_euler[3 * e + cj];
     } else {
-    if (stj) B.last_dof_vel[ja] = qd;   // "last" snapshots (genesis_simulator.py:21-24)
+    if (stj) stq(B.last_dof_vel, 4u * (unsigned)ja, qd);   // "last" snapshots (genesis_simulator.py:21-24)
     if (st) {
-        B.last_feet_vel[(e * F + foot_slot) * 3 + cj] = snap_fv;
-        if (leg == 0) { B.last_base_lin_vel[3 * e + cj] = snap_blv; B.last_base_ang_vel[3 * e + cj] = snap_bav; }
+        stq(B.last_feet_vel, 4u * (unsigned)((e * F + foot_slot) * 3 + cj), snap_fv);
+        if (leg == 0) { stq(B.last_base_lin_vel, 4u * (unsigned)(3 * e + cj), snap_blv); stq(B.last_base_ang_vel, 4u * (unsigned)(3 * e + cj), snap_bav); }
     }
     }
     (void)last_foot_v; (void)qd_start;
@@ -1392,22 +1396,27 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
         foot_p = inj_fp; foot_v = snap_fv; blv = snap_blv; bav = snap_bav; pg = inj_pg; eul = inj_eul; torque = inj_tq;
         f_link[0] = inj_fl[0]; f_link[1] = inj_fl[1]; f_link[2] = inj_fl[2]; f_link[3] = inj_fl[3]; f_base = inj_fb;
     }
-    if (!INJ && stj) { B.dof_pos[ja] = q; B.dof_vel[ja] = qd; B.torques[ja] = torque; }
+    // Read-back stores: a wave-uniform base (kernel argument) + a 32-bit byte offset per lane, so that the store takes its base from scalar
+    // registers (saddr form) -- one offset per index pattern, shared by the arrays that use it -- instead of a 64-bit pointer computed in
+    // vector registers for every store (sign extension, 64-bit shift, add with carry: 3-4 VALU instructions each, ~70 stores per lane in the
+    // step).  Every array stays below 4 GiB (checked where the launch is chosen, lg_host.hip).
+    const unsigned o_ja = 4u * (unsigned)ja, o_e3 = 4u * (unsigned)(3 * e + cj), o_ft = 4u * (unsigned)((e * F + foot_slot) * 3 + cj);
+    if (!INJ && stj) { stq(B.dof_pos, o_ja, q); stq(B.dof_vel, o_ja, qd); stq(B.torques, o_ja, torque); }
     if (!INJ && st) {
-        const int l0 = foot_link - 3;
+        const unsigned o_lk = 4u * (unsigned)((e * nL + foot_link - 3) * 3 + cj);
 #pragma unroll
-        for (int k = 0; k < 4; k++) B.link_contact_forces[(e * nL + l0 + k) * 3 + cj] = f_link[k];
-        B.feet_pos[(e * F + foot_slot) * 3 + cj] = foot_p;
-        B.feet_vel[(e * F + foot_slot) * 3 + cj] = foot_v;
+        for (int k = 0; k < 4; k++) stq(B.link_contact_forces, o_lk + 12u * (unsigned)k, f_link[k]);
+        stq(B.feet_pos, o_ft, foot_p);
+        stq(B.feet_vel, o_ft, foot_v);
         if (leg == 0) {
-            B.base_pos[3 * e + cj] = pos;
-            B.base_lin_vel_w[3 * e + cj] = vw; B.base_ang_vel_w[3 * e + cj] = ww;
-            B.base_lin_vel[3 * e + cj] = blv; B.base_ang_vel[3 * e + cj] = bav;
-            B.projected_gravity[3 * e + cj] = pg; B.base_euler[3 * e + cj] = eul;
-            B.link_contact_forces[(e * nL) * 3 + cj] = f_base;
+            stq(B.base_pos, o_e3, pos);
+            stq(B.base_lin_vel_w, o_e3, vw); stq(B.base_ang_vel_w, o_e3, ww);
+            stq(B.base_lin_vel, o_e3, blv); stq(B.base_ang_vel, o_e3, bav);
+            stq(B.projected_gravity, o_e3, pg); stq(B.base_euler, o_e3, eul);
+            stq(B.link_contact_forces, 4u * (unsigned)((e * nL) * 3 + cj), f_base);
         }
     }
-    if (!INJ && live && leg == 0) B.base_quat[4 * e + L.c] = quat;
+    if (!INJ && live && leg == 0) stq(B.base_quat, 4u * (unsigned)(4 * e + L.c), quat);
 
     // ---------------- terrain sampling around the base and the feet (genesis_simulator.py:552-610) ------
     const int P = PLANE ? 0 : HOT(o_n_height_points);
@@ -2259,14 +2268,17 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
         STAMP(10);
         // ---- persistent MDP state ----
         if (live) {
-            if ((rmask >> ei) & 1u) B.episode_sums[(size_t)ei * N + e] = es0;
-            if (ei + 16 < LG_R_COUNT && ((rmask >> (ei + 16)) & 1u)) B.episode_sums[(size_t)(ei + 16) * N + e] = es1;
-            if (L.is0) { B.feet_air_time[e * F + foot_slot] = air; B.last_contacts[e * F + foot_slot] = (uint8_t)last_contact; }
+            // (32-bit byte offsets from wave-uniform bases, as the read-back stores: (term, N) rows stay below 4 GiB, host-checked)
+            const unsigned o_es = 4u * ((unsigned)ei * (unsigned)N + (unsigned)e);
+            if ((rmask >> ei) & 1u) stq(B.episode_sums, o_es, es0);
+            if (ei + 16 < LG_R_COUNT && ((rmask >> (ei + 16)) & 1u)) stq(B.episode_sums, o_es + 64u * (unsigned)N, es1);
+            if (L.is0) { stq(B.feet_air_time, 4u * (unsigned)(e * F + foot_slot), air); stq(B.last_contacts, (unsigned)(e * F + foot_slot), (uint8_t)last_contact); }
             if (leg == 0) {
-                B.commands[4 * e + L.c] = cmdv;
+                stq(B.commands, 4u * (unsigned)(4 * e + L.c), cmdv);
                 if (L.is0) {
-                    B.episode_length_buf[e] = ep_len; B.fail_buf[e] = (long long)failb;
-                    B.reset_buf[e] = reset ? 1 : 0; B.time_out_buf[e] = time_out ? 1 : 0; B.rew_buf[e] = total;
+                    const unsigned ue = (unsigned)e;
+                    stq(B.episode_length_buf, 4u * ue, (int32_t)ep_len); stq(B.fail_buf, 8u * ue, (int64_t)failb);
+                    stq(B.reset_buf, ue, (uint8_t)(reset ? 1 : 0)); stq(B.time_out_buf, ue, (uint8_t)(time_out ? 1 : 0)); stq(B.rew_buf, 4u * ue, total);
                 }
             }
         }
