@@ -400,6 +400,28 @@ template <bool HF = false> LG_DEV void terrain(const Terr &T, float x, float y, 
     nx = -hx * inv; ny = -hy * inv; nz = inv;
 }
 
+// TWO lookups at once, one in each half of packed-f32 pairs: the float arithmetic of a lookup (cell coordinates, bilinear height, slope,
+// normal: ~35 of its ~55 instructions) is plain per-lane arithmetic, which a lone wave issues in pairs at the price of one (tools/ubench/
+// pk_issue.hip).  Same statements as terrain<true>, half by half; the cell index, the four loads and the rsq stay per lookup.
+LG_DEV void terrain2(const Terr &T, f2 x, f2 y, f2 &h, f2 &nx, f2 &ny, f2 &nz) {
+    const f2 gx = (x + T.border) * T.ihs, gy = (y + T.border) * T.ihs;
+    int ix0 = (int)floorf(gx.x), ix1 = (int)floorf(gx.y), iy0 = (int)floorf(gy.x), iy1 = (int)floorf(gy.y);
+    ix0 = min(max(ix0, 0), T.rows - 2); ix1 = min(max(ix1, 0), T.rows - 2);
+    iy0 = min(max(iy0, 0), T.cols - 2); iy1 = min(max(iy1, 0), T.cols - 2);
+    const f2 dx = gx - f2{(float)ix0, (float)ix1}, dy = gy - f2{(float)iy0, (float)iy1};
+    const f2 fx = {fminf(fmaxf(dx.x, 0.f), 1.f), fminf(fmaxf(dx.y, 0.f), 1.f)}, fy = {fminf(fmaxf(dy.x, 0.f), 1.f), fminf(fmaxf(dy.y, 0.f), 1.f)};
+    const int16_t *q0 = T.hf + ix0 * T.cols + iy0, *q1 = T.hf + ix1 * T.cols + iy1;
+    const f2 h00 = f2{(float)q0[0], (float)q1[0]} * T.vscale, h10 = f2{(float)q0[T.cols], (float)q1[T.cols]} * T.vscale;
+    const f2 h01 = f2{(float)q0[1], (float)q1[1]} * T.vscale, h11 = f2{(float)q0[T.cols + 1], (float)q1[T.cols + 1]} * T.vscale;
+    const f2 omx = 1.f - fx, omy = 1.f - fy;
+    h = (h00 * omx + h10 * fx) * omy + (h01 * omx + h11 * fx) * fy;
+    const f2 hx = ((h10 - h00) * omy + (h11 - h01) * fy) * T.ihs;
+    const f2 hy = ((h01 - h00) * omx + (h11 - h10) * fx) * T.ihs;
+    const f2 s = hx * hx + hy * hy + 1.f;
+    const f2 inv = {rsqrtf(s.x), rsqrtf(s.y)};
+    nx = -hx * inv; ny = -hy * inv; nz = inv;
+}
+
 // response sweeps (see resp_up / resp_down in lg_kernel.h); du replicated, tl / dqdd in joint lanes
 template <int NJ> LG_DEV QV6 resp_up(const QJoint (&J)[NJ], const QV6 &fspat, float tl, float (&du)[NJ]) {
     QV6 dp = {-fspat.a, -fspat.l};
@@ -1020,13 +1042,48 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             // Broad phase of EVERY slot first.  On a heightfield each probe is a dependent round trip (cell index -> four int16 loads ->
             // bilinear height and normal): probe, force, probe, force ... exposed one L2 round trip per slot and sub-step in the serial
             // chain (rough terrain: +14 k cycles per control step over the plane); issued together the loads overlap.
-            const Hit tb = probe(4, Rb, 0.f), ta = probe(0, K[0].R, K[0].P), tc = probe(1, K[1].R, K[1].P);
-            const Hit td = probe(2, K[2].R, K[2].P);
-            Hit te = td;
+            Hit tb, ta, tc, td, te;
+#ifndef LG_NO_PK_TERRAIN
+            if constexpr (HFC && JPL == 3) {
+                // heightfield bound (compile time): the five slots' sphere centres and the foot's, then the six lookups as three packed pairs
+                // (base | hip, thigh | calf, calf's second slot | foot)
+                auto centre = [&](int k, const QM &R, float P, float &rx, float &ry, float &rz) {
+                    rx = bc<0>(P) + bc<0>(R.c0) * sx[k] + bc<0>(R.c1) * sy[k] + bc<0>(R.c2) * sz[k];
+                    ry = bc<1>(P) + bc<1>(R.c0) * sx[k] + bc<1>(R.c1) * sy[k] + bc<1>(R.c2) * sz[k];
+                    rz = bc<2>(P) + bc<2>(R.c0) * sx[k] + bc<2>(R.c1) * sy[k] + bc<2>(R.c2) * sz[k];
+                };
+                float cx[6], cy[6], cz[6];
+                centre(4, Rb, 0.f, cx[0], cy[0], cz[0]); centre(0, K[0].R, K[0].P, cx[1], cy[1], cz[1]); centre(1, K[1].R, K[1].P, cx[2], cy[2], cz[2]);
+                centre(2, K[2].R, K[2].P, cx[3], cy[3], cz[3]); centre(3, K[2].R, K[2].P, cx[4], cy[4], cz[4]);
+                const float rf = K[JPL - 1].P + mulv(K[JPL - 1].R, foot_c_loc);
+                cx[5] = bc<0>(rf); cy[5] = bc<1>(rf); cz[5] = 0.f;
+                f2 hh[3], nnx[3], nny[3], nnz[3];
+#pragma unroll
+                for (int k = 0; k < 3; k++) terrain2(TR, f2{px + cx[2 * k], px + cx[2 * k + 1]}, f2{py + cy[2 * k], py + cy[2 * k + 1]}, hh[k], nnx[k], nny[k], nnz[k]);
+                auto finish = [&](int k, float rx, float ry, float rz, float h, float nx, float ny, float nz) {
+                    Hit t;
+                    t.rx = rx; t.ry = ry; t.rz = rz; t.h = h; t.nx = nx; t.ny = ny; t.nz = nz;
+                    t.depth = srad[k] - (pz + rz - h) * nz;
+                    t.on = t.depth > -margin;
+                    return t;
+                };
+                tb = finish(4, cx[0], cy[0], cz[0], hh[0].x, nnx[0].x, nny[0].x, nnz[0].x);
+                ta = finish(0, cx[1], cy[1], cz[1], hh[0].y, nnx[0].y, nny[0].y, nnz[0].y);
+                tc = finish(1, cx[2], cy[2], cz[2], hh[1].x, nnx[1].x, nny[1].x, nnz[1].x);
+                td = finish(2, cx[3], cy[3], cz[3], hh[1].y, nnx[1].y, nny[1].y, nnz[1].y);
+                te = finish(3, cx[4], cy[4], cz[4], hh[2].x, nnx[2].x, nny[2].x, nnz[2].x);
+                ft_h = hh[2].y; ft_nx = nnx[2].y; ft_ny = nny[2].y; ft_nz = nnz[2].y;
+            } else
+#endif
+            {
+            tb = probe(4, Rb, 0.f); ta = probe(0, K[0].R, K[0].P); tc = probe(1, K[1].R, K[1].P);
+            td = probe(2, K[2].R, K[2].P);
+            te = td;
             if constexpr (JPL == 3) te = probe(3, K[2].R, K[2].P);   // the calf's second slot
             if (HFC) {   // the foot's lookup rides in the same batch of loads
                 const float rf = K[JPL - 1].P + mulv(K[JPL - 1].R, foot_c_loc);
                 terrain<HFC>(TR, px + bc<0>(rf), py + bc<1>(rf), ft_h, ft_nx, ft_ny, ft_nz);
+            }
             }
             slot(4, tb, Rb, 0.f, V0, extb);
 #ifndef LG_NO_PK_SPHERES
