@@ -591,13 +591,21 @@ def main():
     if gather is not None:
         gather.finish()
         gather.wait_s = gather.finish_s = 0.0
-    # roofline: the dominant kernel (physics) of every 8th step is bracketed by HIP events on the launch stream
-    env._engine.profile(args.kernel_timer_stride)
+    # roofline: the dominant kernel (physics) of every `--kernel-timer-stride`-th step is bracketed by HIP events on the launch stream.
+    # A timed launch is not free -- events attached to the dispatch cost ~10 us of bubble around it: stride 8 made the driver's 20-step
+    # regions 6 % slower (27.5 vs 25.9 us per step, same build) -- so with R >= 3 regions only the first (R - 1) // 2 carry the timer: the
+    # median region, which is what `value` reports, is then one without it, and the kernel is still timed live inside timed regions of this
+    # very run.  `roofline.timer` says which regions were sampled.
+    n_rep = max(args.repeats, 1)
+    timer_regions = list(range(n_rep)) if n_rep < 3 else list(range((n_rep - 1) // 2))
+    if args.kernel_timer_stride <= 0:
+        timer_regions = []
     # R timed regions of `--steps` steps each after the one warm-up, median reported.  A region is bracketed by a
     # barrier + synchronize on both sides and its time is the maximum over ranks, as the contract says for "the" timed region
     region_s, region_dev_ms = [], []
     step_i = args.warmup
     for rep in range(max(args.repeats, 1)):
+        env._engine.profile(args.kernel_timer_stride if rep in timer_regions else 0)     # stride 0 = off; samples taken so far are kept
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -666,6 +674,8 @@ def main():
                          "peak_measured": peak_meas, "frac_of_measured": (achieved / peak_meas) if peak_meas else None,
                          "peak_measured_how": "lg_stream_copy: float4 grid-stride copy of 1 GiB x 20 on this device, (read + write) bytes / time",
                          "kernel": layout, "launch_us": launch_s * 1e6, "samples": kern_n,
+                         "timer": {"stride": args.kernel_timer_stride, "sampled_regions": timer_regions, "regions": n_rep,
+                                   "note": "HIP events attached to the dispatch of every stride-th step, in the listed timed regions only (a timed launch costs ~10 us of bubble; the median region carries none when regions >= 3)"},
                          "step_device_us": dev_ms * 1e3 / args.steps,
                          "algorithmic_bytes_per_launch": bytes_env * n_local,
                          "valu": valu_roofline(wkey, launch_s, n_local)},
