@@ -24,6 +24,7 @@ int lg_fail_msg(const std::string &m) { return fail(m); }   // for the other tra
 struct LgEngine {
     LgModelDesc model; LgSimOptions opts; LgTaskCfg task;
     LgModelDesc *d_model = nullptr; LgSimOptions *d_opts = nullptr; LgTaskCfg *d_task = nullptr; LgHot *d_hot = nullptr;
+    float *d_lane = nullptr;
     const int16_t *hf = nullptr;
     LgBuffers bufs; bool bound = false;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
@@ -48,6 +49,11 @@ static int upload_hot(LgEngine *h) {
     if (!h->d_hot) { hipError_t e = hipMalloc(&h->d_hot, 1024); if (e != hipSuccess) return fail(std::string("hipMalloc(hot): ") + hipGetErrorString(e)); }
     HIPCHK(hipMemset(h->d_hot, 0, 1024));
     HIPCHK(hipMemcpy(h->d_hot, &hot, sizeof(LgHot), hipMemcpyHostToDevice));
+    // the lane table of the component-per-lane kernels follows the model and the options (lg_shared.h)
+    std::vector<float> lt(LG_LT_STG * 256);
+    lg_fill_lane_table(lt.data(), h->model, h->opts);
+    if (!h->d_lane) { hipError_t e = hipMalloc(&h->d_lane, lt.size() * sizeof(float)); if (e != hipSuccess) return fail(std::string("hipMalloc(lane table): ") + hipGetErrorString(e)); }
+    HIPCHK(hipMemcpy(h->d_lane, lt.data(), lt.size() * sizeof(float), hipMemcpyHostToDevice));
     return 0;
 }
 
@@ -114,7 +120,7 @@ extern "C" int lg_create(const LgModelDesc *model, const LgSimOptions *opts, con
 
 extern "C" int lg_destroy(LgHandle h) {
     if (!h) return 0;
-    (void)hipFree(h->d_model); (void)hipFree(h->d_opts); (void)hipFree(h->d_task); (void)hipFree(h->d_hot);
+    (void)hipFree(h->d_model); (void)hipFree(h->d_opts); (void)hipFree(h->d_task); (void)hipFree(h->d_hot); (void)hipFree(h->d_lane);
     if (h->ev0) (void)hipEventDestroy(h->ev0);
     if (h->ev1) (void)hipEventDestroy(h->ev1);
     for (hipEvent_t ev : h->prof_ev) (void)hipEventDestroy(ev);
@@ -267,7 +273,7 @@ static bool biped_profile(const LgEngine *h, bool inj = false) {
 
 template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, const float *actions, int64_t counter, hipStream_t st) {
     KParams p;
-    p.M = h->d_model; p.O = h->d_opts; p.T = h->d_task; p.H = h->d_hot; p.hf = h->hf; p.B = h->bufs; p.actions = actions; p.counter = counter;
+    p.M = h->d_model; p.O = h->d_opts; p.T = h->d_task; p.H = h->d_hot; p.LT = h->d_lane; p.hf = h->hf; p.B = h->bufs; p.actions = actions; p.counter = counter;
     p.jrot_identity = 1;
     {
         const LgHot &hot = h->hot;   // refreshed by upload_hot
@@ -276,9 +282,6 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
         p.k.obs_layout = hot.obs_layout; p.k.o_n_height_points = hot.o_n_height_points;
         p.k.reward_mask = (unsigned)hot.reward_mask; p.k.clip_actions = hot.clip_actions;
         p.k.cat_enable = h->task.cat_enable;
-        p.k.seed_lo = (unsigned)(hot.seed & 0xFFFFFFFFull); p.k.seed_hi = (unsigned)(hot.seed >> 32);
-        p.k.gid0_lo = (unsigned)((unsigned long long)hot.env_id_offset & 0xFFFFFFFFull); p.k.gid0_hi = (unsigned)((unsigned long long)hot.env_id_offset >> 32);
-        p.k.slots_reset_dof = hot.slots.reset_dof;
         p.k.joint_axis[3] = -1;
         for (int j = 0; j < JPL; j++) {
             int code = -2;

@@ -512,8 +512,15 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
 #define KB(T, f) KPTR(T, offsetof(KParams, B) + offsetof(LgBuffers, f))
 #define KINT(member) ((int)kdw((int)(offsetof(KParams, member) / 4)))
 #define KFLT(member) (__int_as_float((int)kdw((int)(offsetof(KParams, member) / 4))))
+    // Three-joint legs: the lane's model / option constants come from the host-built LANE TABLE (lg_shared.h: sixteen rows of 80 floats, staged
+    // by the wave, one row read per lane) instead of being derived from the staged model table on every launch (628 instructions).  The model
+    // table itself is staged only where something still walks it: four-joint legs, and the generic tail (env_step_body in the same launch).
+    constexpr bool USE_LT = JPL == 3;
+    constexpr bool NEED_M = !USE_LT || (MPH != 0 && !(((PROF == 1 || PROF == 2 || PROF == 3 || PROF == 4) && MPH == (LG_PHASE_POST | LG_PHASE_RESET)) ||
+                                                     (PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET))));
     const LgModelDesc GAS *Mg = KPTR(const LgModelDesc GAS *, offsetof(KParams, M));
-    __shared__ __attribute__((aligned(16))) uint4 sMraw[MODEL_STG * BLOCK];
+    __shared__ __attribute__((aligned(16))) uint4 sMraw[NEED_M ? MODEL_STG * BLOCK : 1];
+    __shared__ __attribute__((aligned(16))) uint4 sLT[USE_LT ? LG_LT_STG * BLOCK : 1];
     const LgModelDesc *M = reinterpret_cast<const LgModelDesc *>(sMraw);
     const LgSimOptions *__restrict__ O = p.O;
     __shared__ int sHot[256 + 2 * BLOCK];
@@ -522,13 +529,20 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
         const int GAS *hp = KPTR(const int GAS *, offsetof(KParams, H)) + (tl_ & 63);
         hv0 = hp[0]; hv1 = hp[64]; hv2 = hp[128]; hv3 = hp[192];
     }
-    uint4 stg0, stg1, stg2, stg3;
-    {
-        typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    uint4 stg0 = make_uint4(0u, 0u, 0u, 0u), stg1 = stg0, stg2 = stg0, stg3 = stg0, ltg[LG_LT_STG];
+    typedef unsigned int u4v __attribute__((ext_vector_type(4)));
+    if constexpr (NEED_M) {
         const u4v GAS *src = reinterpret_cast<const u4v GAS *>(Mg);
         const u4v a0 = src[tl_], a1 = src[tl_ + BLOCK], a2 = src[tl_ + 2 * BLOCK], a3 = src[tl_ + 3 * BLOCK];
         stg0 = make_uint4(a0.x, a0.y, a0.z, a0.w); stg1 = make_uint4(a1.x, a1.y, a1.z, a1.w);
         stg2 = make_uint4(a2.x, a2.y, a2.z, a2.w); stg3 = make_uint4(a3.x, a3.y, a3.z, a3.w);
+    }
+#pragma unroll
+    for (int k = 0; k < LG_LT_STG; k++) ltg[k] = make_uint4(0u, 0u, 0u, 0u);
+    if constexpr (USE_LT) {
+        const u4v GAS *src = KPTR(const u4v GAS *, offsetof(KParams, LT));
+#pragma unroll
+        for (int k = 0; k < LG_LT_STG; k++) { const u4v a = src[tl_ + k * BLOCK]; ltg[k] = make_uint4(a.x, a.y, a.z, a.w); }
     }
     const LgBuffers &B = p.B;
     unsigned long long _stamp0 = 0; (void)_stamp0;
@@ -616,7 +630,8 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
     const float dr_com = k_base_com_bias ? k_base_com_bias[3 * e + cj] : 0.f;
     const float dr_fric = k_friction_values ? k_friction_values[e] : 1.f;
     const float dr_kp = k_kp_scale ? k_kp_scale[ja] : 1.f, dr_kd = k_kd_scale ? k_kd_scale[ja] : 1.f;
-    const float gain_p = kO->kp[d0 + cjj], gain_d = kO->kd[d0 + cjj], q0 = kO->default_dof_pos[d0 + cjj];
+    float gain_p = 0.f, gain_d = 0.f, q0 = 0.f;      // three-joint legs: from the lane table, below
+    if constexpr (!USE_LT) { gain_p = kO->kp[d0 + cjj]; gain_d = kO->kd[d0 + cjj]; q0 = kO->default_dof_pos[d0 + cjj]; }
     float dr_arm = 0.f, dr_jf = 0.f, dr_jd = 0.f;
     if (k_joint_armature) { dr_arm = k_joint_armature[e]; dr_jf = k_joint_friction[e]; dr_jd = k_joint_damping[e]; }
     const float origin = k_env_origins ? k_env_origins[3 * e + cj] : 0.f;
@@ -722,19 +737,6 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
         wsv[c2++] = __int_as_float(((MPH & LG_PHASE_RESET) && k_obs_dirty) ? (int)k_obs_dirty[eL] : 0);
     }
 
-    // The every-step Philox call of the component-layout tails (observation noise / reset draws, below), issued HERE: its counter and key
-    // are kernel arguments and lane arithmetic, so its ~800 cycles run while the burst above is in flight instead of in the serial tail.
-    // (go2 on the plane only: in the larger tails the four words held across the sub-steps cost more -- go2_wtw +0.4, go2_ee +0.3, go2_ts +0.7 us --
-    // than the hidden call saves)
-    constexpr bool PHILOX_EARLY = FLAT && QTAIL && !INJ;
-    U4 rall_pre = {0u, 0u, 0u, 0u};
-    if constexpr (PHILOX_EARLY) {
-        const unsigned long long gid = (((unsigned long long)KINT(k.gid0_hi) << 32) | (unsigned)KINT(k.gid0_lo)) + (unsigned long long)(long long)e;
-        const U4 c = {(unsigned)(gid & 0xFFFFFFFFull), (unsigned)(gid >> 32), (unsigned)KINT(counter),
-                      L.is0 ? 0x80000000u + (unsigned)(2 * leg) : (L.is1 ? 0x80000000u + (unsigned)(2 * leg) + 1u
-                      : (L.is2 ? 0x40000000u + (unsigned)(KINT(k.slots_reset_dof) + d0) : 0x80000000u + 0x200u + (unsigned)leg))};
-        rall_pre = philox4x32_10(c, (unsigned)KINT(k.seed_lo), (unsigned)KINT(k.seed_hi));
-    }
     asm volatile("" ::: "memory");
     sHot[tl_] = hv0; sHot[tl_ + 64] = hv1; sHot[tl_ + 128] = hv2; sHot[tl_ + 192] = hv3;
     if (MPH != 0) {
@@ -749,7 +751,11 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             for (int k = LG_R_COUNT; k < NST - 1; k++) sStF[k * 16 + tl_] = wsv[k];
         }
     }
-    sMraw[tl_] = stg0; sMraw[tl_ + BLOCK] = stg1; sMraw[tl_ + 2 * BLOCK] = stg2; sMraw[tl_ + 3 * BLOCK] = stg3;
+    if constexpr (NEED_M) { sMraw[tl_] = stg0; sMraw[tl_ + BLOCK] = stg1; sMraw[tl_ + 2 * BLOCK] = stg2; sMraw[tl_ + 3 * BLOCK] = stg3; }
+    if constexpr (USE_LT) {
+#pragma unroll
+        for (int k = 0; k < LG_LT_STG; k++) sLT[tl_ + k * BLOCK] = ltg[k];
+    }
     if (DUO) __builtin_amdgcn_s_waitcnt(0x0F70);   // vmcnt(0): both waves hold everything they read before anything of the step is stored
     __syncthreads();
     STAMP(23);
@@ -791,15 +797,53 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
     TR.vscale = HOT(o_vscale); TR.hf = p.hf;
     constexpr bool HFC = PROF == 3 || PROF == 4 || PROF == 5 || PROF == 6;   // a heightfield is bound (host-checked: the rough task profiles of lg_host.hip; 5 = that and nothing else, generic tail)
     const bool hfmode = HFC ? true : (!PLANE && TR.rows > 0);
-    const float mass0 = M->mass[0] + dr_mass;
-    const float com0 = M->com[0][cj] + dr_com;
+    float lr[LT_USED];                          // this lane's row of the lane table (three-joint legs)
+#pragma unroll
+    for (int k = 0; k < LT_USED; k++) lr[k] = 0.f;
+    if constexpr (USE_LT) {
+        const float4 *row = reinterpret_cast<const float4 *>(sLT) + ei * (LG_LT_ROW / 4);     // ei = 4 leg + c: the lane's type
+#pragma unroll
+        for (int k = 0; k < LT_USED / 4; k++) { const float4 v = row[k]; lr[4 * k] = v.x; lr[4 * k + 1] = v.y; lr[4 * k + 2] = v.z; lr[4 * k + 3] = v.w; }
+        gain_p = lr[LT_KP]; gain_d = lr[LT_KD]; q0 = lr[LT_Q0];
+    }
     auto sym_row = [&](const float *s6) {   // rows of a symmetric 3x3 stored (xx, yy, zz, xy, xz, yz)
         QM r = {s6[L.is0 ? 0 : (L.is1 ? 3 : 4)], s6[L.is0 ? 3 : (L.is1 ? 1 : 5)], s6[L.is0 ? 4 : (L.is1 ? 5 : 2)]};
         return r;
     };
-    const QM I0 = sym_row(M->inertia[0]);
+    float mass0, com0, Lqlo, Lqhi, Leff, Lvlim, arm, jfric, jdamp, foot_c_loc, foot_r, foot_link_pos;
+    QM I0;
     float Lm[JPL], Lcom[JPL], Ljpos[JPL], Lax[JPL];
     QM LIc[JPL];
+    // collision spheres (foot excluded): five "slots", in each the four lanes of the quad test four different
+    // spheres of the SAME body in scalar form.  slot 0: hip, 1: thigh, 2-3: calf, 4: base (4 per quad); four-joint legs:
+    // 0: abad, 1: hip, 2: knee, 3: the sole corners of the foot body, 4: base
+    constexpr int NSLOT = 5;
+    float sx[NSLOT], sy[NSLOT], sz[NSLOT], srad[NSLOT], sden[NSLOT], sidw[NSLOT];   // sden = 1/(1 + kappa dt w), sidw = 1/(dt w)
+    float sole_w = 0.f;                        // sph_w of this lane's sole corner (four-joint legs: its inverse mass is formed per sub-step)
+    unsigned m_tmask, m_pmask, m_smask;        // link masks of the MDP tails
+    if constexpr (USE_LT) {
+        mass0 = lr[LT_MASS0] + dr_mass; com0 = lr[LT_COM0] + dr_com;
+        I0 = QM{lr[LT_I0], lr[LT_I0 + 1], lr[LT_I0 + 2]};
+#pragma unroll
+        for (int j = 0; j < JPL; j++) {
+            Lm[j] = lr[LT_M + j]; Lcom[j] = lr[LT_COM + j]; Ljpos[j] = lr[LT_JPOS + j]; Lax[j] = lr[LT_AX + j];
+            LIc[j] = QM{lr[LT_IC + 3 * j], lr[LT_IC + 3 * j + 1], lr[LT_IC + 3 * j + 2]};
+        }
+        Lqlo = lr[LT_QLO]; Lqhi = lr[LT_QHI]; Leff = lr[LT_EFF]; Lvlim = lr[LT_VLIM];
+        arm = B.joint_armature ? dr_arm : lr[LT_ARM];
+        jfric = B.joint_friction ? dr_jf : lr[LT_JFRIC];
+        jdamp = B.joint_damping ? dr_jd : lr[LT_JDAMP];
+        foot_c_loc = lr[LT_FOOT_C]; foot_r = lr[LT_FOOT_R]; foot_link_pos = lr[LT_LINKPOS];
+#pragma unroll
+        for (int k = 0; k < NSLOT; k++) {
+            sx[k] = lr[LT_SLOT + 6 * k]; sy[k] = lr[LT_SLOT + 6 * k + 1]; sz[k] = lr[LT_SLOT + 6 * k + 2];
+            srad[k] = lr[LT_SLOT + 6 * k + 3]; sden[k] = lr[LT_SLOT + 6 * k + 4]; sidw[k] = lr[LT_SLOT + 6 * k + 5];
+        }
+        m_tmask = __float_as_uint(lr[LT_TMASK]); m_pmask = __float_as_uint(lr[LT_PMASK]); m_smask = __float_as_uint(lr[LT_SMASK]);
+    } else {
+    mass0 = M->mass[0] + dr_mass;
+    com0 = M->com[0][cj] + dr_com;
+    I0 = sym_row(M->inertia[0]);
 #pragma unroll
     for (int j = 0; j < JPL; j++) {
         const int b = b0 + j;
@@ -807,21 +851,14 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
         LIc[j] = sym_row(M->inertia[b]);
     }
     // joint-lane constants
-    const float Lqlo = M->q_lo[d0 + cjj], Lqhi = M->q_hi[d0 + cjj], Leff = M->effort[d0 + cjj];
-    const float Lvlim = HOT(o_joint_vel_clamp) * M->vel_limit[d0 + cjj];
-    const float kps = dr_kp * gain_p, kds = dr_kd * gain_d;
-    const float arm = B.joint_armature ? dr_arm : M->armature[d0 + cjj];
-    const float jfric = B.joint_friction ? dr_jf : M->frictionloss[d0 + cjj];
-    const float jdamp = B.joint_damping ? dr_jd : M->damping[d0 + cjj];
+    Lqlo = M->q_lo[d0 + cjj]; Lqhi = M->q_hi[d0 + cjj]; Leff = M->effort[d0 + cjj];
+    Lvlim = HOT(o_joint_vel_clamp) * M->vel_limit[d0 + cjj];
+    arm = B.joint_armature ? dr_arm : M->armature[d0 + cjj];
+    jfric = B.joint_friction ? dr_jf : M->frictionloss[d0 + cjj];
+    jdamp = B.joint_damping ? dr_jd : M->damping[d0 + cjj];
     const int fs = leg == 0 ? HOT(m_foot_sphere[0]) : (leg == 1 ? HOT(m_foot_sphere[1]) : (leg == 2 ? HOT(m_foot_sphere[2]) : HOT(m_foot_sphere[3])));
-    const float foot_c_loc = M->sph_pos[fs][cj], foot_r = M->sph_r[fs];
-
-    // collision spheres (foot excluded): five "slots", in each the four lanes of the quad test four different
-    // spheres of the SAME body in scalar form.  slot 0: hip, 1: thigh, 2-3: calf, 4: base (4 per quad); four-joint legs:
-    // 0: abad, 1: hip, 2: knee, 3: the sole corners of the foot body, 4: base
-    constexpr int NSLOT = 5;
-    float sx[NSLOT], sy[NSLOT], sz[NSLOT], srad[NSLOT], sden[NSLOT], sidw[NSLOT];   // sden = 1/(1 + kappa dt w), sidw = 1/(dt w)
-    float sole_w = 0.f;                        // sph_w of this lane's sole corner (four-joint legs: its inverse mass is formed per sub-step)
+    foot_c_loc = M->sph_pos[fs][cj]; foot_r = M->sph_r[fs]; foot_link_pos = M->link_pos[foot_link][cj];
+    m_tmask = M->term_link_mask; m_pmask = M->pen_link_mask; m_smask = M->state_link_mask;
     {
         const int a0 = M->body_sph_start[b0], a1 = M->body_sph_start[b0 + 1], a2 = M->body_sph_start[b0 + 2], a3 = M->body_sph_start[b0 + 3];
         const int e0 = M->body_sph_start[0], e1 = M->body_sph_start[1];
@@ -854,6 +891,9 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             sidw[k] = 1.f / (dt * wi);
         }
     }
+    }
+    const float kps = dr_kp * gain_p, kds = dr_kd * gain_d;
+    (void)m_tmask; (void)m_pmask; (void)m_smask; (void)foot_link_pos;
 
     STAMP(24);
     float torque = 0.f;
@@ -1445,7 +1485,7 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             Rp = Rn;
             Pp = P;
         }
-        const float r = Pp + mulv(Rp, M->link_pos[foot_link][cj]);
+        const float r = Pp + mulv(Rp, foot_link_pos);
         foot_p = pos + r;
         foot_v = Vp.l + cross(Vp.a, r);
     }
@@ -1566,7 +1606,7 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
         }
     }
     if (!INJ && !PLANE && B.link_contact_states && live) {   // genesis_simulator.py:53-55
-        const unsigned mask = M->state_link_mask;
+        const unsigned mask = m_smask;
         const int l0 = foot_link - 3, nst = __popc(mask);
 #pragma unroll
         for (int k = 0; k < 4; k++) {
@@ -1796,7 +1836,7 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
         const float cmd0 = bc<0>(cmdv), cmd1 = bc<1>(cmdv), cmd2 = bc<2>(cmdv);
         STAMP(6);
         // ---- check_termination (legged_robot.py:78-92) ----
-        const unsigned tmask = M->term_link_mask, pmask = M->pen_link_mask;
+        const unsigned tmask = m_tmask, pmask = m_pmask;
         const int l0 = foot_link - 3;
         float n2[4];
 #pragma unroll
@@ -1921,8 +1961,8 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
         // leg's `_reset_dofs` block, lane 3: the env-level reset block 0x200 + leg.  A launch ends with its slowest wave, and that is
         // always one with a reset in it: with the reset draws inside the call every wave makes anyway, a reset costs no Philox call
         // (a call is ~800 cycles of quarter-rate multiplies).
-        U4 rall = rall_pre;         // go2 on the plane: evaluated under the start-of-kernel load burst (same counter, same key: see there)
-        if constexpr (!INJ && !PHILOX_EARLY)
+        U4 rall = {0u, 0u, 0u, 0u};      // (issuing this call under the start-of-kernel load burst paid 0.15 us for go2 until the lane table took the
+        if constexpr (!INJ)               //  registers it was hiding in: +0.3 us since, taken out)
             rall = philox(L.is0 ? 0x80000000u + (unsigned)(2 * leg) : (L.is1 ? 0x80000000u + (unsigned)(2 * leg) + 1u
                           : (L.is2 ? 0x40000000u + (unsigned)(h_slots_reset_dof + d0) : 0x80000000u + 0x200u + (unsigned)leg)));
         const float rux = u01(rall.x), ruy = u01(rall.y), ruz = u01(rall.z), ruw = u01(rall.w);
@@ -2110,7 +2150,7 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             // quad broadcasts outside the divergent branches
             const float env4 = L.sel4(o_fric - h_friction_offset, o_mass, bc<0>(o_push), bc<1>(o_push));
             const float pzn = bc<2>(pos);
-            const unsigned smask = M->state_link_mask;
+            const unsigned smask = m_smask;
             const int K = __popc(smask);
             const float csv = (L.sel4(n2[0], n2[1], n2[2], n2[3]) > 1.f) ? 1.f : 0.f;     // contact state of link l0 + c (physics read-back, stale after a reset as in the reference)
             const int cl_ = l0 + L.c;
@@ -2533,7 +2573,7 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
         const float cmd0 = bc<0>(cmdv), cmd1 = bc<1>(cmdv), cmd2 = bc<2>(cmdv);
         STAMP(6);
         // ---- check_termination (legged_robot.py:78-92) ----
-        const unsigned tmask = M->term_link_mask, pmask = M->pen_link_mask;
+        const unsigned tmask = m_tmask, pmask = m_pmask;
         const int l0 = foot_link - 3;
         float n2[4];
 #pragma unroll
@@ -2857,7 +2897,7 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             // quad broadcasts outside the divergent branches
             const float env4 = L.sel4(o_fric - h_friction_offset, o_mass, bc<0>(o_push), bc<1>(o_push));
             const float pzn = bc<2>(pos);
-            const unsigned smask = M->state_link_mask;
+            const unsigned smask = m_smask;
             const int K = __popc(smask);
             const float csv = (L.sel4(n2[0], n2[1], n2[2], n2[3]) > 1.f) ? 1.f : 0.f;     // contact state of link l0 + c (physics read-back, stale after a reset as in the reference)
             const int cl_ = l0 + L.c;

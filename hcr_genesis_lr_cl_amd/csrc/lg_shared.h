@@ -260,11 +260,82 @@ static void fill_hot(LgHot &H, const LgTaskCfg &t, const LgSimOptions &o, const 
     for (int i = 0; i < 2; i++) H.o_bound_y[i] = o.bound_y[i];
 }
 
+// ---- lane table of the component-per-lane kernels (lg_quad.h, three-joint legs) ----------------------------------------------------------
+// What a lane of type (leg, c) -- c: vector component / joint of the quad's lane -- needs of the model and of the options, row by row, laid out
+// by the host whenever either changes (lg_host.hip upload_hot).  The kernel used to derive these ~70 values per lane from the staged model
+// table on every launch: dependent LDS look-ups (body -> sphere range -> sphere), selects for the rows of the symmetric inertias, ten IEEE
+// divisions -- 628 instructions, 2.5 k of the go2 step's 51 k cycles.  Now the wave stages the sixteen rows (5.3 KB) and a lane reads its own.
+#ifndef LG_LT_ROW
+#define LG_LT_ROW 84          /* row stride in floats: 4 x odd, so that the sixteen rows' 16-byte reads spread over all LDS banks (stride 80 = 16 x 5
+                                 puts them on two bank groups: eight-way conflicts, +0.6 us on the go2 step) */
+#endif
+#define LG_LT_STG ((16 * LG_LT_ROW * 4 + 1023) / 1024)   /* uint4 per thread to stage 16 rows (64 threads x 16 B each) */
+enum LgLaneCol {
+    LT_M = 0,        /* 3: mass of the leg's bodies */
+    LT_COM = 3,      /* 3: their centre of mass, this lane's component */
+    LT_JPOS = 6,     /* 3: joint position in the parent frame, component */
+    LT_AX = 9,       /* 3: joint axis, component */
+    LT_IC = 12,      /* 9: row c of each body's rotational inertia */
+    LT_I0 = 21,      /* 3: row c of the base's */
+    LT_MASS0 = 24, LT_COM0 = 25,
+    LT_QLO = 26, LT_QHI = 27, LT_EFF = 28, LT_VLIM = 29, LT_ARM = 30, LT_JFRIC = 31, LT_JDAMP = 32,   /* this lane's joint (lane 3 shadows lane 2) */
+    LT_FOOT_C = 33, LT_FOOT_R = 34, LT_LINKPOS = 35,
+    LT_SLOT = 36,    /* 5 x (x, y, z, radius, 1 / (1 + kappa dt w), 1 / (dt w)): this lane's sphere of each collision slot */
+    LT_KP = 66, LT_KD = 67, LT_Q0 = 68,
+    LT_TMASK = 69, LT_PMASK = 70, LT_SMASK = 71,   /* link masks (bit patterns) */
+    LT_USED = 72
+};
+static_assert(LT_USED <= LG_LT_ROW && LG_LT_ROW % 4 == 0 && 16 * LG_LT_ROW * 4 <= LG_LT_STG * 64 * 16, "lane table geometry");
+inline void lg_fill_lane_table(float *t, const LgModelDesc &m, const LgSimOptions &o) {
+    for (int i = 0; i < LG_LT_STG * 256; i++) t[i] = 0.f;
+    const int legs = m.n_legs;
+    if (m.n_bodies != 1 + 3 * legs) return;       // four-joint legs keep the in-kernel derivation
+    const float dt = o.dt, kappa = o.contact_k * dt + o.contact_b;
+    auto bits = [](uint32_t u) { float f; memcpy(&f, &u, 4); return f; };
+    for (int leg = 0; leg < legs; leg++) for (int c = 0; c < 4; c++) {
+        float *r = t + ((leg << 2) | c) * LG_LT_ROW;
+        const int cj = c < 2 ? c : 2, b0 = 1 + 3 * leg, d0 = 3 * leg, dj = d0 + cj;
+        auto sym_row = [&](const float *s6, float *out) {   // row c (lane 3: row 2) of a symmetric 3x3 stored (xx, yy, zz, xy, xz, yz)
+            out[0] = s6[c == 0 ? 0 : (c == 1 ? 3 : 4)]; out[1] = s6[c == 0 ? 3 : (c == 1 ? 1 : 5)]; out[2] = s6[c == 0 ? 4 : (c == 1 ? 5 : 2)];
+        };
+        for (int j = 0; j < 3; j++) {
+            const int b = b0 + j;
+            r[LT_M + j] = m.mass[b]; r[LT_COM + j] = m.com[b][cj]; r[LT_JPOS + j] = m.jpos[b][cj]; r[LT_AX + j] = m.axis[b][cj];
+            sym_row(m.inertia[b], r + LT_IC + 3 * j);
+        }
+        sym_row(m.inertia[0], r + LT_I0);
+        r[LT_MASS0] = m.mass[0]; r[LT_COM0] = m.com[0][cj];
+        r[LT_QLO] = m.q_lo[dj]; r[LT_QHI] = m.q_hi[dj]; r[LT_EFF] = m.effort[dj]; r[LT_VLIM] = o.joint_vel_clamp * m.vel_limit[dj];
+        r[LT_ARM] = m.armature[dj]; r[LT_JFRIC] = m.frictionloss[dj]; r[LT_JDAMP] = m.damping[dj];
+        const int fs = m.foot_sphere[leg], fl = m.foot_link[leg];
+        r[LT_FOOT_C] = m.sph_pos[fs][cj]; r[LT_FOOT_R] = m.sph_r[fs]; r[LT_LINKPOS] = m.link_pos[fl][cj];
+        // collision slots (lg_quad.h): 0 hip, 1 thigh, 2-3 calf without the foot sphere, 4 base (four spheres per quad); lane c tests sphere c
+        const int a0 = m.body_sph_start[b0], a1 = m.body_sph_start[b0 + 1], a2 = m.body_sph_start[b0 + 2], a3 = m.body_sph_start[b0 + 3];
+        const int e0 = m.body_sph_start[0], e1 = m.body_sph_start[1];
+        int idx[5];
+        idx[0] = a0 + c < a1 ? a0 + c : -1;
+        idx[1] = a1 + c < a2 ? a1 + c : -1;
+        for (int k = 0; k < 2; k++) { int s = a2 + 4 * k + c; if (s >= fs) s++; idx[2 + k] = s < a3 ? s : -1; }
+        idx[4] = e0 + leg * 4 + c < e1 ? e0 + leg * 4 + c : -1;
+        for (int k = 0; k < 5; k++) {
+            const int s = idx[k] > 0 ? idx[k] : 0;
+            float *q = r + LT_SLOT + 6 * k;
+            const float wi = m.sph_w[s];
+            q[0] = m.sph_pos[s][0]; q[1] = m.sph_pos[s][1]; q[2] = m.sph_pos[s][2];
+            q[3] = idx[k] >= 0 ? m.sph_r[s] : -1e30f;        // an empty slot is infinitely far from any surface
+            q[4] = 1.f / (1.f + kappa * dt * wi); q[5] = 1.f / (dt * wi);
+        }
+        r[LT_KP] = o.kp[dj]; r[LT_KD] = o.kd[dj]; r[LT_Q0] = o.default_dof_pos[dj];
+        r[LT_TMASK] = bits(m.term_link_mask); r[LT_PMASK] = bits(m.pen_link_mask); r[LT_SMASK] = bits(m.state_link_mask);
+    }
+}
+
 struct KParams {
     const LgModelDesc *M;
     const LgSimOptions *O;
     const LgTaskCfg *T;
     const LgHot *H;
+    const float *LT;     // lane table (above)
     const int16_t *hf;
     LgBuffers B;
     const float *actions;
@@ -276,9 +347,6 @@ struct KParams {
     struct { int m_n_links, m_foot_link[4], obs_layout, o_n_height_points; unsigned reward_mask; float clip_actions;
              int cat_enable;      // LgTaskCfg.cat_enable: tested on every step, so not behind a memory round trip
              int joint_axis[4];   // per joint index: 0/1/2 if that joint's axis is +-e_x/e_y/e_z on every leg, else -1 (lg_quad.h joint_rot)
-             // what the every-step Philox call of the component-layout tails is keyed on: with these in the kernarg the call is issued
-             // UNDER the start-of-kernel load burst (its ~800 cycles of quarter-rate multiplies need nothing from memory)
-             unsigned seed_lo, seed_hi, gid0_lo, gid0_hi; int slots_reset_dof;
     } k;
     int obs_win;         // first frame of the observation window this launch writes (sliding history, LgTaskCfg.obs_slack)
     int obs_set;         // copy of obs_buf / priv_obs_buf / labels_buf this launch writes (LgTaskCfg.obs_sets)
