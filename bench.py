@@ -491,6 +491,9 @@ def main():
                          "times a few steps under each during the warm-up and runs the timed regions with the fastest (reported in `gather`)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--kernel-timer-stride", type=int, default=8, help="time the physics kernel of every n-th step (0 = off)")
+    ap.add_argument("--preroll", type=int, default=300,
+                    help="untimed env steps before the warm-up that take the freshly reset population (every robot standing) to the state "
+                         "mix of a long run (0 = off)")
     ap.add_argument("--task", default="go2", choices=list(WORKLOADS),
                     help="BASELINE config to run (the headline metric is go2; the others are reported under the same keys "
                          "with their own workload string)")
@@ -551,6 +554,14 @@ def main():
     def obs_outputs(out):      # every observation tensor step() returns: 5-tuple (obs, priv) or 6-tuple (features, labels, critic)
         return [o for o in out[:-3] if o is not None]
     widths = [int(o.shape[1]) for o in obs_outputs(env.step(bank[0]))]
+    # Population pre-roll (part of building the workload, like the random episode clocks above): every env starts standing, so under N(0,1)
+    # actions all n robots fall during the same first ~100 control steps -- a transient with every contact branch live at once, in which a
+    # step costs 23.3 us against 21.8 us once falls and resets are spread out (and 20.9 us while the robots still stand).  The default run
+    # (2000 steps after 100 of warm-up) is far behind it; a short one (the driver's --steps 20 --warmup 5) would sit right in it:
+    # 159.5 M env-steps/s against 171 / 174 M after 300 / 1000 steps.  Both runs should describe the same state mix, so the env is stepped
+    # `--preroll` times (default 300, ~7 ms) before the warm-up; the number is in the JSON line.
+    for i in range(max(args.preroll, 0)):
+        env.step(bank[i % len(bank)])
     gather = None
     gather_info = None
 
@@ -662,11 +673,11 @@ def main():
         layout = env._engine.last_kernel()
         out = {
             "metric": "env-steps/sec, Go2 flat 12-DOF, 4096 envs @1/2/4/8 MI355X" if args.task == "go2" else f"env-steps/sec, {args.task}",
-            "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup,
+            "value": value, "unit": "env-steps/s", "n_gpus": n_gpus, "steps": args.steps, "warmup": args.warmup, "preroll_steps": max(args.preroll, 0),
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
             "vs_baseline": None, "dtype": "f32", "data": "synthetic",
             "config": {"workload": f"{WORKLOADS[args.task]}, {n_local} envs per GPU, fused LeggedRobot.step "
-                                   f"(4 sub-steps dt=0.005) with synthetic N(0,1) actions",
+                                   f"(4 sub-steps dt=0.005) with synthetic N(0,1) actions" + (f", population pre-rolled {args.preroll} steps" if args.preroll > 0 else ""),
                        "envs_total": total_envs, "parallelism": f"env-shard x{world}" + (" [gloo rehearsal, ranks may share a GPU]" if world > 1 and args.backend == "gloo" else "") + ((f" + exchange of (obs, rew, done) of every step by {gather_info['mode']}, {gather_info['steps_per_exchange']} step(s) per exchange" + ("" if gather_info["mode"] == "rccl-sync" else ", overlapped with the following steps")) if gather_info else "")},
             "repeats": len(region_s), "repeats_ms_per_step": [x / args.steps * 1e3 for x in region_s],
             "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",

@@ -270,6 +270,14 @@ class PeerGather(StepGather):
         t0 = time.perf_counter()
         self.last_fill = self.batch
         if self.t % self.batch != 0:
+            # A partly filled batch travels compacted -- (world, fill, n_local, W), as the collective transports send it -- so rank r's rows
+            # lie where the FULL batches of lower ranks put theirs.  Nothing but this call orders the ranks' writes: a rank that is a whole
+            # batch ahead would have its flushed rows overwritten by a slower rank's earlier full batch into the same buffer pair.  So every
+            # rank's full batches land first (drain, barrier), then the flush goes out.
+            if self.copy_stream is not None:
+                self.copy_stream.synchronize()
+            if self.world > 1:
+                dist.barrier()
             self.last_fill = self.t % self.batch
             self._issue((self.t // self.batch) % 2, self.last_fill)
             self.t += self.batch - self.t % self.batch

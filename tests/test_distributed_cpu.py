@@ -69,6 +69,21 @@ def _worker(rank, world, port, q):
         assert gm_.wait_s >= 0.0 and gm_.finish_s > 0.0
         if hasattr(gm_, "close"):
             gm_.close()
+    # a rank that is a whole batch behind: the other one reaches finish() and flushes its partly filled batch first -- the flush must not go
+    # out before the slow rank's full batches have landed in the same buffer pair (compacted layout, distributed.PeerGather.finish)
+    import time
+    gs_ = make_gather("copy-engine", n, 5, world, "cpu", batch=3)
+    gs_.prime()
+    if rank == 0:
+        time.sleep(0.6)
+    outs_s = [gs_(obs + k, ids * (2 + k), (ids % 3 == 0).float()) for k in range(7)]
+    gs_.finish()
+    for rk in range(world):
+        o_k, n_k = shard(64, world, rk)
+        rec = gs_.step_view(outs_s[6], rk, 0, gs_.last_fill)
+        ids_k = torch.arange(o_k, o_k + n_k, dtype=torch.float32)
+        assert torch.allclose(rec[:, 5], ids_k * 8) and torch.allclose(rec[:, 0], ids_k + 6), ("late rank", rk)
+    gs_.close()
     # the ranks agree on the transport: each rank's slowest-rank times decide (rank 1 alone would have picked rccl-sync)
     mode, agreed = pick_fastest({"rccl": 30.0 + 10 * rank, "rccl-sync": 50.0 - 20 * rank, "copy-engine": 35.0})
     assert mode == "copy-engine" and agreed == {"rccl": 40.0, "rccl-sync": 50.0, "copy-engine": 35.0}, (mode, agreed)
