@@ -620,15 +620,20 @@ def main():
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
+        # device-side bracket of the region (step_device_us): two more packets on the queue, so -- like the kernel timer -- only in the regions
+        # that are sampled anyway (all of them when there are fewer than three)
+        dev_bracket = rep in timer_regions or not timer_regions
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         t0 = time.perf_counter()
-        ev0.record()           # torch's current stream == the stream lg_step launches on (engine.py)
+        if dev_bracket:
+            ev0.record()       # torch's current stream == the stream lg_step launches on (engine.py)
         for i in range(args.steps):
             one_step(step_i + i)
         step_i += args.steps
         if gather is not None:
             gather.finish()        # every record of the timed region has arrived before the clock stops
-        ev1.record()
+        if dev_bracket:
+            ev1.record()
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -638,7 +643,7 @@ def main():
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             el = float(t.item())
         region_s.append(el)
-        region_dev_ms.append(ev0.elapsed_time(ev1))
+        region_dev_ms.append(ev0.elapsed_time(ev1) if dev_bracket else None)
     if gather_info is not None:
         n_timed = args.steps * max(args.repeats, 1)
         gather_info.update({"step_us_with_gather": sorted(region_s)[len(region_s) // 2] / args.steps * 1e6,
@@ -648,7 +653,9 @@ def main():
                                     "completion to the arrival of every record (gather.finish()), both inside the timed regions"})
     order = sorted(range(len(region_s)), key=lambda k: region_s[k])
     mid = order[len(order) // 2]                     # the median region (upper median for an even count)
-    elapsed, dev_ms = region_s[mid], region_dev_ms[mid]
+    elapsed = region_s[mid]
+    dev_all = sorted(x for x in region_dev_ms if x is not None)
+    dev_ms = dev_all[len(dev_all) // 2]              # device-side bracket: median of the regions that carry one
     if rank == 0:
         total_envs = n_local * world
         value = total_envs * args.steps / elapsed
