@@ -906,6 +906,16 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
 
     STAMP(12);
     float nf_poison = 0.f;   // becomes NaN when an acceleration or a joint rate of any sub-step was not finite (read-back guard)
+    // SPLIT (the two-wave workgroups of the tron1_pf_ee step, DUO): the two waves used to run the SAME sub-steps side by side and only shared
+    // out the tail.  Now they share out the sub-step: both run the chain kinematics, then wave 0 does the body collision spheres (broad phase,
+    // heightfield lookups, forces) WHILE wave 1 does everything of the articulated-body pass that does not need a force (articulated
+    // inertias, joint factors, base inverse); wave 1 takes the forces through LDS, finishes the pass, the contact solve and the integration,
+    // and hands the new state back.  Two barriers per sub-step; the sphere section (a quarter of a sub-step) leaves the critical path.
+    // While wave 1 then runs the bias recursion, the base and pass 3, wave 0 -- idle otherwise -- forms the feet's operational-space matrices W from
+    // the joint factors and the base inverse wave 1 left in LDS, and hands them over at a third barrier.
+    constexpr bool SPLIT = DUO && !INJ;
+    const bool doA = !SPLIT || role == 0, doB = !SPLIT || role == 1;
+    __shared__ float sXch[SPLIT ? 12 * 64 : 1], sXw[SPLIT ? 21 * 64 : 1], sXa[SPLIT ? 3 * 64 : 1];
     for (int sub = 0; sub < decim; sub++) {
         const QM Rb = quat_rows(L, quat);
         QKin K[JPL];
@@ -945,7 +955,7 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
 #pragma unroll
         for (int j = 0; j < JPL; j++) ext[j] = QV6{0.f, 0.f};
         float ft_h = 0.f, ft_nx = 0.f, ft_ny = 0.f, ft_nz = 1.f;   // terrain under the foot sphere (looked up with the broad phase below, used in stage 2)
-        {
+        if (doA) {
             const float px = bc<0>(pos), py = bc<1>(pos), pz = bc<2>(pos);
             // broad phase of one slot: this lane's sphere of body (R, P); returns the penetration depth (and centre / terrain)
             struct Hit { float rx, ry, rz, h, nx, ny, nz, depth; bool on; };
@@ -1188,56 +1198,100 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
                 }
             }
         }
+        if constexpr (SPLIT) {
+            if (role == 0) {
 #pragma unroll
-        for (int j = 0; j < JPL; j++) f_link[j] = ext[j].l;
+                for (int j = 0; j < JPL; j++) { sXch[(2 * j) * 64 + tl_] = ext[j].a; sXch[(2 * j + 1) * 64 + tl_] = ext[j].l; }
+                sXch[6 * 64 + tl_] = extb.a; sXch[7 * 64 + tl_] = extb.l;
+                sXch[8 * 64 + tl_] = ft_h; sXch[9 * 64 + tl_] = ft_nx; sXch[10 * 64 + tl_] = ft_ny; sXch[11 * 64 + tl_] = ft_nz;
+            }
+        }
 
         if (sub == 0) STAMP(14);
         // ---- actuation (genesis_simulator.py:630-642), three joints at once ---------------------------
         torque = kps * (act * ascale + q0 - q) - kds * qd;
         const float tau = clampf(torque, -Leff, Leff) - jdamp * qd - jfric * clampf(qd * 20.f, -1.f, 1.f);
 
-        // ---- ABA pass 2 (leaf -> root) ------------------------------------------------------------
-        QI6 IA;
-        QV6 pacc;
+        // ---- ABA pass 2 (leaf -> root), first what needs no force: articulated inertias, joint factors, the inertia's share of the bias
+        //      recursion (IA c, U . c) ------------------------------------------------------------
+        QI6 IA, IA0, Inv;
+        QV6 pacc, Ic6[JPL];
         float dinvv = 0.f;      // 1/D of the joints in joint lanes
+        float cwj[JPL], ucj[JPL], cwb = 0.f;
+        QM Icwj[JPL], Icwb = {0.f, 0.f, 0.f};
+        if (doB) {
+#pragma unroll
+            for (int j = JPL - 1; j >= 0; j--) {
+                cwj[j] = K[j].P + mulv(K[j].R, Lcom[j]);
+                Icwj[j] = mulmmt(mulmm(K[j].R, LIc[j]), K[j].R);
+                const QI6 Ib = rigid(L, Lm[j], cwj[j], Icwj[j]);
+                if (j == JPL - 1) IA = Ib;
+                else IA = IA + Ib;
+                J[j].U = muli6(IA, J[j].S);
+                const float armj = bcj(arm, j);
+                J[j].dinv = rcp(dot6(J[j].S, J[j].U) + armj);
+                Ic6[j] = muli6(IA, J[j].c);
+                ucj[j] = dot6(J[j].U, J[j].c);
+                IA = rank1_down(IA, J[j].U, J[j].dinv);
+                { const float dj = j == 3 ? bc<0>(J[j].dinv) : J[j].dinv; if (L.c == j) dinvv = dj; }   // lane 3 holds no dot product of its own
+            }
+            // ---- base inertia and its inverse ----
+            IA0.A.c0 = legsum<LEGS>(IA.A.c0); IA0.A.c1 = legsum<LEGS>(IA.A.c1); IA0.A.c2 = legsum<LEGS>(IA.A.c2);
+            IA0.B.c0 = legsum<LEGS>(IA.B.c0); IA0.B.c1 = legsum<LEGS>(IA.B.c1); IA0.B.c2 = legsum<LEGS>(IA.B.c2);
+            IA0.Bt.c0 = legsum<LEGS>(IA.Bt.c0); IA0.Bt.c1 = legsum<LEGS>(IA.Bt.c1); IA0.Bt.c2 = legsum<LEGS>(IA.Bt.c2);
+            IA0.C.c0 = legsum<LEGS>(IA.C.c0); IA0.C.c1 = legsum<LEGS>(IA.C.c1); IA0.C.c2 = legsum<LEGS>(IA.C.c2);
+            cwb = mulv(Rb, com0);
+            Icwb = mulmmt(mulmm(Rb, I0), Rb);
+            IA0 = IA0 + rigid(L, mass0, cwb, Icwb);
+            Inv = inv6(L, IA0);
+        }
+        if constexpr (SPLIT) {
+            if (role == 1) {                  // what W is made of (besides the kinematics both waves hold): U_j, 1 / D_j, IA0^-1
+#pragma unroll
+                for (int j = 0; j < JPL; j++) { sXw[(3 * j) * 64 + tl_] = J[j].U.a; sXw[(3 * j + 1) * 64 + tl_] = J[j].U.l; sXw[(3 * j + 2) * 64 + tl_] = J[j].dinv; }
+                sXw[9 * 64 + tl_] = Inv.A.c0; sXw[10 * 64 + tl_] = Inv.A.c1; sXw[11 * 64 + tl_] = Inv.A.c2;
+                sXw[12 * 64 + tl_] = Inv.B.c0; sXw[13 * 64 + tl_] = Inv.B.c1; sXw[14 * 64 + tl_] = Inv.B.c2;
+                sXw[15 * 64 + tl_] = Inv.Bt.c0; sXw[16 * 64 + tl_] = Inv.Bt.c1; sXw[17 * 64 + tl_] = Inv.Bt.c2;
+                sXw[18 * 64 + tl_] = Inv.C.c0; sXw[19 * 64 + tl_] = Inv.C.c1; sXw[20 * 64 + tl_] = Inv.C.c2;
+            }
+            __syncthreads();                  // wave 0's forces and wave 1's factors are in LDS
+            if (role == 1) {
+#pragma unroll
+                for (int j = 0; j < JPL; j++) { ext[j].a = sXch[(2 * j) * 64 + tl_]; ext[j].l = sXch[(2 * j + 1) * 64 + tl_]; }
+                extb.a = sXch[6 * 64 + tl_]; extb.l = sXch[7 * 64 + tl_];
+                ft_h = sXch[8 * 64 + tl_]; ft_nx = sXch[9 * 64 + tl_]; ft_ny = sXch[10 * 64 + tl_]; ft_nz = sXch[11 * 64 + tl_];
+            }
+        }
+#pragma unroll
+        for (int j = 0; j < JPL; j++) f_link[j] = ext[j].l;
+        if (sub == 0) STAMP(15);
+        QV6 a0 = {0.f, 0.f}, a_calf = {0.f, 0.f};
+        float qdd = 0.f;
+        if (doB) {
+        // ---- ... then the bias recursion with the forces (same statements, same order as one interleaved pass) ----
 #pragma unroll
         for (int j = JPL - 1; j >= 0; j--) {
-            const float m = Lm[j];
-            const float cw = K[j].P + mulv(K[j].R, Lcom[j]);
-            const QM Icw = mulmmt(mulmm(K[j].R, LIc[j]), K[j].R);
+            const float m = Lm[j], cw = cwj[j];
             const QR cwr = rots(cw);
             const float vc = K[j].V.l + cross(K[j].Wr, cw);
             const float Pm = vc * m;
-            const float Lmo = mulv(Icw, K[j].V.a) + cross(cwr, Pm);
+            const float Lmo = mulv(Icwj[j], K[j].V.a) + cross(cwr, Pm);
             const float fg = gravc * m;
             QV6 pb;
             pb.a = cross(K[j].Wr, Lmo) + cross(K[j].V.l, Pm) - cross(cwr, fg) - ext[j].a;
             pb.l = cross(K[j].Wr, Pm) - fg - ext[j].l;
-            const QI6 Ib = rigid(L, m, cw, Icw);
-            if (j == JPL - 1) { IA = Ib; pacc = pb; }
-            else { IA = IA + Ib; pacc = pacc + pb; }
-            J[j].U = muli6(IA, J[j].S);
-            const float armj = bcj(arm, j), tauj = bcj(tau, j);
-            J[j].dinv = rcp(dot6(J[j].S, J[j].U) + armj);
+            if (j == JPL - 1) pacc = pb;
+            else pacc = pacc + pb;
+            const float tauj = bcj(tau, j);
             J[j].u = tauj - dot6(J[j].S, pacc);
-            const QV6 Ic6 = muli6(IA, J[j].c);
-            const float k = (J[j].u - dot6(J[j].U, J[j].c)) * J[j].dinv;
-            pacc = pacc + Ic6 + J[j].U * k;
-            IA = rank1_down(IA, J[j].U, J[j].dinv);
-            { const float dj = j == 3 ? bc<0>(J[j].dinv) : J[j].dinv; if (L.c == j) dinvv = dj; }   // lane 3 holds no dot product of its own
+            const float k = (J[j].u - ucj[j]) * J[j].dinv;
+            pacc = pacc + Ic6[j] + J[j].U * k;
         }
-        if (sub == 0) STAMP(15);
         // ---- base ---------------------------------------------------------------------------------
-        QI6 IA0;
-        IA0.A.c0 = legsum<LEGS>(IA.A.c0); IA0.A.c1 = legsum<LEGS>(IA.A.c1); IA0.A.c2 = legsum<LEGS>(IA.A.c2);
-        IA0.B.c0 = legsum<LEGS>(IA.B.c0); IA0.B.c1 = legsum<LEGS>(IA.B.c1); IA0.B.c2 = legsum<LEGS>(IA.B.c2);
-        IA0.Bt.c0 = legsum<LEGS>(IA.Bt.c0); IA0.Bt.c1 = legsum<LEGS>(IA.Bt.c1); IA0.Bt.c2 = legsum<LEGS>(IA.Bt.c2);
-        IA0.C.c0 = legsum<LEGS>(IA.C.c0); IA0.C.c1 = legsum<LEGS>(IA.C.c1); IA0.C.c2 = legsum<LEGS>(IA.C.c2);
         QV6 p0 = {legsum<LEGS>(pacc.a - extb.a), legsum<LEGS>(pacc.l - extb.l)};
         {
-            const float cw = mulv(Rb, com0);
-            const QM Icw = mulmmt(mulmm(Rb, I0), Rb);
-            IA0 = IA0 + rigid(L, mass0, cw, Icw);
+            const float cw = cwb;
+            const QM Icw = Icwb;
             const QR wr = rots(ww), cwr = rots(cw);
             const float vc = vw + cross(wr, cw);
             const float Pm = vc * mass0;
@@ -1246,12 +1300,9 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             p0.a += cross(wr, Lmo) + cross(vw, Pm) - cross(cwr, fg);
             p0.l += cross(wr, Pm) - fg;
         }
-        const QI6 Inv = inv6(L, IA0);
-        QV6 a0 = muli6(Inv, QV6{-p0.a, -p0.l});
+        a0 = muli6(Inv, QV6{-p0.a, -p0.l});
         if (sub == 0) STAMP(16);
         // ---- pass 3 (root -> leaf) ----------------------------------------------------------------
-        float qdd;
-        QV6 a_calf;
         {
             QV6 a = a0;
             float gj[JPL];
@@ -1261,11 +1312,11 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             a_calf = a;
         }
         if (sub == 0) STAMP(17);
+        }   // doB (bias recursion, base, pass 3)
         // ---- stage 2: foot contact (exact 3x3 W) + joint-limit stops, block-Jacobi ----------------------
-        float fc = 0.f;                       // foot force in the contact frame (n, t1, t2), component layout
-        float cn, ct1 = L.d0, ct2 = L.d1, cp, depth;
-        bool fact;
-        {
+        float cn = 0.f, ct1 = L.d0, ct2 = L.d1, cp = 0.f, depth = 0.f;
+        bool fact = false;
+        auto contact_frame = [&]() {
             const float r = K[JPL - 1].P + mulv(K[JPL - 1].R, foot_c_loc);
             float h = ft_h, nx = ft_nx, ny = ft_ny, nz = ft_nz;
             if (!HFC) terrain<HFC>(TR, bc<0>(pos) + bc<0>(r), bc<1>(pos) + bc<1>(r), h, nx, ny, nz);
@@ -1281,7 +1332,52 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
                 const float t2 = cross(cn, t1);      // formed outside the conditional (cross-lane reads: see the note at the top)
                 ct2 = tilt ? t2 : ct2;
             }
+        };
+        // dt * W, contact frame, rows.  W_rk = f_r . (acceleration the robot answers f_k with), f_k the unit force along contact axis k at the
+        // contact point.  The articulated-body passes are an L D L^T factorisation of the inverse inertia, so with the UPWARD pass of each unit
+        // force alone (joint residuals du_j, force left at the base p) W = sum_j du_j du_j^T / D_j + P^T IA0^-1 P: no downward passes, no point
+        // accelerations -- the three resp_down chains were the longest dependent stretch of this section.  (Checked against the two-pass form on
+        // random chains to 1e-16 in double; the CPU oracle and the leg-per-lane kernel keep the two-pass form.)
+        auto w_columns = [&](const QR &cpr) {
+            const float axs[3] = {cn, ct1, ct2};
+            float du[3][JPL];
+            QV6 pk[3], qk[3];
+#pragma unroll
+            for (int k = 0; k < 3; k++) {
+                const QV6 fsp = {cross(cpr, axs[k]), axs[k]};
+                pk[k] = resp_up(J, fsp, 0.f, du[k]);
+                qk[k] = muli6(Inv, pk[k]);
+            }
+            const float D00 = dot6(pk[0], qk[0]), D01 = dot6(pk[0], qk[1]), D02 = dot6(pk[0], qk[2]);
+            const float D11 = dot6(pk[1], qk[1]), D12 = dot6(pk[1], qk[2]), D22 = dot6(pk[2], qk[2]);
+            float col[3] = {L.sel(D00, D01, D02), L.sel(D01, D11, D12), L.sel(D02, D12, D22)};   // row r in lane r; symmetric by construction
+#pragma unroll
+            for (int j = 0; j < JPL; j++) {
+                const float us = L.sel(du[0][j], du[1][j], du[2][j]) * J[j].dinv;
+                col[0] += us * du[0][j]; col[1] += us * du[1][j]; col[2] += us * du[2][j];
+            }
+            QM w = {dt * col[0], dt * col[1], dt * col[2]};
+            return w;
+        };
+        const bool w_refresh = w_every <= 1 || (sub % w_every) == 0;   // wave-uniform: W of every foot is recomputed on these sub-steps
+        if constexpr (SPLIT) {
+            if (role == 0 && w_refresh) {     // wave 0, otherwise idle until the new state arrives: W from wave 1's factors
+#pragma unroll
+                for (int j = 0; j < JPL; j++) { J[j].U.a = sXw[(3 * j) * 64 + tl_]; J[j].U.l = sXw[(3 * j + 1) * 64 + tl_]; J[j].dinv = sXw[(3 * j + 2) * 64 + tl_]; }
+                Inv.A.c0 = sXw[9 * 64 + tl_]; Inv.A.c1 = sXw[10 * 64 + tl_]; Inv.A.c2 = sXw[11 * 64 + tl_];
+                Inv.B.c0 = sXw[12 * 64 + tl_]; Inv.B.c1 = sXw[13 * 64 + tl_]; Inv.B.c2 = sXw[14 * 64 + tl_];
+                Inv.Bt.c0 = sXw[15 * 64 + tl_]; Inv.Bt.c1 = sXw[16 * 64 + tl_]; Inv.Bt.c2 = sXw[17 * 64 + tl_];
+                Inv.C.c0 = sXw[18 * 64 + tl_]; Inv.C.c1 = sXw[19 * 64 + tl_]; Inv.C.c2 = sXw[20 * 64 + tl_];
+                contact_frame();
+                const QM w = w_columns(rots(cp));
+                sXa[tl_] = w.c0; sXa[64 + tl_] = w.c1; sXa[128 + tl_] = w.c2;
+            }
+            __syncthreads();                  // W is in LDS
+            if (role == 1 && w_refresh) { Ac_keep.c0 = sXa[tl_]; Ac_keep.c1 = sXa[64 + tl_]; Ac_keep.c2 = sXa[128 + tl_]; }
         }
+        if (doB) {
+        float fc = 0.f;                       // foot force in the contact frame (n, t1, t2), component layout
+        contact_frame();
         float lim_e = 0.f, lim_s = 0.f, lim_T = 0.f;
         if (JPL == 4 || !L.is3) {
             if (q < Lqlo + lmargin) { lim_s = 1.f; lim_e = Lqlo - q; }
@@ -1289,7 +1385,6 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
         }
         float dqdd = 0.f;
         QV6 da0 = {0.f, 0.f};
-        const bool w_refresh = w_every <= 1 || (sub % w_every) == 0;   // wave-uniform: W of every foot is recomputed on these sub-steps
         if (w_refresh || __builtin_amdgcn_ballot_w64(fact || lim_s != 0.f) != 0ull) {
             // contact-frame projector: row r of E = axis r (n, t1, t2)
             QM E;
@@ -1298,31 +1393,7 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             E.c2 = L.sel(bc<2>(cn), bc<2>(ct1), bc<2>(ct2));
             const QM ET = {cn, ct1, ct2};
             const QR cpr = rots(cp);          // the contact point enters every product below
-            if (w_refresh) {      // dt * W, contact frame, rows
-                // W_rk = f_r . (acceleration the robot answers f_k with), f_k the unit force along contact axis k at the contact point.  The
-                // articulated-body passes are an L D L^T factorisation of the inverse inertia, so with the UPWARD pass of each unit force
-                // alone (joint residuals du_j, force left at the base p) W = sum_j du_j du_j^T / D_j + P^T IA0^-1 P: no downward passes, no
-                // point accelerations -- the three resp_down chains were the longest dependent stretch of this section.  (Checked against the
-                // two-pass form on random chains to 1e-16 in double; the CPU oracle and the leg-per-lane kernel keep the two-pass form.)
-                const float axs[3] = {cn, ct1, ct2};
-                float du[3][JPL];
-                QV6 pk[3], qk[3];
-#pragma unroll
-                for (int k = 0; k < 3; k++) {
-                    const QV6 fsp = {cross(cpr, axs[k]), axs[k]};
-                    pk[k] = resp_up(J, fsp, 0.f, du[k]);
-                    qk[k] = muli6(Inv, pk[k]);
-                }
-                const float D00 = dot6(pk[0], qk[0]), D01 = dot6(pk[0], qk[1]), D02 = dot6(pk[0], qk[2]);
-                const float D11 = dot6(pk[1], qk[1]), D12 = dot6(pk[1], qk[2]), D22 = dot6(pk[2], qk[2]);
-                float col[3] = {L.sel(D00, D01, D02), L.sel(D01, D11, D12), L.sel(D02, D12, D22)};   // row r in lane r; symmetric by construction
-#pragma unroll
-                for (int j = 0; j < JPL; j++) {
-                    const float us = L.sel(du[0][j], du[1][j], du[2][j]) * J[j].dinv;
-                    col[0] += us * du[0][j]; col[1] += us * du[1][j]; col[2] += us * du[2][j];
-                }
-                Ac_keep.c0 = dt * col[0]; Ac_keep.c1 = dt * col[1]; Ac_keep.c2 = dt * col[2];
-            }
+            if (w_refresh && !SPLIT) Ac_keep = w_columns(cpr);
             const QM Ac = Ac_keep;
             float vfree;
             {
@@ -1408,6 +1479,20 @@ __global__ __launch_bounds__(PROF == 6 && MPH == (LG_PHASE_POST | LG_PHASE_RESET
             const float dxq = cross(d, quat);                   // outside the conditional (cross-lane reads)
             const float nq = chh * quat + (L.is3 ? -dv : qw_b * d + dxq);
             quat = nq * rsqrtf(sum4(nq * nq));
+        }
+        }   // doB
+        if constexpr (SPLIT) {
+            // wave 1 hands the new state (and what the read-back needs of the contact solve) to wave 0; both continue with the same values
+            if (role == 1) {
+                sXch[0 * 64 + tl_] = q; sXch[1 * 64 + tl_] = qd; sXch[2 * 64 + tl_] = pos; sXch[3 * 64 + tl_] = quat; sXch[4 * 64 + tl_] = vw;
+                sXch[5 * 64 + tl_] = ww; sXch[6 * 64 + tl_] = f_link[3]; sXch[7 * 64 + tl_] = nf_poison; sXch[8 * 64 + tl_] = extb.l;
+            }
+            __syncthreads();
+            if (role == 0) {
+                q = sXch[0 * 64 + tl_]; qd = sXch[1 * 64 + tl_]; pos = sXch[2 * 64 + tl_]; quat = sXch[3 * 64 + tl_]; vw = sXch[4 * 64 + tl_];
+                ww = sXch[5 * 64 + tl_]; f_link[3] = sXch[6 * 64 + tl_]; nf_poison = sXch[7 * 64 + tl_];
+            }
+            // (no third barrier: the next writes into the buffer are wave 0's own, behind its reads above; wave 1 reads them behind the next barrier)
         }
         if (sub == 0) STAMP(20);
         f_base = legsum<LEGS>(extb.l);
