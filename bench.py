@@ -604,11 +604,11 @@ def main():
         gather.wait_s = gather.finish_s = 0.0
     # roofline: the dominant kernel (physics) of every `--kernel-timer-stride`-th step is bracketed by HIP events on the launch stream.
     # A timed launch is not free -- events attached to the dispatch cost ~10 us of bubble around it: stride 8 made the driver's 20-step
-    # regions 6 % slower (27.5 vs 25.9 us per step, same build) -- so with R >= 3 regions only the first (R - 1) // 2 carry the timer: the
-    # median region, which is what `value` reports, is then one without it, and the kernel is still timed live inside timed regions of this
+    # regions 6 % slower (27.5 vs 25.9 us per step, same build) -- so with R >= 3 regions only the FIRST carries the timer (it is the slowest
+    # anyway: first dispatches after the warm-up): the median region, which is what `value` reports, is then one of at least four without it, and the kernel is still timed live inside timed regions of this
     # very run.  `roofline.timer` says which regions were sampled.
     n_rep = max(args.repeats, 1)
-    timer_regions = list(range(n_rep)) if n_rep < 3 else list(range((n_rep - 1) // 2))
+    timer_regions = list(range(n_rep)) if n_rep < 3 else [0]
     if args.kernel_timer_stride <= 0:
         timer_regions = []
     # R timed regions of `--steps` steps each after the one warm-up, median reported.  A region is bracketed by a
