@@ -23,8 +23,8 @@ OUT = os.environ.get("LG_BUILD_OUT") or os.path.join(CSRC, "liblgsim.so")
 OBJ = os.path.join(CSRC, "obj" if "LG_BUILD_OUT" not in os.environ else "obj_" + os.path.splitext(os.path.basename(OUT))[0])
 LLVM_BIN = os.environ.get("LG_LLVM_BIN", "/opt/rocm/lib/llvm/bin")
 DPP_PASS = os.environ.get("LG_NO_DPP_PASS", "0") != "1"
-N_GROUPS = 20
-QUAD_GROUPS = list(range(0, 9)) + list(range(17, 20))   # lg_inst.hip: groups that include lg_quad.h
+N_GROUPS = 22
+QUAD_GROUPS = list(range(0, 9)) + list(range(17, 22))   # lg_inst.hip: groups that include lg_quad.h
 COMMON = ["lg_shared.h", "lg_math.h", os.path.join(INC, "lgsim.h")]
 # -fno-slp-vectorize: packing scalars into v_pk_* costs more v_mov / AGPR shuffles than it saves here.
 # iterative-ilp scheduling: the kernels run one wave per SIMD, so occupancy is irrelevant and the scheduler should fill DPP /

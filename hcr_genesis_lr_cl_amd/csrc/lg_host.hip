@@ -372,8 +372,8 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
             auto rs = [&](int prof) { return (unsigned)h->hot.reward_mask == lg_default_reward_mask(prof) && !(rse && atoi(rse) == 0); };
             if (fuse && rest == PR && flat_profile(h)) { if (rs(1)) LG_LAUNCH(pi, (lg_launch_quad_rs<4, 1, false>), qgrid); else LG_LAUNCH(pi, (lg_launch_quad<4, true, PR, 1, 3>), qgrid); }
             else if (fuse && rest == PR && wtw_profile(h)) { if (rs(2)) LG_LAUNCH(pi, (lg_launch_quad_rs<4, 2, false>), qgrid); else LG_LAUNCH(pi, (lg_launch_quad<4, true, PR, 2, 3>), qgrid); }
-            else if (fuse && rest == PR && rough_profile(h) == 3) LG_LAUNCH(pi, (lg_launch_quad<4, true, PR, 3, 3>), qgrid);
-            else if (fuse && rest == PR && rough_profile(h) == 4) LG_LAUNCH(pi, (lg_launch_quad<4, true, PR, 4, 3>), qgrid);
+            else if (fuse && rest == PR && rough_profile(h) == 3) { if (rs(3)) LG_LAUNCH(pi, (lg_launch_quad_rs<4, 3, false>), qgrid); else LG_LAUNCH(pi, (lg_launch_quad<4, true, PR, 3, 3>), qgrid); }
+            else if (fuse && rest == PR && rough_profile(h) == 4) { if (rs(4)) LG_LAUNCH(pi, (lg_launch_quad_rs<4, 4, false>), qgrid); else LG_LAUNCH(pi, (lg_launch_quad<4, true, PR, 4, 3>), qgrid); }
             else if (fuse && rest == PR) LG_LAUNCH(pi, (lg_launch_quad<4, true, PR, 0, 3>), qgrid);
             else if (fuse && rest == LG_PHASE_POST) LG_LAUNCH(pi, (lg_launch_quad<4, true, LG_PHASE_POST, 0, 3>), qgrid);
         } else {
@@ -421,8 +421,8 @@ template <int LEGS, int JPL = 3> static int launch(LgEngine *h, uint32_t ph, con
                             else { h->last_kernel = "(lg_launch_quad_inj<" #L_ ", " #P_ ">)"; lg_launch_quad_inj<L_, P_>(qgrid, st, p); } } while (0)
             if (flat_profile(h, true)) LG_INJ(4, 1);
             else if (wtw_profile(h, true)) LG_INJ(4, 2);
-            else if (rp == 3) { h->last_kernel = "(lg_launch_quad_inj<4, 3>)"; lg_launch_quad_inj<4, 3>(qgrid, st, p); }
-            else if (rp == 4) { h->last_kernel = "(lg_launch_quad_inj<4, 4>)"; lg_launch_quad_inj<4, 4>(qgrid, st, p); }
+            else if (rp == 3) LG_INJ(4, 3);
+            else if (rp == 4) LG_INJ(4, 4);
             else done = false;
 #undef LG_INJ
         } else {

@@ -1,12 +1,12 @@
 // lg_inst.hip -- the kernel instantiations of the library, compiled once per GROUP (hipcc -DLG_GROUP=g ... -c, the groups in parallel;
 // hcr_genesis_lr_cl_amd/build.py).  One translation unit holding all of them took over three minutes to build; a group is a
-// handful of kernels that share template parameters.  Groups 0-8 and 17-19 hold the component-per-lane kernels (lg_quad.h), groups 9-16 the
+// handful of kernels that share template parameters.  Groups 0-8 and 17-21 hold the component-per-lane kernels (lg_quad.h), groups 9-16 the
 // leg-per-lane ones (lg_kernel.h) and do not include lg_quad.h, so an edit there leaves their objects valid.
 //
 // The host side (lg_host.hip) calls the launchers declared in lg_shared.h; every instantiation it names must appear in exactly
 // one group below (a missing one is a link error, not a run-time surprise).
 #ifndef LG_GROUP
-#error "compile with -DLG_GROUP=<0..19> (hcr_genesis_lr_cl_amd/build.py)"
+#error "compile with -DLG_GROUP=<0..21> (hcr_genesis_lr_cl_amd/build.py)"
 #endif
 #include "lg_kernel.h"
 #if LG_GROUP < 9 || LG_GROUP >= 17
@@ -87,6 +87,10 @@ QUAD_INJ(4, 1) QUAD_INJ(4, 2) QUAD_INJ(4, 3) QUAD_INJ(4, 4) QUAD_INJ(2, 6)
 QUAD_RS(4, 1, false) QUAD_RS(4, 2, false)
 #elif LG_GROUP == 19   // ... on injected read-backs (golden replays)
 QUAD_RS(4, 1, true) QUAD_RS(4, 2, true)
+#elif LG_GROUP == 20   // go2_ee, the go2 rough heads
+QUAD_RS(4, 3, false) QUAD_RS(4, 4, false)
+#elif LG_GROUP == 21   // ... on injected read-backs
+QUAD_RS(4, 3, true) QUAD_RS(4, 4, true)
 #else
 #error "LG_GROUP out of range"
 #endif

@@ -364,9 +364,9 @@ void lg_launch_env(dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, cons
 template <int LEGS, int PROF>
 void lg_launch_quad_inj(dim3 grid, hipStream_t st, const KParams &p);
 // The reward sets of the reference's own task configs (bit k: term k of include/lgsim.h LgReward has a non-zero scale), by task profile:
-// go2 (legged_gym/envs/go2/go2_config.py) and go2_wtw.  A task whose set equals its profile's runs the instantiation that has it as a
-// compile-time constant (lg_quad.h RS): whole step (INJ = false) or the golden-replay form (INJ = true).  (Measured for the other
-// profiles too -- go2_ee and the rough heads 0x242a6567, tron1_pf_ee 0x2cb38577: +-0.1 us, not kept.)
-constexpr unsigned lg_default_reward_mask(int prof) { return prof == 1 ? 0x26a2296fu : (prof == 2 ? 0x7f2c0967u : 0u); }
+// go2 (legged_gym/envs/go2/go2_config.py), go2_wtw, go2_ee and the go2 rough heads (one set).  A task whose set equals its profile's runs
+// the instantiation that has it as a compile-time constant (lg_quad.h RS): whole step (INJ = false) or the golden-replay form (INJ = true).
+// (tron1_pf_ee, 0x2cb38577: +-0.1 us, not kept.)
+constexpr unsigned lg_default_reward_mask(int prof) { return prof == 1 ? 0x26a2296fu : (prof == 2 ? 0x7f2c0967u : ((prof == 3 || prof == 4) ? 0x242a6567u : 0u)); }
 template <int LEGS, int PROF, bool INJ>
 void lg_launch_quad_rs(dim3 grid, hipStream_t st, hipEvent_t e0, hipEvent_t e1, const KParams &p);

@@ -614,7 +614,7 @@ def test_baseline_config_full_size_properties(task, n_local, n_global, offset):
     assert len(a) == len(b) and all(torch.equal(x, y) for x, y in zip(a, b))
 
 
-@pytest.mark.parametrize("task", ["go2", "go2_wtw"])
+@pytest.mark.parametrize("task", ["go2", "go2_wtw", "go2_ee", "go2_ts"])
 def test_constant_reward_set_instantiation_equals_the_general_one(task, monkeypatch):
     """A task whose reward set is its profile's default runs the instantiation that has the set as a compile-time constant (lg_quad.h RS,
     lg_host.hip); LG_REWARD_SET_CONST=0 sends the same task through the general instantiation.  Both step from the same state every step
