@@ -250,6 +250,8 @@ def load_lib():
     lib.lg_profile_read.argtypes = [H, C.POINTER(C.c_float), C.POINTER(i32)]
     lib.lg_philox.argtypes = [C.POINTER(u32 * 4), C.POINTER(u32 * 2), C.POINTER(u32 * 4)]
     lib.lg_philox.restype = C.c_int
+    lib.lg_dpp_kat.argtypes = [C.POINTER(C.c_float), C.POINTER(C.c_float)]
+    lib.lg_dpp_kat.restype = C.c_int
     lib.lg_stream_copy.argtypes = [C.c_void_p, C.c_void_p, i64, i32, C.c_void_p, C.POINTER(C.c_float)]
     lib.lg_stream_copy.restype = C.c_int
     lib.lg_terrain_generate.argtypes = [C.c_void_p, i32, C.c_void_p, C.c_void_p, C.c_void_p, i32, i32, i32, i32, i32, i32, C.c_double, C.c_void_p, C.c_void_p]
@@ -271,7 +273,7 @@ def load_lib():
 
 
 EXPORTS = ["lg_create", "lg_destroy", "lg_set_task", "lg_set_terrain", "lg_bind", "lg_step",
-           "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_obs_set_select", "lg_obs_window_select", "lg_profile", "lg_profile_read", "lg_philox", "lg_stream_copy", "lg_terrain_generate", "lg_last_kernel", "lg_last_error",
+           "lg_time_steps", "lg_obs_window", "lg_obs_set", "lg_obs_set_select", "lg_obs_window_select", "lg_profile", "lg_profile_read", "lg_philox", "lg_dpp_kat", "lg_stream_copy", "lg_terrain_generate", "lg_last_kernel", "lg_last_error",
            "lg_abi_version"]
 ROLLOUT_EXPORTS = ["lg_rollout_record", "lg_rollout_gae"]          # include/lgrollout.h
 ROLLOUT_MAX_COPIES = 8

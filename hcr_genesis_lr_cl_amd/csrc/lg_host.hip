@@ -646,6 +646,45 @@ extern "C" int lg_philox(const uint32_t counter[4], const uint32_t key[2], uint3
     return 0;
 }
 
+// DPP operand known-answer test (tests/test_gpu_dpp_operands.py): the behaviour of THIS chip that hcr_genesis_lr_cl_amd/dpp_hazard_pass.py builds on.
+// The rule "VALU writes a VGPR -> DPP read: two wait states" concerns the DPP-routed source (src0) only; a plain operand (src1) or the
+// accumulator of a DPP multiply-add written in the slot before is forwarded like for any VALU instruction -- cases 0 and 1, no wait state, must
+// be exact.  Case 2: a fresh DPP source behind `s_nop 1` -- exact.  Case 3: the same without the nop -- the negative control, reported, not
+// required either way (it reads whatever the register held before: here a NaN).  This file is compiled with plain hipcc: the pass never sees it.
+__global__ void dpp_kat_kernel(const float *in, float *out) {
+    const int t = threadIdx.x;
+    const float x = in[t], y = in[64 + t];
+    float a, r0, r1, r2, r3;
+    asm volatile(
+        "s_nop 4\n\t"
+        "v_mul_f32_e32 %0, %5, %6\n\t"
+        "v_add_f32_dpp %1, %5, %0 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_e32 %2, %5, %6\n\t"
+        "v_fmac_f32_dpp %2, %5, %6 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mul_f32_e32 %3, %5, %6\n\t"
+        "s_nop 1\n\t"
+        "v_add_f32_dpp %3, %3, %5 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n\t"
+        "v_mov_b32_e32 %4, 0x7fc00000\n\t"
+        "s_nop 4\n\t"
+        "v_mul_f32_e32 %4, %5, %6\n\t"
+        "v_add_f32_dpp %4, %4, %5 quad_perm:[1,2,0,3] row_mask:0xf bank_mask:0xf\n\t"
+        "s_nop 4"
+        : "=&v"(a), "=&v"(r0), "=&v"(r1), "=&v"(r2), "=&v"(r3) : "v"(x), "v"(y));
+    out[t] = r0; out[64 + t] = r1; out[128 + t] = r2; out[192 + t] = r3; out[256 + t] = a;
+}
+
+extern "C" int lg_dpp_kat(const float *in_host, float *out_host) {
+    if (!in_host || !out_host) return fail("lg_dpp_kat: null argument");
+    float *d = nullptr;
+    HIPCHK(hipMalloc(&d, (128 + 320) * sizeof(float)));
+    HIPCHK(hipMemcpy(d, in_host, 128 * sizeof(float), hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(dpp_kat_kernel, dim3(1), dim3(64), 0, 0, d, d + 128);
+    hipError_t e = hipMemcpy(out_host, d + 128, 320 * sizeof(float), hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return fail(std::string("lg_dpp_kat: ") + hipGetErrorString(e));
+    return 0;
+}
+
 extern "C" const char *lg_last_kernel(LgHandle h) { return h ? h->last_kernel.c_str() : ""; }
 
 extern "C" int lg_obs_window(LgHandle h, int32_t *first_frame) {

@@ -409,6 +409,10 @@ int lg_terrain_generate(const LgTerrainTile *tiles, int32_t n_tiles, const doubl
                         void *stream);
 /* Diagnostic: one Philox4x32-10 block computed on the device by the kernel's own generator (known-answer tests). */
 int lg_philox(const uint32_t counter[4], const uint32_t key[2], uint32_t out[4]);
+/* Known-answer test of the DPP operand behaviour the build's hazard pass relies on (hcr_genesis_lr_cl_amd/dpp_hazard_pass.py; no
+ * reference counterpart).  in: 64 x then 64 y (host); out: 5 x 64 floats (host) -- rot1(x) + x y with the product written in the slot
+ * before | x y + rot1(x) y likewise (fused) | rot1(x y) + x behind the two wait states | the same without them (negative control) | x y. */
+int lg_dpp_kat(const float *in_host, float *out_host);
 const char *lg_last_error(void);
 int lg_abi_version(void);
 
