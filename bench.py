@@ -611,12 +611,15 @@ def main():
     timer_regions = list(range(n_rep)) if n_rep < 3 else [0]
     if args.kernel_timer_stride <= 0:
         timer_regions = []
+    # at least ~10 samples in the sampled region, so that its first launch (right behind a synchronize: up to 10 us slower) does not
+    # dominate the mean of a short region -- the driver's 20 steps are timed at every 2nd step, the default 2000 at every 8th
+    timer_stride = max(1, min(args.kernel_timer_stride, args.steps // 10)) if args.kernel_timer_stride > 0 else 0
     # R timed regions of `--steps` steps each after the one warm-up, median reported.  A region is bracketed by a
     # barrier + synchronize on both sides and its time is the maximum over ranks, as the contract says for "the" timed region
     region_s, region_dev_ms = [], []
     step_i = args.warmup
     for rep in range(max(args.repeats, 1)):
-        env._engine.profile(args.kernel_timer_stride if rep in timer_regions else 0)     # stride 0 = off; samples taken so far are kept
+        env._engine.profile(timer_stride if rep in timer_regions else 0)     # stride 0 = off; samples taken so far are kept
         if dist is not None:
             dist.barrier()
         torch.cuda.synchronize()
@@ -692,7 +695,7 @@ def main():
                          "peak_measured": peak_meas, "frac_of_measured": (achieved / peak_meas) if peak_meas else None,
                          "peak_measured_how": "lg_stream_copy: float4 grid-stride copy of 1 GiB x 20 on this device, (read + write) bytes / time",
                          "kernel": layout, "launch_us": launch_s * 1e6, "samples": kern_n,
-                         "timer": {"stride": args.kernel_timer_stride, "sampled_regions": timer_regions, "regions": n_rep,
+                         "timer": {"stride": timer_stride, "sampled_regions": timer_regions, "regions": n_rep,
                                    "note": "HIP events attached to the dispatch of every stride-th step, in the listed timed regions only (a timed launch costs ~10 us of bubble; the median region carries none when regions >= 3)"},
                          "step_device_us": dev_ms * 1e3 / args.steps,
                          "algorithmic_bytes_per_launch": bytes_env * n_local,
